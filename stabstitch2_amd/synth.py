@@ -1,0 +1,141 @@
+"""Deterministic synthetic inputs and checkpoints.
+
+The reference tree holds no pretrained weights and no sample video (SURVEY.md table of
+facts), and the build box has no network, so benchmarks, smoke tests and parity tests run on
+  * an analytic multi-sinusoid texture viewed through two (or three) shaking, horizontally
+    offset windows (SURVEY.md §8d "synthetic inputs"), and
+  * checkpoints filled per key from `RandomState(crc32(key))`, in the reference's
+    `{'model': state_dict}` layout (`spatial_warp.pth`, `temporal_warp.pth`, `smooth_warp.pth`,
+    Full_model_inference/README.md:2-6), with the stage-1 head biased so that view 2 lands
+    0.45 W to the right of view 1 (non-degenerate ~1.45 W canvas).
+Nothing here is on the timed path.
+"""
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LR_H, LR_W = 360, 480
+
+
+# --------------------------------------------------------------------------- texture / clips
+def _texture_table():
+    rs = np.random.RandomState(1234)
+    amp = rs.uniform(8.0, 24.0, size=8)
+    period = np.exp(rs.uniform(np.log(16.0), np.log(300.0), size=8))
+    ang = rs.uniform(0.0, 2 * np.pi, size=8)
+    fx = np.cos(ang) / period
+    fy = np.sin(ang) / period
+    phase = rs.uniform(0.0, 2 * np.pi, size=(8, 3))
+    return amp, fx, fy, phase
+
+
+def texture_window(x0, y0, height, width):
+    """[3,H,W] fp32 BGR-like texture, 0..255, sampled at pixel (x0 + c, y0 + r)."""
+    amp, fx, fy, phase = _texture_table()
+    xs = x0 + np.arange(width, dtype=np.float64)[None, :]
+    ys = y0 + np.arange(height, dtype=np.float64)[:, None]
+    out = np.full((3, height, width), 127.5, dtype=np.float64)
+    for k in range(8):
+        arg = 2 * np.pi * (fx[k] * xs + fy[k] * ys)
+        for c in range(3):
+            out[c] += amp[k] * np.sin(arg + phase[k, c])
+    return np.clip(out, 0.0, 255.0).astype(np.float32)
+
+
+def _ar1(rs, n, sigma, rho=0.9):
+    s = np.zeros(n)
+    for t in range(1, n):
+        s[t] = rho * s[t - 1] + rs.normal(0.0, sigma * np.sqrt(1 - rho * rho))
+    return s
+
+
+def to_lr(hr):
+    """[1,3,H,W] 0..255 -> [1,3,360,480] in [-1,1] (bilinear, half-pixel centres)."""
+    if hr.shape[2] == LR_H and hr.shape[3] == LR_W:
+        lr = hr
+    else:
+        lr = F.interpolate(hr, size=(LR_H, LR_W), mode='bilinear', align_corners=False)
+    return lr / 127.5 - 1.0
+
+
+def make_clip(n_frames, height, width, seed=0, views=2):
+    """-> (hr_lists, lr_lists): per view a list of n_frames tensors [1,3,H,W] / [1,3,360,480]."""
+    rs = np.random.RandomState(1000 + seed)
+    sigma = 1.5 * height / 360.0
+    x0, y0 = 40.0 + 13.0 * seed, 30.0 + 7.0 * seed
+    hr_lists, lr_lists = [], []
+    for v in range(views):
+        sx = _ar1(rs, n_frames, sigma)
+        sy = _ar1(rs, n_frames, sigma)
+        hrs, lrs = [], []
+        for t in range(n_frames):
+            fr = texture_window(x0 + 0.45 * width * v + sx[t], y0 + sy[t], height, width)
+            hr = torch.from_numpy(fr).unsqueeze(0)
+            hrs.append(hr)
+            lrs.append(to_lr(hr))
+        hr_lists.append(hrs)
+        lr_lists.append(lrs)
+    return hr_lists, lr_lists
+
+
+# --------------------------------------------------------------------------- checkpoints
+def _rs(key):
+    return np.random.RandomState(zlib.crc32(key.encode()) & 0x7FFFFFFF)
+
+
+def _fill(key, ref):
+    """One tensor of a synthetic checkpoint; `ref` gives shape/dtype."""
+    rs = _rs(key)
+    shape = tuple(ref.shape)
+    leaf = key.rsplit('.', 1)[-1]
+    if leaf == 'num_batches_tracked':
+        return torch.tensor(100, dtype=torch.long)
+    if leaf == 'running_var':
+        return torch.from_numpy((np.abs(rs.normal(0, 1, shape)) * 0.5 + 0.5).astype(np.float32))
+    if leaf == 'running_mean':
+        return torch.from_numpy(rs.normal(0, 0.1, shape).astype(np.float32))
+    is_bn = len(shape) == 1 and ('bn' in key or 'downsample.1' in key or key.endswith('stage1.1.' + leaf))
+    if is_bn:
+        if leaf == 'weight':
+            return torch.from_numpy(rs.uniform(0.8, 1.2, shape).astype(np.float32))
+        return torch.from_numpy(rs.normal(0, 0.1, shape).astype(np.float32))
+    if leaf == 'bias':
+        return torch.from_numpy(rs.normal(0, 0.02, shape).astype(np.float32))
+    fan_in = int(np.prod(shape[1:]))
+    gain = 2.0
+    # heads: keep the regressed motions at a few pixels
+    if key.startswith('regressNet1_part2.4'):
+        gain = 0.03
+    elif '_part2_ref.4' in key or '_part2_tgt.4' in key:
+        gain = 0.016
+    elif key.startswith('regressNet2_part2.4'):
+        gain = 0.005
+    if key.startswith('MotionPre.embedding1'):
+        return torch.from_numpy(rs.normal(0, 0.004, shape).astype(np.float32))
+    if key.startswith('MotionPre.embedding3'):
+        return torch.from_numpy(rs.normal(0, 0.3, shape).astype(np.float32))
+    if key.startswith('MotionPre.decoding'):
+        gain = 0.5
+    return torch.from_numpy(rs.normal(0, np.sqrt(gain / fan_in), shape).astype(np.float32))
+
+
+def synthetic_state_dict(module, view_shift_px=-216.0):
+    """Fill every entry of `module.state_dict()` deterministically (same values for any module
+    with the same key layout: reference, oracle or HIP-backed)."""
+    sd = {}
+    for key, ref in module.state_dict().items():
+        sd[key] = _fill(key, ref).to(ref.dtype)
+    k = 'regressNet1_part2.4.bias'
+    if k in sd and view_shift_px is not None:
+        sd[k] = torch.tensor([view_shift_px, 0.0] * 4, dtype=torch.float32)
+    return sd
+
+
+def write_synthetic_checkpoints(model_dir, spatial, temporal, smooth):
+    """spatial_warp.pth / temporal_warp.pth / smooth_warp.pth in the reference layout."""
+    import os
+    os.makedirs(model_dir, exist_ok=True)
+    for name, mod in (('spatial_warp', spatial), ('temporal_warp', temporal), ('smooth_warp', smooth)):
+        torch.save({'model': synthetic_state_dict(mod)}, os.path.join(model_dir, name + '.pth'))

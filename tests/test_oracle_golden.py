@@ -1,0 +1,210 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_goldens.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import geometry as G, samplers as S, nets as N, pipeline as P, metrics as M
+from stabstitch2_amd import synth
+
+torch.set_grad_enabled(False)
+
+
+def close(a, b, tol, what=''):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+    assert err <= tol, '%s max|diff| %.3e > %.1e' % (what, err, tol)
+
+
+@pytest.fixture(scope='module')
+def nets():
+    sp, tp, sm = N.SpatialNet().eval(), N.TemporalNet().eval(), N.SmoothNet().eval()
+    for m in (sp, tp, sm):
+        m.load_state_dict(synth.synthetic_state_dict(m), strict=True)
+    return sp, tp, sm
+
+
+def test_state_dict_layout(nets):
+    # tensor counts of SURVEY.md §8b
+    assert [len(m.state_dict()) for m in nets] == [130, 104, 14]
+
+
+def test_g1_dlt_decomposition(golden):
+    g = golden('g1_dlt')
+    off = cases.g1_offsets()
+    for tag, scale in (('full', 1.0), ('feat', 8.0)):
+        H, H_tgt, H_ref = G.decompose(off, 360, 480, scale)
+        # homographies are compared through their action on the image corners (px)
+        for name, mat in (('H_', H), ('H_tgt_', H_tgt), ('H_ref_', H_ref)):
+            ref = torch.from_numpy(g[name + tag])
+            pts = torch.tensor([[0., 0., 1.], [480., 0., 1.], [0., 360., 1.], [480., 360., 1.]]).T / \
+                torch.tensor([[scale], [scale], [1.0]])
+            a = mat @ pts
+            b = ref @ pts
+            close(a[:, :2] / a[:, 2:3], b[:, :2] / b[:, 2:3], 5e-2 / scale * 8, name + tag)
+    _, H_tgt, H_ref = G.decompose(off, 360, 480, 1.0)
+    rigid = G.rigid_mesh(off.shape[0], 360, 480)
+    close(rigid, g['rigid'], 0, 'rigid')
+    close(G.norm_mesh(rigid, 360, 480), g['norm_rigid'], 1e-6, 'norm_rigid')
+    close(G.homography_to_mesh(H_ref, rigid), g['mesh_ref'], 5e-2, 'mesh_ref')
+    close(G.homography_to_mesh(H_tgt, rigid), g['mesh_tgt'], 5e-2, 'mesh_tgt')
+
+
+def test_g2_homography_sampler(golden):
+    g = golden('g2_homo')
+    U, th = cases.g2_inputs()
+    close(S.homography_warp(U, th, (45, 60)), g['out'], 1e-4, 'homo')
+    close(S.homography_warp(U, th, (23, 31)), g['out_small'], 1e-4, 'homo_small')
+
+
+def test_g3_cost_volume(golden):
+    g = golden('g3_costvol')
+    a, b = cases.g3_inputs(False)
+    close(N.cost_volume(a, b, 5), g['cv5'], 1e-5, 'cv5')
+    close(N.cost_volume(a, b, 3), g['cv3'], 1e-5, 'cv3')
+    fa, fb = cases.g3_inputs(True)
+    f5 = N.cost_volume(fa, fb, 5)
+    f3 = N.cost_volume(fa, fb, 3)
+    close(f5[0, :, 22, :], g['full5_rows'], 1e-5, 'full5 rows')
+    close(f3[0, :, 0, :], g['full3_rows'], 1e-5, 'full3 rows')
+    close(f5.sum(dim=(2, 3)), g['full5_chsum'], 2e-3, 'full5 channel sums')
+    close(f3.sum(dim=(2, 3)), g['full3_chsum'], 2e-3, 'full3 channel sums')
+
+
+def test_g4_ccl(golden):
+    g = golden('g4_ccl')
+    a, b = cases.g4_inputs(False)
+    close(N.ccl(a, b), g['flow'], 1e-4, 'ccl small')
+    fa, fb = cases.g4_inputs(True)
+    close(N.ccl(fa, fb), g['flow_full'], 1e-4, 'ccl full')
+
+
+def test_g5_tps_points(golden):
+    g = golden('g5_tps_points')
+    nrigid, warped, query = cases.g5_meshes()
+    close(S.tps_points(query, nrigid, warped), g['p_a'], 1e-5, 'tps points (rigid->warped)')
+    close(S.tps_points(query, warped, nrigid), g['p_b'], 1e-5, 'tps points (warped->rigid)')
+
+
+def test_g6_tps_dense_warp(golden):
+    g = golden('g6_tps_warp')
+    U, src, tgt, size, ident = cases.g6_inputs()
+    wn = S.tps_warp(U, src, tgt, size, 'NORMAL')
+    wf = S.tps_warp(U, src, tgt, size, 'FAST')
+    # ramp channels 3,4 pin the sampling coordinates themselves (px) wherever the tap is interior
+    close(wn[:, 3:5], g['normal'][:, 3:5], 2e-4 * 96 / 2 + 1e-4, 'coords NORMAL')
+    close(wn[:, 0:3], g['normal'][:, 0:3], 2e-3, 'intensity NORMAL')
+    close(wf, g['fast'], 2e-3, 'FAST')
+    close(S.tps_warp(U, ident, tgt, (72, 96), 'NORMAL'), g['ident_normal'], 2e-3, 'identity NORMAL')
+    close(S.tps_warp(U, ident, tgt, (72, 96), 'FAST'), g['ident_fast'], 2e-3, 'identity FAST')
+
+
+def test_g7_fusion(golden):
+    g = golden('g7_fusion')
+    wm = torch.from_numpy(g['warped_with_mask'])
+    close(P.average_fusion(wm[0, 0:3], wm[1, 0:3]), g['average'], 1e-3, 'average')
+    close(P.linear_blender(wm[0:1, 0:3], wm[1:2, 0:3], wm[0:1, 3:4], wm[1:2, 3:4]), g['linear'], 1e-3, 'linear')
+    close(P.linear_blender(wm[0:1, 0:3], wm[1:2, 0:3], wm[0:1, 3:4], wm[1:2, 3:4], mask=True),
+          g['mask1'], 1e-5, 'mask1')
+
+
+@pytest.fixture(scope='module')
+def clip16():
+    return synth.make_clip(16, 360, 480, seed=0)
+
+
+@pytest.fixture(scope='module')
+def stages(nets, clip16):
+    sp, tp, sm = nets
+    _, lr = clip16
+    s1, s2 = P.spatial_stage(sp, lr[0], lr[1])
+    t1 = P.temporal_stage(tp, lr[0])
+    t2 = P.temporal_stage(tp, lr[1])
+    smesh1, ts1 = P.tsmotion_prepare(s1, t1)
+    smesh2, ts2 = P.tsmotion_prepare(s2, t2)
+    acc = P.smooth_stage(sm, ts1, ts2, smesh1, smesh2)
+    return dict(s1=s1, s2=s2, t1=t1, t2=t2, ts1=ts1, ts2=ts2, smesh1=smesh1, smesh2=smesh2, acc=acc)
+
+
+def test_g8_nets(golden, nets, clip16, stages):
+    g = golden('g8_nets')
+    sp, tp, sm = nets
+    _, lr = clip16
+    o1, o2r, o2t = sp(lr[0][0], lr[1][0])
+    close(o1, g['offset_1'], 1e-3, 'offset_1')
+    close(o2r, g['offset_2_ref'], 1e-3, 'offset_2_ref')
+    close(o2t, g['offset_2_tgt'], 1e-3, 'offset_2_tgt')
+    st = stages
+    close(torch.cat(st['s1'], 0), g['motion1'], 5e-2, 'motion1')
+    close(torch.cat(st['s2'], 0), g['motion2'], 5e-2, 'motion2')
+    close(torch.cat(st['t1'], 0), g['tmotion1'], 1e-3, 'tmotion1')
+    close(torch.cat(st['t2'], 0), g['tmotion2'], 1e-3, 'tmotion2')
+    close(torch.cat(st['ts1'], 0), g['tsmotion1'], 5e-2, 'tsmotion1')
+    close(torch.cat(st['ts2'], 0), g['tsmotion2'], 5e-2, 'tsmotion2')
+    a = list(st['ts1'][0:7]); a[0] = a[0] * 0
+    b = list(st['ts2'][0:7]); b[0] = b[0] * 0
+    w0 = N.build_SmoothNet(sm, a, b, st['smesh1'][0:7], st['smesh2'][0:7])
+    for k, v in w0.items():
+        close(v, g['w0_' + k], 5e-2, 'window0 ' + k)
+    # eval-mode batch invariance of the oracle nets (lets the HIP path batch frames)
+    bo = sp(torch.cat(lr[0][0:3], 0), torch.cat(lr[1][0:3], 0))
+    close(bo[0][0:1], o1, 1e-3, 'batched offset_1')
+    close(bo[1][0:1], o2r, 1e-3, 'batched offset_2_ref')
+
+
+def test_g9_pipeline(golden, clip16, stages):
+    g = golden('g9_pipeline')
+    hr, lr = clip16
+    acc = stages['acc']
+    close(acc['smooth_mesh1'], g['smooth_mesh1'], 5e-2, 'smooth_mesh1')
+    close(acc['smooth_mesh2'], g['smooth_mesh2'], 5e-2, 'smooth_mesh2')
+    close(acc['ori_path2'], g['ori_path2'], 5e-2, 'ori_path2')
+    close(acc['smooth_path2'], g['smooth_path2'], 5e-2, 'smooth_path2')
+    # render with the GOLDEN meshes so that canvas truncation cannot flip on a 1e-2 px mesh delta
+    m1 = torch.from_numpy(g['smooth_mesh1'])
+    m2 = torch.from_numpy(g['smooth_mesh2'])
+    for wm, fm in (('NORMAL', 'AVERAGE'), ('FAST', 'AVERAGE'), ('NORMAL', 'LINEAR')):
+        tag = '%s_%s' % (wm.lower(), fm.lower())
+        frames, ow, oh = P.get_stable_sqe(hr[0][:4], hr[1][:4], m1, m2, wm, fm)
+        assert [int(oh), int(ow)] == list(g['canvas_' + tag])
+        got = np.stack([cases.box_down(f, 16) for f in frames])
+        close(got, g['frames_' + tag][:4], 2e-2, 'frames ' + tag)
+        if tag == 'normal_average':
+            close(frames[0][150:214, 300:396], g['frame0_crop'], 5e-2, 'frame0 crop')
+    w1 = M.warp_lr_with_mask(lr[0][:4], m1)
+    w2 = M.warp_lr_with_mask(lr[1][:4], m2)
+    for i in range(4):
+        p, s = M.alignment_psnr_ssim(w1[i], w2[i])
+        assert abs(p - g['psnr'][i]) < 0.01, (p, g['psnr'][i])
+        assert abs(s - g['ssim'][i]) < 1e-3, (s, g['ssim'][i])
+    close(cases.box_down(w1[3], 4), g['lr_warp1_frame3'], 2e-2, 'lr warp')
+    assert abs(M.stability_score(torch.from_numpy(g['smooth_path2'])) - float(g['stability'])) < 1e-4
+    assert abs(M.distortion_score(m2) - float(g['distortion'])) < 1e-5
+
+
+def test_g10_three_view(golden):
+    g = golden('g10_threeview')
+    m12_1, m12_2, m23_1, m23_2 = cases.g10_meshes()
+    n = m12_1.shape[1]
+    hr, _ = synth.make_clip(n, 180, 320, seed=3, views=3)
+    mesh1, mid, mesh3 = P.three_view_compose(m12_1, m12_2, m23_1, m23_2, 180, 320)
+    close(mesh1, g['mesh1'], 5e-2, 'mesh1')
+    close(mid, g['middle'], 5e-2, 'middle')
+    close(mesh3, g['mesh3'], 5e-2, 'mesh3')
+    for fm in ('AVERAGE', 'LINEAR'):
+        frames, ow, oh = P.three_view_render(hr[0], hr[1], hr[2], torch.from_numpy(g['mesh1']),
+                                             torch.from_numpy(g['middle']), torch.from_numpy(g['mesh3']),
+                                             'NORMAL', fm)
+        assert [int(oh), int(ow)] == list(g['canvas_' + fm.lower()])
+        got = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), 4) for f in frames])
+        close(got, g['frames_' + fm.lower()], 5e-2, 'three-view ' + fm)
+
+
+def test_g11_psnr_ssim(golden):
+    g = golden('g11_metrics')
+    a, b = cases.g11_images()
+    assert abs(M.psnr(a, b) - float(g['psnr'])) < 1e-6
+    assert abs(M.ssim(a, b) - float(g['ssim'])) < 1e-6
