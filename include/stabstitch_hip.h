@@ -1,0 +1,161 @@
+/* libstabstitch_hip.so -- C ABI of the MI355X (gfx950) StabStitch++ inference hot path.
+ *
+ * The reference (nie-lang/StabStitch2) has no FFI: its hot path is a chain of stock ATen ops
+ * behind a Python module API.  The Python modules of `stabstitch2_amd/` keep that API
+ *  and bind the entry points below through ctypes; each entry point names the
+ * reference code it replaces (paths relative to Full_model_inference/Codes of the reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless noted; the caller owns all buffers
+ *     (the library never allocates, never synchronises, never touches the default stream);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it;
+ *   - return value: SS_OK or a negative SS_ERR_* code (no exceptions cross the boundary);
+ *   - "nhwc" tensors are [N][T][H][W][C] with C fastest (T = 1 for 2-D); channel counts of conv
+ *     inputs must be multiples of 4 (pad with zero channels; weights carry matching zero taps);
+ *   - meshes are [.., 7, 9, 2] = 63 control points, (x, y) interleaved, as in the reference.
+ */
+#ifndef STABSTITCH_HIP_H
+#define STABSTITCH_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_OK 0
+#define SS_ERR_ARG (-1)          /* bad dimension / null pointer / unsupported combination */
+#define SS_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch */
+#define SS_ERR_UNSUPPORTED (-3)
+
+#define SS_WARP_NORMAL 0         /* the reference's clamped-index bilinear (utils/torch_tps_transform.py:30-106) */
+#define SS_WARP_FAST 1           /* F.grid_sample(bilinear, zeros, align_corners=True) (:158-162) */
+
+int ss_version(void);
+const char* ss_error_string(int code);
+
+/* ---- layout plumbing (replaces the implicit NCHW tensors of the reference modules) ---------- */
+/* [n][c][h][w] -> [n][h][w][c_pad], channels c..c_pad-1 written as 0 */
+int ss_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream);
+/* [n][h][w][c_stride] (first c channels) -> [n][c][h][w] */
+int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, int c_stride, void* stream);
+
+/* ---- K1/K2/K4/K11: convolution as fp32-MFMA implicit GEMM ------------------------------------
+ * Replaces nn.Conv2d(+BatchNorm2d eval)(+residual)(+ReLU) of the ResNet-18 trunk
+ * (spatial_network.py:123-139), the regressor convs (spatial_network.py:147-209,
+ * temporal_network.py:65-93) and nn.Conv3d of SmoothNet (smooth_network.py:123-131).
+ *   in   [n][t][h][w][cin]            cin % 4 == 0
+ *   wgt  [cout][kt][kh][kw][cin]      (BN folded by the caller)
+ *   bias [cout] or NULL, res (same shape as out) or NULL
+ *   out  [n][to][ho][wo][out_cs]      first cout channels written (out_cs >= cout)
+ * stride applies to h and w (temporal stride is 1).  `groups` > 1 runs `groups` independent
+ * problems with element strides in_gs / w_gs / out_gs between them (used by the CCL Gram). */
+int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const float* res, float* out,
+                 int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw, int stride,
+                 int pad_t, int pad_h, int pad_w, int relu, int out_cs,
+                 int groups, long long in_gs, long long w_gs, long long out_gs, void* stream);
+
+/* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */
+int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
+                    void* stream);
+
+/* K5: nn.Linear (+ReLU): y[m][nout] = x[m][k] . w[nout][k] + b  (spatial_network.py:170-178, 211-219) */
+int ss_linear(const float* x, const float* w, const float* b, float* y, int m, int k, int nout, int relu,
+              void* stream);
+
+/* ---- K3: contextual correlation layer (spatial_network.py:369-425) ---------------------------
+ * f1, f2 nhwc [n][h][w][c]; flow out NCHW [n][2][h][w] (ch0 = dx, ch1 = dy).
+ * ws: caller workspace of ss_ccl_workspace_floats(n,h,w,c) floats. */
+long long ss_ccl_workspace_floats(int n, int h, int w, int c);
+int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float* flow_nhwc4, int n, int h, int w, int c,
+           float softmax_scale, float* ws, void* stream);
+
+/* ---- K8: cost volume (spatial_network.py:333-358, temporal_network.py:149-174) ---------------
+ * x1, x2 nhwc [n][h][w][c]; out nhwc [n][h][w][out_cs], channel j*(2r+1)+i, channels >= (2r+1)^2
+ * written as 0.  out[.,y,x,d] = leaky_relu_0.1(mean_c x1[y,x,c] * x2[y+j-r, x+i-r, c]). */
+int ss_cost_volume(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
+                   int out_cs, void* stream);
+
+/* ---- K6: 4-point DLT, bidirectional decomposition, H -> mesh (fp64 on device) -----------------
+ * ss_tensor_dlt: utils/torch_DLT.py:17-45; src, dst [n][4][2] -> H [n][3][3]. */
+int ss_tensor_dlt(const float* src, const float* dst, float* H, int n, void* stream);
+/* spatial_network.py:291-312: offset_1 [n][8] at image size (img_h, img_w), feature scale 8 ->
+ * normalised homographies theta_ref = M^-1 H_ref M, theta_tgt = M^-1 H_tgt M, each [n][3][3]. */
+int ss_spatial_decompose(const float* offset8, float* theta_ref, float* theta_tgt, int n, float img_h,
+                         float img_w, void* stream);
+/* spatial_network.py:63-118 (build_SpatialNet tail): offset_1 [n][8], offset_2_ref/tgt [n][126] ->
+ * motion1, motion2 [n][7][9][2] (mesh - rigid). */
+int ss_spatial_meshes(const float* offset8, const float* off_ref, const float* off_tgt, float* motion1,
+                      float* motion2, int n, float img_h, float img_w, void* stream);
+
+/* ---- K7: homography sampler (utils/torch_homo_transform.py:6-184) ----------------------------
+ * theta [n][3][3]; nhwc variant for the 1/8 feature maps, nchw variant = the reference API. */
+int ss_homo_warp_nhwc(const float* in, const float* theta, float* out, int n, int h, int w, int c,
+                      int out_h, int out_w, void* stream);
+int ss_homo_warp_nchw(const float* in, const float* theta, float* out, int n, int c, int h, int w,
+                      int out_h, int out_w, void* stream);
+
+/* ---- K9/K10: thin-plate spline (utils/torch_tps_transform.py:168-226,
+ *      utils/torch_tps_transform_point.py:21-125) -------------------------------------------- */
+/* source, target [n][63][2] (normalised) -> T [n][2][66]; fp32 kernel matrix, fp64 solve. */
+int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream);
+/* point [n][q][2] evaluated through (source, T) -> out [n][q][2] */
+int ss_tps_points(const float* point, const float* source, const float* T, float* out, int n, int q,
+                  void* stream);
+/* test_online_tra.py:309-347 for one view, all frames at once: smotion, tmotion [n][63][2] (LR px)
+ * -> smesh [n][63][2] = rigid + smotion, tsmotion [n][63][2] (frame 0 = 0).
+ * ws: ss_tsmotion_workspace_floats(n) floats. */
+long long ss_tsmotion_workspace_floats(int n);
+int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
+                float img_h, float img_w, float* ws, void* stream);
+
+/* ---- K12/K13: dense TPS warp and fusion (utils/torch_tps_transform.py:108-165,
+ *      test_online_tra.py:34-58, 138-150) ----------------------------------------------------- */
+/* generic: U [b][c][h][w] NCHW, source [b][63][2], T [b][2][66] -> out [b][c][hc][wc] */
+int ss_tps_warp_nchw(const float* U, const float* source, const float* T, float* out, int b, int c, int h,
+                     int w, int hc, int wc, int mode, void* stream);
+/* same, plus one extra output channel = warp of an all-ones plane (the validity mask of
+ * test_online_tra.py:144-147): out [b][c+1][hc][wc] */
+int ss_tps_warp_mask_nchw(const float* U, const float* source, const float* T, float* out, int b, int c,
+                          int h, int w, int hc, int wc, int mode, void* stream);
+/* fused render of one stitched frame, AVERAGE fusion, 2 or 3 views (chained (1+2)+3):
+ * imgs: array of `views` device pointers (host array) to [3][h][w]; source [views][63][2];
+ * T [views][2][66]; out [3][hc][wc]. */
+int ss_render_average(const float* const* imgs, const float* source, const float* T, float* out, int views,
+                      int h, int w, int hc, int wc, int mode, void* stream);
+/* LINEAR fusion (linear_blender): ref, tgt [3][hc][wc]; ref_m, tgt_m [hc][wc]; out [3][hc][wc];
+ * mask1_out optional [hc][wc]; ws: ss_linear_blend_workspace_floats(hc, wc) floats. */
+long long ss_linear_blend_workspace_floats(int hc, int wc);
+int ss_linear_blend(const float* ref, const float* tgt, const float* ref_m, const float* tgt_m, float* out,
+                    float* mask1_out, int hc, int wc, float* ws, void* stream);
+
+/* ---- K14: canvas bounding box and mesh normalisation (test_online_tra.py:103-136) ------------
+ * mesh: n_points (x,y) pairs at LR scale (480x360); each is scaled to the HR frame as the reference
+ * does (x*img_w/480, y*img_h/360) before the min/max; img_w <= 0 / img_h <= 0 means the mesh is
+ * already in canvas pixels (three-view second canvas).  bbox (device) [4] = wmin, wmax, hmin, hmax;
+ * accumulate != 0 folds the existing bbox contents in (second view, more clips). */
+int ss_mesh_bbox(const float* mesh, int n_points, float img_h, float img_w, float* bbox, int accumulate,
+                 void* stream);
+/* out = norm(scale(mesh) - (wmin,hmin); Hc_f, Wc_f) with the float canvas size read from bbox on device */
+int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_points, float img_h,
+                      float img_w, void* stream);
+
+/* ---- K11: SmoothNet glue (smooth_network.py:64-157) ------------------------------------------
+ * smesh1/2, tsmotion1/2 [frames][63][2] (LR px).  Window wi covers frames wi*wstride .. +t-1
+ * (wstride = 1: the sliding window of test_online_tra.py:359-392 without materialising it;
+ * wstride = t: plain batch of windows).  tsflow = running sum of tsmotion inside the window; with
+ * zero_first != 0 the first tsmotion of every window counts as 0 (test_online_tra.py:362-366).
+ * embed: hidden nhwc [nw][t][7][9][128] =
+ *        relu(E1 smesh1) | relu(E3 tsflow1) | relu(E1 smesh2) | relu(E3 tsflow2);  e1w,e3w [32][2]; e1b,e3b [32]. */
+int ss_smooth_embed(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+                    const float* e1w, const float* e1b, const float* e3w, const float* e3b, float* hidden,
+                    int nw, int t, int wstride, int zero_first, void* stream);
+/* finalize: delta [nw][t][63][4] (decoder output) -> the 8 tensors of build_SmoothNet, each
+ * [nw][t][63][2]; any output pointer may be NULL. */
+int ss_smooth_finalize(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+                       const float* delta, float* ori_mesh1, float* ori_mesh2, float* ori_path1,
+                       float* ori_path2, float* smooth_mesh1, float* smooth_mesh2, float* smooth_path1,
+                       float* smooth_path2, int nw, int t, int wstride, int zero_first, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+// Shared helpers for libstabstitch_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stabstitch_hip.h"
+
+#define SS_GRID_H 6
+#define SS_GRID_W 8
+#define SS_NV 63   // (SS_GRID_H+1)*(SS_GRID_W+1) control points
+#define SS_NT 66   // SS_NV + 3 TPS coefficients per coordinate
+
+static inline int ss_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : SS_ERR_LAUNCH;
+}
+
+static inline int ss_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// exact n / d for n < 65536, 1 <= d < 65536:  q = umulhi(n, ceil(2^32 / d)); d == 1 -> mul = 0 (identity)
+static inline uint32_t ss_fastdiv_magic(uint32_t d) {
+    if (d <= 1) return 0u;
+    return (uint32_t)(((1ull << 32) + d - 1) / d);
+}
+__device__ __forceinline__ uint32_t ss_fastdiv(uint32_t n, uint32_t mul) {
+    return mul ? __umulhi(n, mul) : n;
+}
+
+__device__ __forceinline__ float ss_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float ss_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float ss_wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}

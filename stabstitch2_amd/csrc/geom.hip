@@ -1,0 +1,458 @@
+// Exact-math geometry kernels: 4-point DLT, bidirectional decomposition, H -> mesh, homography
+// sampler, thin-plate-spline solve / point evaluation, tsmotion composition, canvas bbox.
+// These are tiny (63-vertex meshes) but accuracy-critical: linear solves run in fp64 on device
+// (the reference's fp32 torch.inverse of the 8x8 DLT system is itself +-0.02 px);
+// everything the reference evaluates in fp32 (RBF kernel, normalisation, sampling) stays fp32
+// with the same operation order (no fma contraction where the reference has separate ops).
+#include "common.h"
+#include "device_math.h"
+
+// ------------------------------------------------------------------------------------------------
+// small dense helpers (fp64, one thread)
+__device__ void solve8(double A[8][9]) {   // in-place Gauss-Jordan with partial pivoting, solution in A[.][8]
+    for (int c = 0; c < 8; ++c) {
+        int piv = c;
+        double best = fabs(A[c][c]);
+        for (int r = c + 1; r < 8; ++r) {
+            double v = fabs(A[r][c]);
+            if (v > best) { best = v; piv = r; }
+        }
+        if (piv != c)
+            for (int k = 0; k < 9; ++k) { double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+        double inv = 1.0 / A[c][c];
+        for (int k = c; k < 9; ++k) A[c][k] *= inv;
+        for (int r = 0; r < 8; ++r) {
+            if (r == c) continue;
+            double f = A[r][c];
+            for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k];
+        }
+    }
+}
+
+// homography src -> dst from 4 correspondences (rows as utils/torch_DLT.py:29-38)
+__device__ void dlt4(const float sx[4], const float sy[4], const float dx[4], const float dy[4], double H[9]) {
+    double A[8][9];
+    for (int i = 0; i < 4; ++i) {
+        double x = sx[i], y = sy[i], u = dx[i], v = dy[i];
+        double* r0 = A[2 * i];
+        double* r1 = A[2 * i + 1];
+        r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -u * x; r0[7] = -u * y; r0[8] = u;
+        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -v * x; r1[7] = -v * y; r1[8] = v;
+    }
+    solve8(A);
+    for (int i = 0; i < 8; ++i) H[i] = A[i][8];
+    H[8] = 1.0;
+}
+
+__device__ void inv3(const double m[9], double o[9]) {
+    double c0 = m[4] * m[8] - m[5] * m[7];
+    double c1 = m[5] * m[6] - m[3] * m[8];
+    double c2 = m[3] * m[7] - m[4] * m[6];
+    double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
+    double id = 1.0 / det;
+    o[0] = c0 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c1 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c2 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+__device__ void mul3(const double a[9], const double b[9], double o[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+// H, H_tgt, H_ref for one offset (spatial_network.py:72-93 / :291-300), corner points / scale in fp32
+__device__ void decompose(const float* off, float img_h, float img_w, float scale, double H[9], double Ht[9],
+                          double Hr[9]) {
+    const float cx[4] = {0.f, img_w, 0.f, img_w};
+    const float cy[4] = {0.f, 0.f, img_h, img_h};
+    float sx[4], sy[4], dx[4], dy[4], hx[4], hy[4];
+    for (int i = 0; i < 4; ++i) {
+        float mx = off[2 * i], my = off[2 * i + 1];
+        sx[i] = cx[i] / scale;
+        sy[i] = cy[i] / scale;
+        dx[i] = __fadd_rn(cx[i], mx) / scale;
+        dy[i] = __fadd_rn(cy[i], my) / scale;
+        hx[i] = __fadd_rn(cx[i], mx / 2.f) / scale;
+        hy[i] = __fadd_rn(cy[i], my / 2.f) / scale;
+    }
+    dlt4(sx, sy, dx, dy, H);
+    dlt4(sx, sy, hx, hy, Ht);
+    double Hi[9];
+    inv3(H, Hi);
+    mul3(Hi, Ht, Hr);
+}
+
+__global__ void tensor_dlt_kernel(const float* __restrict__ src, const float* __restrict__ dst, float* __restrict__ H,
+                                  int n) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    float sx[4], sy[4], dx[4], dy[4];
+    for (int i = 0; i < 4; ++i) {
+        sx[i] = src[b * 8 + 2 * i]; sy[i] = src[b * 8 + 2 * i + 1];
+        dx[i] = dst[b * 8 + 2 * i]; dy[i] = dst[b * 8 + 2 * i + 1];
+    }
+    double h[9];
+    dlt4(sx, sy, dx, dy, h);
+    for (int i = 0; i < 9; ++i) H[b * 9 + i] = (float)h[i];
+}
+
+extern "C" int ss_tensor_dlt(const float* src, const float* dst, float* H, int n, void* stream) {
+    if (!src || !dst || !H || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(tensor_dlt_kernel, dim3(ss_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, src, dst, H, n);
+    return ss_launch_status();
+}
+
+__global__ void spatial_decompose_kernel(const float* __restrict__ off, float* __restrict__ th_ref,
+                                         float* __restrict__ th_tgt, int n, float img_h, float img_w) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    double H[9], Ht[9], Hr[9];
+    decompose(off + b * 8, img_h, img_w, 8.f, H, Ht, Hr);
+    // theta = M^-1 H M,  M = [[w/2,0,w/2],[0,h/2,h/2],[0,0,1]] at feature size (w,h) = (img_w/8, img_h/8)
+    double fw = (double)(img_w / 8.f / 2.f), fh = (double)(img_h / 8.f / 2.f);
+    double M[9] = {fw, 0, fw, 0, fh, fh, 0, 0, 1};
+    double Mi[9] = {1.0 / fw, 0, -1.0, 0, 1.0 / fh, -1.0, 0, 0, 1};
+    double t[9], o[9];
+    mul3(Mi, Hr, t); mul3(t, M, o);
+    for (int i = 0; i < 9; ++i) th_ref[b * 9 + i] = (float)o[i];
+    mul3(Mi, Ht, t); mul3(t, M, o);
+    for (int i = 0; i < 9; ++i) th_tgt[b * 9 + i] = (float)o[i];
+}
+
+extern "C" int ss_spatial_decompose(const float* offset8, float* theta_ref, float* theta_tgt, int n, float img_h,
+                                    float img_w, void* stream) {
+    if (!offset8 || !theta_ref || !theta_tgt || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(spatial_decompose_kernel, dim3(ss_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, offset8,
+                       theta_ref, theta_tgt, n, img_h, img_w);
+    return ss_launch_status();
+}
+
+__device__ __forceinline__ void rigid_vertex(int v, float img_h, float img_w, float& x, float& y) {
+    int i = v / (SS_GRID_W + 1), j = v - i * (SS_GRID_W + 1);
+    x = linspace_at(0.f, img_w, SS_GRID_W + 1, j);
+    y = linspace_at(0.f, img_h, SS_GRID_H + 1, i);
+}
+
+// one block (64 threads) per batch item; thread v < 63 = vertex
+__global__ void spatial_meshes_kernel(const float* __restrict__ off, const float* __restrict__ off_ref,
+                                      const float* __restrict__ off_tgt, float* __restrict__ motion1,
+                                      float* __restrict__ motion2, float img_h, float img_w) {
+    __shared__ double sHr[9], sHt[9];
+    int b = blockIdx.x, v = threadIdx.x;
+    if (v == 0) {
+        double H[9], Ht[9], Hr[9], inv[9];
+        decompose(off + b * 8, img_h, img_w, 1.f, H, Ht, Hr);
+        inv3(Hr, inv);
+        for (int i = 0; i < 9; ++i) sHr[i] = inv[i];
+        inv3(Ht, inv);
+        for (int i = 0; i < 9; ++i) sHt[i] = inv[i];
+    }
+    __syncthreads();
+    if (v >= SS_NV) return;
+    float rx, ry;
+    rigid_vertex(v, img_h, img_w, rx, ry);
+    for (int which = 0; which < 2; ++which) {
+        const double* Hi = which ? sHt : sHr;
+        double X = Hi[0] * rx + Hi[1] * ry + Hi[2];
+        double Y = Hi[3] * rx + Hi[4] * ry + Hi[5];
+        double Z = Hi[6] * rx + Hi[7] * ry + Hi[8];
+        float mx = (float)(X / Z), my = (float)(Y / Z);
+        const float* o2 = (which ? off_tgt : off_ref) + (long long)b * 126 + v * 2;
+        float* out = (which ? motion2 : motion1) + (long long)b * 126 + v * 2;
+        out[0] = __fsub_rn(__fadd_rn(mx, o2[0]), rx);
+        out[1] = __fsub_rn(__fadd_rn(my, o2[1]), ry);
+    }
+}
+
+extern "C" int ss_spatial_meshes(const float* offset8, const float* off_ref, const float* off_tgt, float* motion1,
+                                 float* motion2, int n, float img_h, float img_w, void* stream) {
+    if (!offset8 || !off_ref || !off_tgt || !motion1 || !motion2 || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(spatial_meshes_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, offset8, off_ref, off_tgt,
+                       motion1, motion2, img_h, img_w);
+    return ss_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool NHWC>
+__global__ void homo_warp_kernel(const float* __restrict__ in, const float* __restrict__ theta,
+                                 float* __restrict__ out, int n, int c, int h, int w, int oh, int ow) {
+    // NHWC: thread = (pixel, channel quad); NCHW: thread = (pixel), loops channels
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int cq = NHWC ? c / 4 : 1;
+    long long total = (long long)n * oh * ow * cq;
+    if (idx >= total) return;
+    int q = (int)(idx % cq);
+    long long pix = idx / cq;
+    int x = (int)(pix % ow);
+    long long r2 = pix / ow;
+    int y = (int)(r2 % oh);
+    int b = (int)(r2 / oh);
+    const float* th = theta + b * 9;
+    float gx = linspace_at(-1.f, 1.f, ow, x), gy = linspace_at(-1.f, 1.f, oh, y);
+    float xs = fmaf(th[2], 1.f, fmaf(th[1], gy, th[0] * gx));
+    float ys = fmaf(th[5], 1.f, fmaf(th[4], gy, th[3] * gx));
+    float ts = fmaf(th[8], 1.f, fmaf(th[7], gy, th[6] * gx));
+    if (!(fabsf(ts) >= 1e-7f)) ts = __fadd_rn(ts, 1e-6f);
+    float xn = xs / ts, yn = ys / ts;
+    SsTaps t = taps_normal(xn, yn, w, h);
+    if (NHWC) {
+        const float4* base = reinterpret_cast<const float4*>(in) + (long long)b * h * w * cq;
+        float4 a = base[((long long)t.y0 * w + t.x0) * cq + q];
+        float4 bb = base[((long long)t.y1 * w + t.x0) * cq + q];
+        float4 cc = base[((long long)t.y0 * w + t.x1) * cq + q];
+        float4 d = base[((long long)t.y1 * w + t.x1) * cq + q];
+        float4 o;
+        o.x = blend4(t, a.x, bb.x, cc.x, d.x);
+        o.y = blend4(t, a.y, bb.y, cc.y, d.y);
+        o.z = blend4(t, a.z, bb.z, cc.z, d.z);
+        o.w = blend4(t, a.w, bb.w, cc.w, d.w);
+        reinterpret_cast<float4*>(out)[idx] = o;
+    } else {
+        long long hw = (long long)h * w, ohw = (long long)oh * ow;
+        for (int ch = 0; ch < c; ++ch) {
+            const float* pl = in + ((long long)b * c + ch) * hw;
+            float v = blend4(t, pl[(long long)t.y0 * w + t.x0], pl[(long long)t.y1 * w + t.x0],
+                             pl[(long long)t.y0 * w + t.x1], pl[(long long)t.y1 * w + t.x1]);
+            out[((long long)b * c + ch) * ohw + (long long)y * ow + x] = v;
+        }
+    }
+}
+
+extern "C" int ss_homo_warp_nhwc(const float* in, const float* theta, float* out, int n, int h, int w, int c,
+                                 int out_h, int out_w, void* stream) {
+    if (!in || !theta || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || out_h < 2 || out_w < 2)
+        return SS_ERR_ARG;
+    long long total = (long long)n * out_h * out_w * (c / 4);
+    hipLaunchKernelGGL((homo_warp_kernel<true>), dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       theta, out, n, c, h, w, out_h, out_w);
+    return ss_launch_status();
+}
+
+extern "C" int ss_homo_warp_nchw(const float* in, const float* theta, float* out, int n, int c, int h, int w,
+                                 int out_h, int out_w, void* stream) {
+    if (!in || !theta || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || out_h < 2 || out_w < 2) return SS_ERR_ARG;
+    long long total = (long long)n * out_h * out_w;
+    hipLaunchKernelGGL((homo_warp_kernel<false>), dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       theta, out, n, c, h, w, out_h, out_w);
+    return ss_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// TPS: 66x66 system [[P,R],[0,P^T]] assembled in fp32 as the reference does, solved in fp64.
+#define TPS_LD 68
+// one block of 256 threads per system; src_stride = 0 shares one source mesh across the batch
+__global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
+                                                        const float* __restrict__ target,
+                                                        float* __restrict__ T) {
+    __shared__ double A[SS_NT][TPS_LD];
+    __shared__ float sx[SS_NV], sy[SS_NV];
+    __shared__ int s_piv;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* src = source + (long long)b * src_stride;
+    const float* tgt = target + (long long)b * SS_NV * 2;
+    if (tid < SS_NV) { sx[tid] = src[tid * 2]; sy[tid] = src[tid * 2 + 1]; }
+    __syncthreads();
+    for (int e = tid; e < SS_NT * TPS_LD; e += 256) {
+        int r = e / TPS_LD, c = e - r * TPS_LD;
+        double v = 0.0;
+        if (r < SS_NV) {
+            if (c == 0) v = 1.0;
+            else if (c == 1) v = sx[r];
+            else if (c == 2) v = sy[r];
+            else if (c < SS_NT) v = (double)tps_rbf(__fsub_rn(sx[r], sx[c - 3]), __fsub_rn(sy[r], sy[c - 3]));
+            else v = tgt[r * 2 + (c - SS_NT)];
+        } else if (c >= 3 && c < SS_NT) {
+            int k = r - SS_NV;
+            v = k == 0 ? 1.0 : (k == 1 ? (double)sx[c - 3] : (double)sy[c - 3]);
+        }
+        A[r][c] = v;
+    }
+    __syncthreads();
+    for (int col = 0; col < SS_NT; ++col) {
+        if (tid == 0) {
+            int piv = col;
+            double best = fabs(A[col][col]);
+            for (int r = col + 1; r < SS_NT; ++r) {
+                double v = fabs(A[r][col]);
+                if (v > best) { best = v; piv = r; }
+            }
+            s_piv = piv;
+        }
+        __syncthreads();
+        int piv = s_piv;
+        if (piv != col && tid < TPS_LD) {
+            double t = A[col][tid]; A[col][tid] = A[piv][tid]; A[piv][tid] = t;
+        }
+        __syncthreads();
+        double pinv = 1.0 / A[col][col];
+        // Gauss-Jordan: eliminate column `col` from every other row (columns > col only)
+        int ncols = TPS_LD - (col + 1);
+        for (int e = tid; e < SS_NT * ncols; e += 256) {
+            int r = e / ncols, c = col + 1 + (e - r * ncols);
+            if (r != col) A[r][c] -= (A[r][col] * pinv) * A[col][c];
+        }
+        __syncthreads();
+    }
+    if (tid < SS_NT) {
+        double d = A[tid][tid];
+        T[(long long)b * 2 * SS_NT + tid] = (float)(A[tid][SS_NT] / d);
+        T[(long long)b * 2 * SS_NT + SS_NT + tid] = (float)(A[tid][SS_NT + 1] / d);
+    }
+}
+
+extern "C" int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream) {
+    if (!source || !target || !T || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
+                       target, T);
+    return ss_launch_status();
+}
+
+__global__ void tps_points_kernel(const float* __restrict__ point, const float* __restrict__ source,
+                                  long long src_stride, const float* __restrict__ T, float* __restrict__ out, int q) {
+    __shared__ float sx[SS_NV], sy[SS_NV], Tx[SS_NT], Ty[SS_NT];
+    int b = blockIdx.y;
+    if (threadIdx.x < SS_NV) {
+        sx[threadIdx.x] = source[(long long)b * src_stride + threadIdx.x * 2];
+        sy[threadIdx.x] = source[(long long)b * src_stride + threadIdx.x * 2 + 1];
+    }
+    if (threadIdx.x < SS_NT) {
+        Tx[threadIdx.x] = T[(long long)b * 2 * SS_NT + threadIdx.x];
+        Ty[threadIdx.x] = T[(long long)b * 2 * SS_NT + SS_NT + threadIdx.x];
+    }
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+    float x = point[((long long)b * q + i) * 2], y = point[((long long)b * q + i) * 2 + 1];
+    float ox, oy;
+    tps_eval(sx, sy, Tx, Ty, x, y, ox, oy);
+    out[((long long)b * q + i) * 2] = ox;
+    out[((long long)b * q + i) * 2 + 1] = oy;
+}
+
+extern "C" int ss_tps_points(const float* point, const float* source, const float* T, float* out, int n, int q,
+                             void* stream) {
+    if (!point || !source || !T || !out || n <= 0 || q <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(tps_points_kernel, dim3(ss_cdiv(q, 128), n), dim3(128), 0, (hipStream_t)stream, point, source,
+                       (long long)SS_NV * 2, T, out, q);
+    return ss_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// tsmotion (test_online_tra.py:309-347), one view, all frames
+// ws layout: [nrigid 126][ntgt n*126][npts n*126][T n*132]
+__global__ void tsm_prepare_kernel(const float* __restrict__ smotion, const float* __restrict__ tmotion,
+                                   float* __restrict__ smesh, float* __restrict__ ws, int n, float img_h,
+                                   float img_w) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * SS_NV) return;
+    int k = idx / SS_NV, v = idx - k * SS_NV;
+    float rx, ry;
+    rigid_vertex(v, img_h, img_w, rx, ry);
+    float* nrigid = ws;
+    float* ntgt = ws + 126;
+    float* npts = ntgt + (long long)n * 126;
+    if (k == 0) { nrigid[v * 2] = norm1(rx, img_w); nrigid[v * 2 + 1] = norm1(ry, img_h); }
+    float smx = __fadd_rn(rx, smotion[idx * 2]), smy = __fadd_rn(ry, smotion[idx * 2 + 1]);
+    smesh[idx * 2] = smx;
+    smesh[idx * 2 + 1] = smy;
+    if (k + 1 < n) {   // target of frame k+1 = normalised spatial mesh of frame k
+        ntgt[(long long)(k + 1) * 126 + v * 2] = norm1(smx, img_w);
+        ntgt[(long long)(k + 1) * 126 + v * 2 + 1] = norm1(smy, img_h);
+    }
+    if (k == 0) { ntgt[v * 2] = norm1(rx, img_w); ntgt[v * 2 + 1] = norm1(ry, img_h); }   // unused, keep defined
+    npts[(long long)k * 126 + v * 2] = norm1(__fadd_rn(rx, tmotion[idx * 2]), img_w);
+    npts[(long long)k * 126 + v * 2 + 1] = norm1(__fadd_rn(ry, tmotion[idx * 2 + 1]), img_h);
+}
+
+__global__ void tsm_finish_kernel(const float* __restrict__ ws, const float* __restrict__ smesh,
+                                  float* __restrict__ tsmotion, int n, float img_h, float img_w) {
+    __shared__ float sx[SS_NV], sy[SS_NV], Tx[SS_NT], Ty[SS_NT];
+    int k = blockIdx.x, v = threadIdx.x;
+    const float* nrigid = ws;
+    const float* npts = ws + 126 + (long long)n * 126;
+    const float* T = npts + (long long)n * 126 + (long long)k * 132;
+    if (v < SS_NV) { sx[v] = nrigid[v * 2]; sy[v] = nrigid[v * 2 + 1]; }
+    if (v < SS_NT) { Tx[v] = T[v]; Ty[v] = T[SS_NT + v]; }
+    __syncthreads();
+    if (v >= SS_NV) return;
+    long long o = ((long long)k * SS_NV + v) * 2;
+    if (k == 0) { tsmotion[o] = 0.f; tsmotion[o + 1] = 0.f; return; }
+    float ox, oy;
+    tps_eval(sx, sy, Tx, Ty, npts[(long long)k * 126 + v * 2], npts[(long long)k * 126 + v * 2 + 1], ox, oy);
+    tsmotion[o] = __fsub_rn(recover1(ox, img_w), smesh[o]);
+    tsmotion[o + 1] = __fsub_rn(recover1(oy, img_h), smesh[o + 1]);
+}
+
+extern "C" long long ss_tsmotion_workspace_floats(int n) { return 126 + (long long)n * (126 + 126 + 132); }
+
+extern "C" int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
+                           float img_h, float img_w, float* ws, void* stream) {
+    if (!smotion || !tmotion || !smesh || !tsmotion || !ws || n <= 0) return SS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tsm_prepare_kernel, dim3(ss_cdiv(n * SS_NV, 128)), dim3(128), 0, st, smotion, tmotion, smesh, ws,
+                       n, img_h, img_w);
+    float* ntgt = ws + 126;
+    float* T = ntgt + (long long)n * 252;
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(256), 0, st, (const float*)ws, 0ll, (const float*)ntgt, T);
+    hipLaunchKernelGGL(tsm_finish_kernel, dim3(n), dim3(128), 0, st, (const float*)ws, (const float*)smesh, tsmotion,
+                       n, img_h, img_w);
+    return ss_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// canvas bbox over scaled meshes (test_online_tra.py:103-120); single block
+__global__ void mesh_bbox_kernel(const float* __restrict__ mesh, int npts, float img_h, float img_w,
+                                 float* __restrict__ bbox, int accumulate) {
+    __shared__ float red[4][4];
+    float wmin = INFINITY, wmax = -INFINITY, hmin = INFINITY, hmax = -INFINITY;
+    for (int i = threadIdx.x; i < npts; i += blockDim.x) {
+        float x = img_w > 0.f ? __fmul_rn(mesh[i * 2], img_w) / 480.0f : mesh[i * 2];
+        float y = img_h > 0.f ? __fmul_rn(mesh[i * 2 + 1], img_h) / 360.0f : mesh[i * 2 + 1];
+        wmin = fminf(wmin, x); wmax = fmaxf(wmax, x);
+        hmin = fminf(hmin, y); hmax = fmaxf(hmax, y);
+    }
+    wmin = ss_wave_min(wmin); wmax = ss_wave_max(wmax); hmin = ss_wave_min(hmin); hmax = ss_wave_max(hmax);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave][0] = wmin; red[wave][1] = wmax; red[wave][2] = hmin; red[wave][3] = hmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < 4; ++wv) {
+            wmin = fminf(wmin, red[wv][0]); wmax = fmaxf(wmax, red[wv][1]);
+            hmin = fminf(hmin, red[wv][2]); hmax = fmaxf(hmax, red[wv][3]);
+        }
+        if (accumulate) {
+            wmin = fminf(wmin, bbox[0]); wmax = fmaxf(wmax, bbox[1]);
+            hmin = fminf(hmin, bbox[2]); hmax = fmaxf(hmax, bbox[3]);
+        }
+        bbox[0] = wmin; bbox[1] = wmax; bbox[2] = hmin; bbox[3] = hmax;
+    }
+}
+
+extern "C" int ss_mesh_bbox(const float* mesh, int n_points, float img_h, float img_w, float* bbox, int accumulate,
+                            void* stream) {
+    if (!mesh || !bbox || n_points <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(mesh_bbox_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mesh, n_points, img_h, img_w, bbox,
+                       accumulate);
+    return ss_launch_status();
+}
+
+// test_online_tra.py:103-104, 129-136: scale to HR, translate by (-wmin,-hmin), normalise by the float canvas size
+__global__ void mesh_normalize_kernel(const float* __restrict__ mesh, const float* __restrict__ bbox,
+                                      float* __restrict__ out, int npts, float img_h, float img_w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    float wmin = bbox[0], wmax = bbox[1], hmin = bbox[2], hmax = bbox[3];
+    float ow = __fsub_rn(wmax, wmin), oh = __fsub_rn(hmax, hmin);
+    float x = img_w > 0.f ? __fmul_rn(mesh[i * 2], img_w) / 480.0f : mesh[i * 2];
+    float y = img_h > 0.f ? __fmul_rn(mesh[i * 2 + 1], img_h) / 360.0f : mesh[i * 2 + 1];
+    out[i * 2] = norm1(__fsub_rn(x, wmin), ow);
+    out[i * 2 + 1] = norm1(__fsub_rn(y, hmin), oh);
+}
+
+extern "C" int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_points, float img_h,
+                                 float img_w, void* stream) {
+    if (!mesh || !bbox || !out || n_points <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(mesh_normalize_kernel, dim3(ss_cdiv(n_points, 256)), dim3(256), 0, (hipStream_t)stream, mesh,
+                       bbox, out, n_points, img_h, img_w);
+    return ss_launch_status();
+}

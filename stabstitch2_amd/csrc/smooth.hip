@@ -1,0 +1,105 @@
+// SmoothNet glue (K11): per-vertex embeddings in front of the Conv3d stack and the mesh/path
+// bookkeeping behind the decoder (smooth_network.py:29-34, 66-72, 139-157).  The three
+// Conv3d(128,128,(5,3,3)) layers run on the implicit-GEMM engine in conv.hip (t = 7 frames).
+#include "common.h"
+
+// window wi covers frames wi*wstride + [0, t); tsflow = running sum of tsmotion inside the window,
+// with the first entry optionally forced to 0 (test_online_tra.py:362-366)
+__device__ __forceinline__ void window_flow(const float* __restrict__ ts, long long base, int tt, int v, int zero_first,
+                                            float& fx, float& fy) {
+    float ax = zero_first ? 0.f : ts[(base * SS_NV + v) * 2];
+    float ay = zero_first ? 0.f : ts[(base * SS_NV + v) * 2 + 1];
+    for (int s = 1; s <= tt; ++s) {
+        ax = __fadd_rn(ax, ts[((base + s) * SS_NV + v) * 2]);
+        ay = __fadd_rn(ay, ts[((base + s) * SS_NV + v) * 2 + 1]);
+    }
+    fx = ax;
+    fy = ay;
+}
+
+__global__ void smooth_embed_kernel(const float* __restrict__ sm1, const float* __restrict__ sm2,
+                                    const float* __restrict__ ts1, const float* __restrict__ ts2,
+                                    const float* __restrict__ e1w, const float* __restrict__ e1b,
+                                    const float* __restrict__ e3w, const float* __restrict__ e3b,
+                                    float* __restrict__ hidden, int nw, int t, int wstride, int zero_first) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)nw * t * SS_NV * 128;
+    if (idx >= total) return;
+    int ch = (int)(idx & 127);
+    long long r = idx >> 7;
+    int v = (int)(r % SS_NV);
+    r /= SS_NV;
+    int tt = (int)(r % t);
+    int wi = (int)(r / t);
+    long long base = (long long)wi * wstride;
+    int grp = ch >> 5, c = ch & 31;
+    float x, y;
+    const float *wq, *bq;
+    if ((grp & 1) == 0) {
+        const float* sm = grp == 0 ? sm1 : sm2;
+        x = sm[((base + tt) * SS_NV + v) * 2];
+        y = sm[((base + tt) * SS_NV + v) * 2 + 1];
+        wq = e1w; bq = e1b;
+    } else {
+        window_flow(grp == 1 ? ts1 : ts2, base, tt, v, zero_first, x, y);
+        wq = e3w; bq = e3b;
+    }
+    float o = __fadd_rn(__fadd_rn(__fmul_rn(x, wq[c * 2]), __fmul_rn(y, wq[c * 2 + 1])), bq[c]);
+    hidden[idx] = fmaxf(o, 0.f);
+}
+
+extern "C" int ss_smooth_embed(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+                               const float* e1w, const float* e1b, const float* e3w, const float* e3b, float* hidden,
+                               int nw, int t, int wstride, int zero_first, void* stream) {
+    if (!smesh1 || !smesh2 || !ts1 || !ts2 || !e1w || !e1b || !e3w || !e3b || !hidden || nw <= 0 || t <= 0 ||
+        wstride <= 0)
+        return SS_ERR_ARG;
+    long long total = (long long)nw * t * SS_NV * 128;
+    hipLaunchKernelGGL(smooth_embed_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, smesh1, smesh2,
+                       ts1, ts2, e1w, e1b, e3w, e3b, hidden, nw, t, wstride, zero_first);
+    return ss_launch_status();
+}
+
+__global__ void smooth_finalize_kernel(const float* __restrict__ sm1, const float* __restrict__ sm2,
+                                       const float* __restrict__ ts1, const float* __restrict__ ts2,
+                                       const float* __restrict__ delta, float* __restrict__ om1,
+                                       float* __restrict__ om2, float* __restrict__ op1, float* __restrict__ op2,
+                                       float* __restrict__ smm1, float* __restrict__ smm2, float* __restrict__ sp1,
+                                       float* __restrict__ sp2, int nw, int t, int wstride, int zero_first) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)nw * t * SS_NV;
+    if (idx >= total) return;
+    int v = (int)(idx % SS_NV);
+    long long r = idx / SS_NV;
+    int tt = (int)(r % t);
+    int wi = (int)(r / t);
+    long long base = (long long)wi * wstride;
+    float4 d = *reinterpret_cast<const float4*>(delta + idx * 4);
+    for (int view = 0; view < 2; ++view) {
+        const float* sm = view ? sm2 : sm1;
+        float mx = sm[((base + tt) * SS_NV + v) * 2], my = sm[((base + tt) * SS_NV + v) * 2 + 1];
+        float fx, fy;
+        window_flow(view ? ts2 : ts1, base, tt, v, zero_first, fx, fy);
+        float dx = view ? d.z : d.x, dy = view ? d.w : d.y;
+        float* om = view ? om2 : om1;
+        float* op = view ? op2 : op1;
+        float* smm = view ? smm2 : smm1;
+        float* sp = view ? sp2 : sp1;
+        if (om) { om[idx * 2] = mx; om[idx * 2 + 1] = my; }
+        if (op) { op[idx * 2] = fx; op[idx * 2 + 1] = fy; }
+        if (smm) { smm[idx * 2] = __fsub_rn(mx, dx); smm[idx * 2 + 1] = __fsub_rn(my, dy); }
+        if (sp) { sp[idx * 2] = __fadd_rn(fx, dx); sp[idx * 2 + 1] = __fadd_rn(fy, dy); }
+    }
+}
+
+extern "C" int ss_smooth_finalize(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+                                  const float* delta, float* ori_mesh1, float* ori_mesh2, float* ori_path1,
+                                  float* ori_path2, float* smooth_mesh1, float* smooth_mesh2, float* smooth_path1,
+                                  float* smooth_path2, int nw, int t, int wstride, int zero_first, void* stream) {
+    if (!smesh1 || !smesh2 || !ts1 || !ts2 || !delta || nw <= 0 || t <= 0 || wstride <= 0) return SS_ERR_ARG;
+    long long total = (long long)nw * t * SS_NV;
+    hipLaunchKernelGGL(smooth_finalize_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, smesh1,
+                       smesh2, ts1, ts2, delta, ori_mesh1, ori_mesh2, ori_path1, ori_path2, smooth_mesh1, smooth_mesh2,
+                       smooth_path1, smooth_path2, nw, t, wstride, zero_first);
+    return ss_launch_status();
+}

@@ -1,0 +1,185 @@
+"""Parameter containers with the reference checkpoint layout + weight preparation for the HIP engine.
+
+The nn.Conv2d / nn.BatchNorm2d / nn.Linear / nn.Conv3d objects below are never *called*: they only
+hold parameters under the reference's state-dict keys so that
+`net.load_state_dict(torch.load('spatial_warp.pth')['model'])` works with strict=True.  The forward
+passes run on libstabstitch_hip.so with weights repacked once per load:
+  * eval-mode BatchNorm folded into the preceding conv (scale into the filter, shift into a bias);
+  * filters [cout,cin,kh,kw] -> [cout,1,kh,kw,cin_pad4] (NHWC taps, zero taps for padded channels);
+  * first FC of every regressor re-indexed from the reference's NCHW flatten to NHWC flatten.
+Architecture restated from torchvision 0.14.1 resnet18 (spatial_network.py:123-139) and the
+reference's regressors (spatial_network.py:147-259, temporal_network.py:65-105).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        self.stride = stride
+
+
+def res_layer(cin, cout, stride):
+    return nn.Sequential(BasicBlock(cin, cout, stride), BasicBlock(cout, cout, 1))
+
+
+def make_trunk():
+    """(feature_extractor_stage1, feature_extractor_stage2) with the reference's Sequential indices."""
+    stage1 = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+                           nn.MaxPool2d(3, 2, 1), res_layer(64, 64, 1), res_layer(64, 128, 2))
+    stage2 = nn.Sequential(res_layer(128, 256, 2))
+    return stage1, stage2
+
+
+def regress_convs(cin, widths):
+    mods, c = [], cin
+    for wd in widths:
+        mods += [nn.Conv2d(c, wd, 3, padding=1, bias=False), nn.ReLU(inplace=True),
+                 nn.Conv2d(wd, wd, 3, padding=1, bias=False), nn.ReLU(inplace=True), nn.MaxPool2d(2, 2)]
+        c = wd
+    return nn.Sequential(*mods)
+
+
+def regress_fc(fin, h1, h2, fout):
+    return nn.Sequential(nn.Linear(fin, h1), nn.ReLU(inplace=True), nn.Linear(h1, h2), nn.ReLU(inplace=True),
+                         nn.Linear(h2, fout))
+
+
+# --------------------------------------------------------------------------- weight preparation
+def pack_conv2d(conv, bn=None):
+    """-> (wgt [cout,1,kh,kw,cin_pad4], bias [cout] | None) on the conv's device."""
+    w = conv.weight.detach().float()
+    bias = None
+    if bn is not None:
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        bias = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
+    cout, cin, kh, kw = w.shape
+    cp = pad4(cin)
+    out = torch.zeros((cout, 1, kh, kw, cp), device=w.device, dtype=torch.float32)
+    out[:, 0, :, :, :cin] = w.permute(0, 2, 3, 1)
+    return out.contiguous(), bias
+
+
+def pack_conv3d(conv):
+    w = conv.weight.detach().float()          # [cout,cin,kt,kh,kw]
+    return w.permute(0, 2, 3, 4, 1).contiguous(), conv.bias.detach().float().contiguous()
+
+
+def pack_fc_first(lin, c, hw):
+    """nn.Linear over an NCHW flatten (index c*hw + p) -> columns re-ordered for an NHWC flatten (p*c + ch)."""
+    w = lin.weight.detach().float()
+    n = w.shape[0]
+    w = w.view(n, c, hw).permute(0, 2, 1).reshape(n, hw * c).contiguous()
+    return w, lin.bias.detach().float().contiguous()
+
+
+def pack_fc(lin):
+    return lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous()
+
+
+class PreparedMixin:
+    """Lazy, invalidating cache of repacked weights."""
+
+    def _prepared(self):
+        dev = next(self.parameters()).device
+        cache = getattr(self, '_prep_cache', None)
+        if cache is None or cache[0] != dev:
+            with torch.no_grad():
+                cache = (dev, self._prepare())
+            object.__setattr__(self, '_prep_cache', cache)
+        return cache[1]
+
+    def _invalidate(self):
+        object.__setattr__(self, '_prep_cache', None)
+
+    def load_state_dict(self, *a, **k):
+        self._invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+
+# --------------------------------------------------------------------------- forward helpers (HIP)
+def prep_trunk_stage1(stage1):
+    p = {'conv1': pack_conv2d(stage1[0], stage1[1])}
+    p['layer1'] = [prep_block(b) for b in stage1[4]]
+    p['layer2'] = [prep_block(b) for b in stage1[5]]
+    return p
+
+
+def prep_trunk_stage2(stage2):
+    return {'layer3': [prep_block(b) for b in stage2[0]]}
+
+
+def prep_block(blk):
+    d = {'c1': pack_conv2d(blk.conv1, blk.bn1), 'c2': pack_conv2d(blk.conv2, blk.bn2), 'stride': blk.stride,
+         'ds': None}
+    if blk.downsample is not None:
+        d['ds'] = pack_conv2d(blk.downsample[0], blk.downsample[1])
+    return d
+
+
+def run_block(x, p):
+    y = ops.conv(x, p['c1'][0], p['c1'][1], stride=p['stride'], pad=(0, 1, 1), relu=True)
+    idt = x if p['ds'] is None else ops.conv(x, p['ds'][0], p['ds'][1], stride=p['stride'], pad=(0, 0, 0))
+    return ops.conv(y, p['c2'][0], p['c2'][1], res=idt, stride=1, pad=(0, 1, 1), relu=True)
+
+
+def run_stage1(x_nchw, p, chunk=32):
+    """[n,3,H,W] NCHW in [-1,1] -> nhwc [n,H/8,W/8,128]."""
+    outs = []
+    for s in range(0, x_nchw.shape[0], chunk):
+        x = ops.nchw_to_nhwc(x_nchw[s:s + chunk], 4)
+        x = ops.conv(x, p['conv1'][0], p['conv1'][1], stride=2, pad=(0, 3, 3), relu=True)
+        x = ops.maxpool(x, 3, 2, 1)
+        for b in p['layer1']:
+            x = run_block(x, b)
+        for b in p['layer2']:
+            x = run_block(x, b)
+        outs.append(x)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+def run_stage2(x, p):
+    for b in p['layer3']:
+        x = run_block(x, b)
+    return x
+
+
+def prep_regressor(convs, fcs, last_c, last_hw):
+    cw = [pack_conv2d(m)[0] for m in convs if isinstance(m, nn.Conv2d)]
+    lin = [m for m in fcs if isinstance(m, nn.Linear)]
+    return {'convs': cw, 'fc': [pack_fc_first(lin[0], last_c, last_hw), pack_fc(lin[1]), pack_fc(lin[2])]}
+
+
+def run_regressor(x, p):
+    """x nhwc; pairs of 3x3 conv+ReLU then 2x2 max-pool; NHWC flatten; 3 FC."""
+    for i, w in enumerate(p['convs']):
+        x = ops.conv(x, w, None, stride=1, pad=(0, 1, 1), relu=True)
+        if i & 1:
+            x = ops.maxpool(x, 2, 2, 0)
+    flat = x.reshape(x.shape[0], -1)
+    if flat.shape[1] != p['fc'][0][0].shape[1]:
+        raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
+                         % (p['fc'][0][0].shape[1], flat.shape[1]))
+    y = ops.linear(flat, p['fc'][0][0], p['fc'][0][1], relu=True)
+    y = ops.linear(y, p['fc'][1][0], p['fc'][1][1], relu=True)
+    return ops.linear(y, p['fc'][2][0], p['fc'][2][1], relu=False)

@@ -1,0 +1,230 @@
+"""Thin tensor-level wrappers over the C ABI: allocate outputs with torch, launch on the current
+stream, return device tensors.  No arithmetic happens in Python."""
+import ctypes
+
+import torch
+
+from . import _hip as H
+
+
+def _f(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+# ------------------------------------------------------------------ layout
+def nchw_to_nhwc(x, c_pad=None):
+    n, c, h, w = x.shape
+    c_pad = c_pad or ((c + 3) // 4) * 4
+    out = torch.empty((n, h, w, c_pad), device=x.device, dtype=torch.float32)
+    H.call('ss_nchw_to_nhwc', H.dptr(_f(x)), H.dptr(out), n, c, h, w, c_pad, H.stream())
+    return out
+
+
+def nhwc_to_nchw(x, c=None):
+    n, h, w, cs = x.shape
+    c = c or cs
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    H.call('ss_nhwc_to_nchw', H.dptr(x), H.dptr(out), n, c, h, w, cs, H.stream())
+    return out
+
+
+# ------------------------------------------------------------------ conv / pool / fc
+def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=None):
+    """x nhwc [n,h,w,c] or [n,t,h,w,c]; wgt [cout,kt,kh,kw,cin] (cin == x channels)."""
+    five = x.dim() == 5
+    if five:
+        n, t, h, w, c = x.shape
+    else:
+        n, h, w, c = x.shape
+        t = 1
+    cout, kt, kh, kw, cin = wgt.shape
+    assert cin == c, (cin, c)
+    pt, ph, pw = pad
+    to = t + 2 * pt - kt + 1
+    ho = (h + 2 * ph - kh) // stride + 1
+    wo = (w + 2 * pw - kw) // stride + 1
+    if out is None:
+        shape = (n, to, ho, wo, cout) if five else (n, ho, wo, cout)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
+           n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), out.shape[-1],
+           1, 0, 0, 0, H.stream())
+    return out
+
+
+def maxpool(x, k, stride, pad=0):
+    n, h, w, c = x.shape
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    out = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    H.call('ss_maxpool_nhwc', H.dptr(x), H.dptr(out), n, h, w, c, k, stride, pad, H.stream())
+    return out
+
+
+def linear(x, w, b=None, relu=False):
+    m, k = x.shape
+    nout = w.shape[0]
+    assert w.shape[1] == k
+    out = torch.empty((m, nout), device=x.device, dtype=torch.float32)
+    H.call('ss_linear', H.dptr(x), H.dptr(w), H.dptr(b, True), H.dptr(out), m, k, nout, int(relu), H.stream())
+    return out
+
+
+# ------------------------------------------------------------------ correlation
+def ccl(f1, f2, scale=10.0, want_nchw=True, want_nhwc4=True):
+    """f1, f2 nhwc [n,h,w,c] -> (flow NCHW [n,2,h,w] | None, flow nhwc4 [n,h,w,4] | None)."""
+    n, h, w, c = f1.shape
+    ws = torch.empty(int(H.lib().ss_ccl_workspace_floats(n, h, w, c)), device=f1.device, dtype=torch.float32)
+    a = torch.empty((n, 2, h, w), device=f1.device, dtype=torch.float32) if want_nchw else None
+    b = torch.empty((n, h, w, 4), device=f1.device, dtype=torch.float32) if want_nhwc4 else None
+    H.call('ss_ccl', H.dptr(f1), H.dptr(f2), H.dptr(a, True), H.dptr(b, True), n, h, w, c, float(scale),
+           H.dptr(ws), H.stream())
+    return a, b
+
+
+def cost_volume(x1, x2, r):
+    """nhwc in -> nhwc [n,h,w,pad4((2r+1)^2)] (padding channels are zero)."""
+    n, h, w, c = x1.shape
+    d = (2 * r + 1) ** 2
+    cs = ((d + 3) // 4) * 4
+    out = torch.empty((n, h, w, cs), device=x1.device, dtype=torch.float32)
+    H.call('ss_cost_volume', H.dptr(x1), H.dptr(x2), H.dptr(out), n, h, w, c, r, cs, H.stream())
+    return out
+
+
+# ------------------------------------------------------------------ geometry
+def tensor_dlt(src, dst):
+    n = src.shape[0]
+    out = torch.empty((n, 3, 3), device=src.device, dtype=torch.float32)
+    H.call('ss_tensor_dlt', H.dptr(_f(src)), H.dptr(_f(dst)), H.dptr(out), n, H.stream())
+    return out
+
+
+def spatial_decompose(offset8, img_h, img_w):
+    n = offset8.shape[0]
+    a = torch.empty((n, 3, 3), device=offset8.device, dtype=torch.float32)
+    b = torch.empty((n, 3, 3), device=offset8.device, dtype=torch.float32)
+    H.call('ss_spatial_decompose', H.dptr(offset8), H.dptr(a), H.dptr(b), n, float(img_h), float(img_w), H.stream())
+    return a, b
+
+
+def spatial_meshes(offset8, off_ref, off_tgt, img_h, img_w):
+    n = offset8.shape[0]
+    m1 = torch.empty((n, 7, 9, 2), device=offset8.device, dtype=torch.float32)
+    m2 = torch.empty((n, 7, 9, 2), device=offset8.device, dtype=torch.float32)
+    H.call('ss_spatial_meshes', H.dptr(offset8), H.dptr(off_ref), H.dptr(off_tgt), H.dptr(m1), H.dptr(m2), n,
+           float(img_h), float(img_w), H.stream())
+    return m1, m2
+
+
+def homo_warp_nhwc(x, theta, out_h, out_w):
+    n, h, w, c = x.shape
+    out = torch.empty((n, out_h, out_w, c), device=x.device, dtype=torch.float32)
+    H.call('ss_homo_warp_nhwc', H.dptr(x), H.dptr(theta), H.dptr(out), n, h, w, c, out_h, out_w, H.stream())
+    return out
+
+
+def homo_warp_nchw(x, theta, out_h, out_w):
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32)
+    H.call('ss_homo_warp_nchw', H.dptr(x), H.dptr(theta), H.dptr(out), n, c, h, w, out_h, out_w, H.stream())
+    return out
+
+
+def tps_solve(source, target):
+    n = source.shape[0]
+    T = torch.empty((n, 2, 66), device=source.device, dtype=torch.float32)
+    H.call('ss_tps_solve', H.dptr(_f(source)), H.dptr(_f(target)), H.dptr(T), n, H.stream())
+    return T
+
+
+def tps_points(point, source, T):
+    n, q, _ = point.shape
+    out = torch.empty((n, q, 2), device=point.device, dtype=torch.float32)
+    H.call('ss_tps_points', H.dptr(_f(point)), H.dptr(_f(source)), H.dptr(T), H.dptr(out), n, q, H.stream())
+    return out
+
+
+def tsmotion(smotion, tmotion, img_h=360, img_w=480):
+    """smotion, tmotion [n,7,9,2] -> (smesh, tsmotion) [n,7,9,2]."""
+    n = smotion.shape[0]
+    ws = torch.empty(int(H.lib().ss_tsmotion_workspace_floats(n)), device=smotion.device, dtype=torch.float32)
+    smesh = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
+    tsm = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
+    H.call('ss_tsmotion', H.dptr(_f(smotion)), H.dptr(_f(tmotion)), H.dptr(smesh), H.dptr(tsm), n, float(img_h),
+           float(img_w), H.dptr(ws), H.stream())
+    return smesh, tsm
+
+
+# ------------------------------------------------------------------ render
+MODES = {'NORMAL': 0, 'FAST': 1}
+
+
+def tps_warp(U, source, T, hc, wc, mode='NORMAL', with_mask=False):
+    b, c, h, w = U.shape
+    out = torch.empty((b, c + int(with_mask), hc, wc), device=U.device, dtype=torch.float32)
+    H.call('ss_tps_warp_mask_nchw' if with_mask else 'ss_tps_warp_nchw', H.dptr(_f(U)), H.dptr(_f(source)),
+           H.dptr(T), H.dptr(out), b, c, h, w, hc, wc, MODES[mode], H.stream())
+    return out
+
+
+def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None):
+    """imgs: list of 2|3 device tensors [1,3,h,w] / [3,h,w]; source [V,63,2]; T [V,2,66] -> [3,hc,wc]."""
+    v = len(imgs)
+    imgs = [_f(i) for i in imgs]
+    h, w = imgs[0].shape[-2:]
+    arr = (ctypes.c_void_p * v)(*[i.data_ptr() for i in imgs])
+    if out is None:
+        out = torch.empty((3, hc, wc), device=imgs[0].device, dtype=torch.float32)
+    for i in imgs:
+        H.dptr(i)
+    H.call('ss_render_average', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(out), v, h, w, hc, wc, MODES[mode],
+           H.stream())
+    return out
+
+
+def linear_blend(ref, tgt, ref_m, tgt_m, want_mask=False):
+    """ref,tgt [3,hc,wc]; ref_m,tgt_m [hc,wc] -> fused [3,hc,wc] (or mask1 [hc,wc])."""
+    hc, wc = ref_m.shape[-2:]
+    ws = torch.empty(int(H.lib().ss_linear_blend_workspace_floats(hc, wc)), device=ref_m.device, dtype=torch.float32)
+    out = None if want_mask else torch.empty((3, hc, wc), device=ref_m.device, dtype=torch.float32)
+    mk = torch.empty((hc, wc), device=ref_m.device, dtype=torch.float32) if want_mask else None
+    H.call('ss_linear_blend', H.dptr(ref, True), H.dptr(tgt, True), H.dptr(_f(ref_m)), H.dptr(_f(tgt_m)),
+           H.dptr(out, True), H.dptr(mk, True), hc, wc, H.dptr(ws), H.stream())
+    return mk if want_mask else out
+
+
+def mesh_bbox(meshes, img_h, img_w):
+    """meshes: list of LR-scale tensors [...,2] -> device tensor [4] = wmin, wmax, hmin, hmax (HR px)."""
+    bbox = torch.empty(4, device=meshes[0].device, dtype=torch.float32)
+    for i, m in enumerate(meshes):
+        m = _f(m)
+        H.call('ss_mesh_bbox', H.dptr(m), m.numel() // 2, float(img_h), float(img_w), H.dptr(bbox), int(i > 0),
+               H.stream())
+    return bbox
+
+
+def mesh_normalize(mesh, bbox, img_h, img_w):
+    """LR-scale mesh [...,2] -> canvas-normalised [N,63,2]."""
+    m = _f(mesh)
+    out = torch.empty((m.numel() // 126, 63, 2), device=m.device, dtype=torch.float32)
+    H.call('ss_mesh_normalize', H.dptr(m), H.dptr(bbox), H.dptr(out), m.numel() // 2, float(img_h), float(img_w),
+           H.stream())
+    return out
+
+
+# ------------------------------------------------------------------ smooth glue
+def smooth_embed(sm1, sm2, ts1, ts2, e1w, e1b, e3w, e3b, nw, t, wstride, zero_first):
+    hidden = torch.empty((nw, t, 7, 9, 128), device=sm1.device, dtype=torch.float32)
+    H.call('ss_smooth_embed', H.dptr(sm1), H.dptr(sm2), H.dptr(ts1), H.dptr(ts2), H.dptr(e1w), H.dptr(e1b),
+           H.dptr(e3w), H.dptr(e3b), H.dptr(hidden), nw, t, wstride, int(zero_first), H.stream())
+    return hidden
+
+
+def smooth_finalize(sm1, sm2, ts1, ts2, delta, nw, t, wstride, zero_first):
+    names = ('ori_mesh1', 'ori_mesh2', 'ori_path1', 'ori_path2', 'smooth_mesh1', 'smooth_mesh2', 'smooth_path1',
+             'smooth_path2')
+    outs = {k: torch.empty((nw, t, 7, 9, 2), device=sm1.device, dtype=torch.float32) for k in names}
+    H.call('ss_smooth_finalize', H.dptr(sm1), H.dptr(sm2), H.dptr(ts1), H.dptr(ts2), H.dptr(delta),
+           *[H.dptr(outs[k]) for k in names], nw, t, wstride, int(zero_first), H.stream())
+    return outs

@@ -1,0 +1,217 @@
+"""Online 2-view / 3-view stitching pipeline on the MI355X HIP engine.
+
+Tensor-level counterpart of `test()` in Full_model_inference/Codes/test_online_tra.py:158-426 and
+test_online_tra_threeview.py:95-519 (file / video I/O excluded), with the reference's helper names
+(`get_stable_sqe`, `linear_blender`, `recover_mesh`, `get_rigid_mesh`, `get_norm_mesh`).
+
+The reference walks the clip frame by frame with batch 1.  Here every stage is one batched pass
+over the whole clip (the clip is resident in HBM): SpatialNet over all frame pairs, TemporalNet
+over all frames of a view, one batched tsmotion composition per view, all sliding SmoothNet windows
+as one batch, one batched TPS solve for every (frame, view), then one fused warp+blend launch per
+stitched frame.  The only host round trip is the data-dependent canvas size (test_online_tra.py:122-123).
+"""
+import torch
+
+from . import grid_res, ops
+from .spatial_network import get_rigid_mesh, get_norm_mesh, build_SpatialNet  # noqa: F401 (reference names)
+
+grid_h = grid_res.GRID_H
+grid_w = grid_res.GRID_W
+LR_H, LR_W = 360, 480
+WINDOW = 7
+
+
+def recover_mesh(norm_mesh, height, width):
+    """test_online_tra.py:61-69."""
+    b = norm_mesh.size()[0]
+    x = (norm_mesh[..., 0] + 1) * float(width) / 2.
+    y = (norm_mesh[..., 1] + 1) * float(height) / 2.
+    return torch.stack([x, y], 2).reshape([b, grid_h + 1, grid_w + 1, 2])
+
+
+def linear_blender(ref, tgt, ref_m, tgt_m, mask=False):
+    """test_online_tra.py:34-58; ref,tgt [1,3,H,W], ref_m,tgt_m [1,1,H,W]."""
+    if mask:
+        return ops.linear_blend(None, None, ref_m[0, 0].contiguous(), tgt_m[0, 0].contiguous(), True)[None, None]
+    return ops.linear_blend(ref[0].contiguous(), tgt[0].contiguous(), ref_m[0, 0].contiguous(),
+                            tgt_m[0, 0].contiguous())[None]
+
+
+# ------------------------------------------------------------------ stages (batched over the clip)
+def _stack(lst, dev):
+    return torch.stack([t.to(dev, non_blocking=True).float() for t in lst], 0)
+
+
+@torch.no_grad()
+def spatial_stage(spatial_net, lr1, lr2, chunk=16):
+    """lr1, lr2 [N,3,360,480] device -> smotion1, smotion2 [N,7,9,2]."""
+    m1, m2 = [], []
+    for s in range(0, lr1.shape[0], chunk):
+        o = build_SpatialNet(spatial_net, lr1[s:s + chunk], lr2[s:s + chunk])
+        m1.append(o['motion1'])
+        m2.append(o['motion2'])
+    return torch.cat(m1, 0), torch.cat(m2, 0)
+
+
+@torch.no_grad()
+def temporal_stage(temporal_net, lr):
+    """lr [N,3,360,480] device -> tmotion [N,7,9,2] (frame 0 = 0)."""
+    m = temporal_net.motions(lr.unsqueeze(1))[:, 0]
+    return torch.cat((torch.zeros_like(m[:1]), m), 0)
+
+
+@torch.no_grad()
+def estimate_meshes(nets, lr1, lr2):
+    """Stages 1-3 of test() (test_online_tra.py:284-392) for one clip.
+    lr1, lr2: [N,3,360,480] device tensors (or lists of [1,3,360,480]).
+    -> dict(smooth_mesh1/2, ori_mesh1/2 [1,N,7,9,2], ori_path2, smooth_path2 stitched as test_metric_ssd.py:433-436)."""
+    spatial_net, temporal_net, smooth_net = nets
+    dev = next(spatial_net.parameters()).device
+    if isinstance(lr1, (list, tuple)):
+        lr1 = torch.cat([t.to(dev) for t in lr1], 0)
+        lr2 = torch.cat([t.to(dev) for t in lr2], 0)
+    n = lr1.shape[0]
+    if n < WINDOW:
+        raise ValueError('need at least %d frames for the sliding smooth window, got %d' % (WINDOW, n))
+    s1, s2 = spatial_stage(spatial_net, lr1, lr2)
+    t1 = temporal_stage(temporal_net, lr1)
+    t2 = temporal_stage(temporal_net, lr2)
+    smesh1, tsm1 = ops.tsmotion(s1, t1, LR_H, LR_W)
+    smesh2, tsm2 = ops.tsmotion(s2, t2, LR_H, LR_W)
+    nw = n - (WINDOW - 1)
+    o, _ = smooth_net.run_windows(smesh1, smesh2, tsm1, tsm2, nw, WINDOW, 1, 1)
+    out = {}
+    for k in ('ori_mesh1', 'ori_mesh2', 'smooth_mesh1', 'smooth_mesh2'):
+        # window 0 contributes its 7 frames, every later window its last frame (test_online_tra.py:377-392)
+        out[k] = torch.cat((o[k][0], o[k][1:, -1]), 0).unsqueeze(0)
+    # stitched paths of the metric harness (test_metric_ssd.py:427-436)
+    op, sp = o['ori_path2'], o['smooth_path2']
+    inc = op[1:, -1] - op[1:, -2]
+    ori_path = torch.cat((op[0], op[0, -1:] + torch.cumsum(inc, 0)), 0)
+    smooth_path = torch.cat((sp[0], ori_path[WINDOW:] + (sp[1:, -1] - op[1:, -1])), 0)
+    out['ori_path2'] = ori_path.unsqueeze(0)
+    out['smooth_path2'] = smooth_path.unsqueeze(0)
+    out['smotion1'], out['smotion2'], out['tmotion1'], out['tmotion2'] = s1, s2, t1, t2
+    out['tsmotion1'], out['tsmotion2'] = tsm1, tsm2
+    return out
+
+
+# ------------------------------------------------------------------ render
+@torch.no_grad()
+def render_plan(meshes, img_h, img_w, prescaled=False):
+    """Canvas + TPS coefficients for every (frame, view).
+    meshes: list of V tensors [1,N,7,9,2] (LR scale, or HR canvas pixels with prescaled=True).
+    -> (Hc, Wc, source [N,V,63,2], T [N,V,2,66])."""
+    dev = meshes[0].device
+    v = len(meshes)
+    n = meshes[0].shape[1]
+    sh, sw = (0.0, 0.0) if prescaled else (img_h, img_w)
+    bbox = ops.mesh_bbox([m for m in meshes], sh, sw)
+    bb = bbox.cpu()                                       # the one host sync: data-dependent canvas size
+    wc_f, hc_f = bb[1] - bb[0], bb[3] - bb[2]
+    hc, wc = int(hc_f.int()), int(wc_f.int())
+    src = torch.stack([ops.mesh_normalize(m[0], bbox, sh, sw) for m in meshes], 1).contiguous()   # [N,V,63,2]
+    nrigid = get_norm_mesh(get_rigid_mesh(1, img_h, img_w, device=dev), img_h, img_w)
+    tgt = nrigid.expand(n * v, -1, -1).contiguous()
+    T = ops.tps_solve(src.view(n * v, 63, 2), tgt).view(n, v, 2, 66)
+    return hc, wc, src, T
+
+
+@torch.no_grad()
+def render_frames(img_lists, meshes, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None, prescaled=False):
+    """img_lists: V lists (or tensors [N,3,H,W]) of HR frames (0..255); meshes: V tensors [1,N,7,9,2].
+    -> (frames [N,3,Hc,Wc] device tensor, Hc, Wc)."""
+    v = len(img_lists)
+    dev = meshes[0].device
+    n = meshes[0].shape[1]
+    first = img_lists[0][0]
+    img_h, img_w = first.shape[-2:]
+    hc, wc, src, T = render_plan(meshes, img_h, img_w, prescaled)
+    if out is None:
+        out = torch.empty((n, 3, hc, wc), device=dev, dtype=torch.float32)
+    for i in range(n):
+        imgs = [img_lists[k][i].to(dev, non_blocking=True) for k in range(v)]
+        if fusion_mode == 'AVERAGE':
+            ops.render_average(imgs, src[i], T[i], hc, wc, warp_mode, out=out[i])
+        else:
+            U = torch.stack([im.reshape(3, img_h, img_w) for im in imgs], 0)
+            w = ops.tps_warp(U, src[i], T[i], hc, wc, warp_mode, with_mask=True)     # [V,4,Hc,Wc]
+            f = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
+            if v == 3:
+                m12 = w[0, 3] + w[1, 3] - w[0, 3] * w[1, 3]
+                f = ops.linear_blend(f, w[2, 0:3], m12.contiguous(), w[2, 3])
+            out[i].copy_(f)
+    return out, hc, wc
+
+
+def get_stable_sqe(img1_list, img2_list, smooth_mesh1, smooth_mesh2, warp_mode, fusion_mode):
+    """test_online_tra.py:96-154 -> (list of ndarray [Hc,Wc,3] fp32, Wc, Hc) like the reference."""
+    frames, hc, wc = render_frames([img1_list, img2_list], [smooth_mesh1, smooth_mesh2], warp_mode, fusion_mode)
+    host = frames.permute(0, 2, 3, 1).cpu().numpy()
+    return [host[i] for i in range(host.shape[0])], torch.tensor(wc, dtype=torch.int32), \
+        torch.tensor(hc, dtype=torch.int32)
+
+
+@torch.no_grad()
+def run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', to_host=False):
+    """-> (frames, Hc, Wc, smooth_mesh1, smooth_mesh2); frames = device tensor [N,3,Hc,Wc]
+    (or list of HWC ndarrays with to_host=True)."""
+    acc = estimate_meshes(nets, lr1, lr2)
+    frames, hc, wc = render_frames([hr1, hr2], [acc['smooth_mesh1'], acc['smooth_mesh2']], warp_mode, fusion_mode)
+    if to_host:
+        host = frames.permute(0, 2, 3, 1).cpu().numpy()
+        frames = [host[i] for i in range(host.shape[0])]
+    return frames, hc, wc, acc['smooth_mesh1'], acc['smooth_mesh2']
+
+
+# ------------------------------------------------------------------ three-view (threeview:345-505)
+def _scale(m, img_h, img_w):
+    return torch.stack([m[..., 0] * img_w / 480, m[..., 1] * img_h / 360], 4)
+
+
+@torch.no_grad()
+def three_view_compose(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w):
+    """Mesh alignment, middle plane and TPS re-projection of the outer views.  Inputs [1,N,7,9,2] (LR scale)
+    -> (mesh1, middle, mesh3) in first-canvas HR pixels.  Mesh-sized glue stays in torch; the TPS solves and
+    point evaluations run on the HIP kernels."""
+    a1, a2 = _scale(w12_m1, img_h, img_w), _scale(w12_m2, img_h, img_w)
+    b1, b2 = _scale(w23_m1, img_h, img_w), _scale(w23_m2, img_h, img_w)
+    off = (a2 - b1).reshape(a2.shape[0], a2.shape[1], -1, 2).mean(2).unsqueeze(2).unsqueeze(2)
+    b1, b2 = b1 + off, b2 + off
+    mid = (a2 + b1) / 2.
+    wmin = torch.stack([m[..., 0].min() for m in (a1, a2, b1, b2)]).min()
+    wmax = torch.stack([m[..., 0].max() for m in (a1, a2, b1, b2)]).max()
+    hmin = torch.stack([m[..., 1].min() for m in (a1, a2, b1, b2)]).min()
+    hmax = torch.stack([m[..., 1].max() for m in (a1, a2, b1, b2)]).max()
+    ow, oh = wmax - wmin, hmax - hmin
+
+    def shift(m):
+        return torch.stack([m[..., 0] - wmin, m[..., 1] - hmin], 4)
+
+    def nrm(m):      # [1,N,7,9,2] -> [N,63,2]
+        return torch.stack([m[0, ..., 0] * 2. / ow - 1., m[0, ..., 1] * 2. / oh - 1.], 3).reshape(m.shape[1], -1, 2)
+
+    def rec(nm):
+        return torch.stack([(nm[..., 0] + 1) * ow / 2., (nm[..., 1] + 1) * oh / 2.], 2).reshape(1, -1, 7, 9, 2)
+    a1, a2, b1, b2, mid = map(shift, (a1, a2, b1, b2, mid))
+    nmid = nrm(mid).contiguous()
+    n1 = ops.tps_points(nrm(a1).contiguous(), nrm(a2).contiguous(), ops.tps_solve(nrm(a2).contiguous(), nmid))
+    n3 = ops.tps_points(nrm(b2).contiguous(), nrm(b1).contiguous(), ops.tps_solve(nrm(b1).contiguous(), nmid))
+    return rec(n1), mid, rec(n3)
+
+
+@torch.no_grad()
+def three_view_render(img1, img2, img3, mesh1, middle, mesh3, warp_mode='NORMAL', fusion_mode='AVERAGE'):
+    """Meshes are HR-scale canvas pixels here (output of three_view_compose)."""
+    return render_frames([img1, img2, img3], [mesh1, middle, mesh3], warp_mode, fusion_mode, prescaled=True)
+
+
+@torch.no_grad()
+def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE'):
+    a12 = estimate_meshes(nets, lr1, lr2)
+    a23 = estimate_meshes(nets, lr2, lr3)
+    img_h, img_w = hr1[0].shape[-2:]
+    m1, mid, m3 = three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'],
+                                     a23['smooth_mesh2'], img_h, img_w)
+    frames, hc, wc = three_view_render(hr1, hr2, hr3, m1, mid, m3, warp_mode, fusion_mode)
+    return frames, hc, wc, m1, mid, m3

@@ -1,0 +1,60 @@
+"""TemporalNet on the MI355X HIP engine; module API of Full_model_inference/Codes/temporal_network.py
+(`TemporalNet()`, `build_TemporalNet(net, img_tensor_list)`, 104 state-dict tensors incl. the unused
+feature_extractor_stage2).  The reference walks the clip frame by frame (temporal_network.py:129-145);
+here every frame's stage-1 features are computed in one batched pass and all consecutive-pair cost
+volumes / regressions in another (eval mode is batch invariant)."""
+import torch
+import torch.nn as nn
+
+from . import grid_res, layers as L, ops
+
+grid_h = grid_res.GRID_H
+grid_w = grid_res.GRID_W
+
+
+class TemporalNet(L.PreparedMixin, nn.Module):
+    def __init__(self, dropout=0.):
+        super().__init__()
+        self.regressNet2_part1 = L.regress_convs(49, (64, 128, 128, 256))
+        self.regressNet2_part2 = L.regress_fc(1536, 1024, 512, (grid_w + 1) * (grid_h + 1) * 2)
+        self.feature_extractor_stage1, self.feature_extractor_stage2 = L.make_trunk()
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+        self.eval()
+
+    def _prepare(self):
+        return {'s1': L.prep_trunk_stage1(self.feature_extractor_stage1),
+                'r2': L.prep_regressor(self.regressNet2_part1, self.regressNet2_part2, 256, 6)}
+
+    @torch.no_grad()
+    def motions(self, frames):
+        """frames [N,B,3,360,480] (device) -> [N-1,B,7,9,2] mesh motions between consecutive frames."""
+        p = self._prepared()
+        n, b = frames.shape[0], frames.shape[1]
+        f = L.run_stage1(frames.reshape(n * b, *frames.shape[2:]), p['s1'])
+        f = f.view(n, b, *f.shape[1:])
+        x1 = f[:-1].reshape((n - 1) * b, *f.shape[2:])
+        x2 = f[1:].reshape((n - 1) * b, *f.shape[2:])
+        off = L.run_regressor(ops.cost_volume(x1, x2, 3), p['r2'])
+        return off.view(n - 1, b, grid_h + 1, grid_w + 1, 2)
+
+    def forward(self, img_tensor_list):
+        dev = next(self.parameters()).device
+        frames = torch.stack([t.to(dev, non_blocking=True).float() for t in img_tensor_list], 0)
+        m = self.motions(frames)
+        return [m[i] for i in range(m.shape[0])]
+
+    @staticmethod
+    def cost_volume(x1, x2, search_range, norm=True, fast=True):
+        if norm:
+            raise NotImplementedError('norm=True is never used by the reference inference path')
+        d = (2 * search_range + 1) ** 2
+        return ops.nhwc_to_nchw(ops.cost_volume(ops.nchw_to_nhwc(x1), ops.nchw_to_nhwc(x2), search_range), d)
+
+
+def build_TemporalNet(net, img_tensor_list):
+    """temporal_network.py:23-34 -> dict(motion_list = [zeros] + N-1 motions), each [B,7,9,2]."""
+    motion_list = net(img_tensor_list)
+    motion_list.insert(0, torch.zeros_like(motion_list[0]))
+    return dict(motion_list=motion_list)

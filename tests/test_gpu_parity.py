@@ -1,0 +1,323 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden fixtures.  Runs on the MI355X box:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+from oracle import geometry as G, samplers as S, nets as N, pipeline as P, metrics as M
+from stabstitch2_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def close(a, b, tol, what=''):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+    assert np.isfinite(a).all(), what + ' has non-finite values'
+    assert err <= tol, '%s max|diff| %.3e > %.1e' % (what, err, tol)
+    return err
+
+
+# ------------------------------------------------------------------ conv engine
+def _pack(w, cin_pad):
+    cout, cin = w.shape[:2]
+    if w.dim() == 4:
+        out = torch.zeros(cout, 1, w.shape[2], w.shape[3], cin_pad)
+        out[:, 0, :, :, :cin] = w.permute(0, 2, 3, 1)
+    else:
+        out = torch.zeros(cout, w.shape[2], w.shape[3], w.shape[4], cin_pad)
+        out[..., :cin] = w.permute(0, 2, 3, 4, 1)
+    return out.contiguous()
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,s,p,bias,res,relu', [
+    (2, 3, 64, 72, 96, 7, 2, 3, True, False, True),      # conv1 shape class (cin padded 3->4, K tail)
+    (1, 64, 64, 90, 120, 3, 1, 1, True, True, True),     # layer1 block tail
+    (3, 64, 128, 45, 60, 3, 2, 1, True, False, True),    # strided
+    (3, 64, 128, 45, 60, 1, 2, 0, True, False, False),   # downsample 1x1
+    (2, 121, 64, 45, 60, 3, 1, 1, False, False, True),   # cost-volume regressor (121 -> 124 ch)
+    (5, 128, 256, 5, 7, 3, 1, 1, False, False, True),    # tiny map, M tail
+    (16, 64, 64, 90, 120, 3, 1, 1, True, True, True),    # large M -> 128-row tiles
+    (16, 128, 128, 45, 60, 3, 1, 1, True, False, True),  # 128x128 tiles
+])
+def test_conv2d(dev, n, cin, cout, h, w, k, s, p, bias, res, relu):
+    from stabstitch2_amd import ops
+    rs = np.random.RandomState(n * 1000 + cin + cout)
+    x = torch.from_numpy(rs.normal(0, 1, (n, cin, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rs.normal(0, 1, (cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+    b = torch.from_numpy(rs.normal(0, 1, cout).astype(np.float32)) if bias else None
+    ref = F.conv2d(x, wt, b, stride=s, padding=p)
+    r = torch.from_numpy(rs.normal(0, 1, tuple(ref.shape)).astype(np.float32)) if res else None
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    cp = (cin + 3) // 4 * 4
+    xd = ops.nchw_to_nhwc(x.to(dev), cp)
+    rd = ops.nchw_to_nhwc(r.to(dev)) if res else None
+    out = ops.conv(xd, _pack(wt, cp).to(dev), b.to(dev) if bias else None, rd, stride=s, pad=(0, p, p), relu=relu)
+    close(ops.nhwc_to_nchw(out), ref, 2e-5 * max(1.0, float(ref.abs().max())), 'conv2d')
+
+
+def test_conv3d(dev):
+    from stabstitch2_amd import ops
+    rs = np.random.RandomState(7)
+    x = torch.from_numpy(rs.normal(0, 1, (3, 128, 7, 7, 9)).astype(np.float32))
+    wt = torch.from_numpy((rs.normal(0, 1, (128, 128, 5, 3, 3)) / np.sqrt(128 * 45)).astype(np.float32))
+    b = torch.from_numpy(rs.normal(0, 1, 128).astype(np.float32))
+    ref = F.relu(F.conv3d(x, wt, b, padding=(2, 1, 1)))
+    out = ops.conv(x.permute(0, 2, 3, 4, 1).contiguous().to(dev), _pack(wt, 128).to(dev), b.to(dev), None,
+                   stride=1, pad=(2, 1, 1), relu=True)
+    close(out.permute(0, 4, 1, 2, 3), ref, 5e-5, 'conv3d')
+
+
+def test_pool_linear_layout(dev):
+    from stabstitch2_amd import ops
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.normal(0, 1, (2, 64, 45, 61)).astype(np.float32))
+    xd = ops.nchw_to_nhwc(x.to(dev))
+    close(ops.nhwc_to_nchw(xd), x, 0, 'layout round trip')
+    close(ops.nhwc_to_nchw(ops.maxpool(xd, 3, 2, 1)), F.max_pool2d(x, 3, 2, 1), 0, 'maxpool 3/2/1')
+    close(ops.nhwc_to_nchw(ops.maxpool(xd, 2, 2, 0)), F.max_pool2d(x, 2, 2), 0, 'maxpool 2/2 floor')
+    for m in (1, 3, 19):
+        a = torch.from_numpy(rs.normal(0, 1, (m, 1536)).astype(np.float32))
+        w = torch.from_numpy((rs.normal(0, 1, (1024, 1536)) / 39.0).astype(np.float32))
+        b = torch.from_numpy(rs.normal(0, 1, 1024).astype(np.float32))
+        close(ops.linear(a.to(dev), w.to(dev), b.to(dev), relu=True), F.relu(F.linear(a, w, b)), 5e-5, 'linear')
+    a = torch.from_numpy(rs.normal(0, 1, (5, 2)).astype(np.float32))
+    w = torch.from_numpy(rs.normal(0, 1, (32, 2)).astype(np.float32))
+    close(ops.linear(a.to(dev), w.to(dev), None), F.linear(a, w), 1e-6, 'linear k=2')
+
+
+# ------------------------------------------------------------------ correlation
+def test_cost_volume(dev, golden):
+    from stabstitch2_amd import ops
+    g = golden('g3_costvol')
+    a, b = cases.g3_inputs(False)
+    for r, key in ((5, 'cv5'), (3, 'cv3')):
+        d = (2 * r + 1) ** 2
+        out = ops.cost_volume(ops.nchw_to_nhwc(a.to(dev)), ops.nchw_to_nhwc(b.to(dev)), r)
+        assert float(out[..., d:].abs().max()) == 0.0
+        close(ops.nhwc_to_nchw(out, d), g[key], 1e-5, 'cost volume r=%d vs reference' % r)
+    fa, fb = cases.g3_inputs(True)
+    for r, rows, chs, row in ((5, 'full5_rows', 'full5_chsum', 22), (3, 'full3_rows', 'full3_chsum', 0)):
+        d = (2 * r + 1) ** 2
+        out = ops.nhwc_to_nchw(ops.cost_volume(ops.nchw_to_nhwc(fa.to(dev)), ops.nchw_to_nhwc(fb.to(dev)), r), d)
+        close(out[0, :, row, :], g[rows], 1e-5, 'full rows')
+        close(out.sum(dim=(2, 3)), g[chs], 2e-3, 'full channel sums')
+        close(out, N.cost_volume(fa, fb, r), 1e-5, 'full vs oracle')
+    # direction symmetry as a size-independent property on a batch
+    x1 = torch.randn(3, 45, 60, 128, device=dev)
+    x2 = torch.randn(3, 45, 60, 128, device=dev)
+    c12 = ops.cost_volume(x1, x2, 5)[..., :121].view(3, 45, 60, 11, 11)
+    c21 = ops.cost_volume(x2, x1, 5)[..., :121].view(3, 45, 60, 11, 11)
+    assert torch.allclose(c12[:, 10, 10, 7, 8], c21[:, 12, 13, 3, 2], atol=1e-6)
+
+
+def test_ccl(dev, golden):
+    from stabstitch2_amd import ops
+    g = golden('g4_ccl')
+    for full, key in ((False, 'flow'), (True, 'flow_full')):
+        a, b = cases.g4_inputs(full)
+        flow, flow4 = ops.ccl(ops.nchw_to_nhwc(a.to(dev)), ops.nchw_to_nhwc(b.to(dev)), 10.0)
+        close(flow, g[key], 1e-4, 'ccl vs reference')
+        close(flow4[..., :2].permute(0, 3, 1, 2), g[key], 1e-4, 'ccl nhwc4')
+        assert float(flow4[..., 2:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ geometry
+def test_dlt_decomposition_meshes(dev, golden):
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.utils import torch_DLT
+    g = golden('g1_dlt')
+    off = cases.g1_offsets()
+    b = off.shape[0]
+    c = torch.tensor([[0., 0.], [480., 0.], [0., 360.], [480., 360.]]).unsqueeze(0).expand(b, -1, -1)
+    H = torch_DLT.tensor_DLT(c.to(dev), (c + off.reshape(b, 4, 2)).to(dev)).cpu()
+    pts = torch.tensor([[0., 0., 1.], [480., 0., 1.], [0., 360., 1.], [480., 360., 1.], [240., 180., 1.]]).T
+    pa, pb = H @ pts, torch.from_numpy(g['H_full']) @ pts
+    close(pa[:, :2] / pa[:, 2:3], pb[:, :2] / pb[:, 2:3], 5e-2, 'DLT action on corners (px)')
+    zero = torch.zeros(b, 126, device=dev)
+    m1, m2 = ops.spatial_meshes(off.to(dev), zero, zero, 360, 480)
+    rigid = torch.from_numpy(g['rigid'])
+    close(m1.cpu() + rigid, g['mesh_ref'], 5e-2, 'mesh_ref vs reference')
+    close(m2.cpu() + rigid, g['mesh_tgt'], 5e-2, 'mesh_tgt vs reference')
+    # against an fp64 evaluation of the same algebra the device solve must be far tighter
+    _, Ht, Hr = G.decompose(off.double(), 360, 480, 1.0)
+    close(m1.cpu() + rigid, G.homography_to_mesh(Hr, rigid.double()).float(), 2e-4, 'mesh_ref vs fp64')
+    th_ref, th_tgt = ops.spatial_decompose(off.to(dev), 360, 480)
+    _, Ht8, Hr8 = G.decompose(off.double(), 360, 480, 8.0)
+    Mm = torch.tensor([[30., 0., 30.], [0., 22.5, 22.5], [0., 0., 1.]], dtype=torch.float64)
+    close(th_ref, (torch.inverse(Mm) @ Hr8 @ Mm).float(), 2e-5, 'theta_ref')
+    close(th_tgt, (torch.inverse(Mm) @ Ht8 @ Mm).float(), 2e-5, 'theta_tgt')
+
+
+def test_homography_sampler(dev, golden):
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.utils import torch_homo_transform
+    g = golden('g2_homo')
+    U, th = cases.g2_inputs()
+    close(torch_homo_transform.transformer(U.to(dev), th.to(dev), (45, 60)), g['out'], 1e-4, 'homo nchw')
+    close(torch_homo_transform.transformer(U.to(dev), th.to(dev), (23, 31)), g['out_small'], 1e-4, 'homo nchw small')
+    out = ops.homo_warp_nhwc(ops.nchw_to_nhwc(U.to(dev)), th.to(dev), 45, 60)
+    close(ops.nhwc_to_nchw(out), g['out'], 1e-4, 'homo nhwc')
+
+
+def test_tps_points_and_tsmotion(dev, golden):
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.utils import torch_tps_transform_point
+    g = golden('g5_tps_points')
+    nrigid, warped, query = [t.to(dev) for t in cases.g5_meshes()]
+    close(torch_tps_transform_point.transformer(query, nrigid, warped), g['p_a'], 1e-5, 'tps points a')
+    close(torch_tps_transform_point.transformer(query, warped, nrigid), g['p_b'], 1e-5, 'tps points b')
+    # interpolation property: the spline maps its own control points onto the targets
+    close(torch_tps_transform_point.transformer(warped, warped, nrigid), nrigid, 2e-5, 'tps interpolation')
+    g8 = golden('g8_nets')
+    smesh, tsm = ops.tsmotion(torch.from_numpy(g8['motion1']).to(dev), torch.from_numpy(g8['tmotion1']).to(dev))
+    close(tsm, g8['tsmotion1'], 2e-3, 'tsmotion vs reference')
+
+
+def test_tps_dense_warp_and_fusion(dev, golden):
+    from stabstitch2_amd import ops, pipeline
+    from stabstitch2_amd.utils import torch_tps_transform
+    g = golden('g6_tps_warp')
+    U, src, tgt, size, ident = cases.g6_inputs()
+    Ud, sd, td = U.to(dev), src.to(dev), tgt.to(dev)
+    wn = torch_tps_transform.transformer(Ud, sd, td, size, 'NORMAL')
+    wf = torch_tps_transform.transformer(Ud, sd, td, size, 'FAST')
+    close(wn[:, 3:5], g['normal'][:, 3:5], 2e-4 * 96 / 2 + 1e-4, 'coords NORMAL (px)')
+    close(wn[:, 0:3], g['normal'][:, 0:3], 2e-3, 'intensity NORMAL')
+    close(wf, g['fast'], 2e-3, 'FAST')
+    close(torch_tps_transform.transformer(Ud, ident.to(dev), td, (72, 96), 'NORMAL'), g['ident_normal'], 2e-3, 'id N')
+    close(torch_tps_transform.transformer(Ud, ident.to(dev), td, (72, 96), 'FAST'), g['ident_fast'], 2e-3, 'id F')
+    g7 = golden('g7_fusion')
+    T = ops.tps_solve(sd, td)
+    wm = ops.tps_warp(Ud[:, 0:3].contiguous(), sd, T, size[0], size[1], 'NORMAL', with_mask=True)
+    close(wm, g7['warped_with_mask'], 2e-3, 'warp + ones mask')
+    fused = ops.render_average([Ud[0, 0:3].contiguous(), Ud[1, 0:3].contiguous()], sd, T, size[0], size[1], 'NORMAL')
+    close(fused, g7['average'], 3e-3, 'fused AVERAGE render')
+    gm = torch.from_numpy(g7['warped_with_mask']).to(dev)
+    lin = pipeline.linear_blender(gm[0:1, 0:3], gm[1:2, 0:3], gm[0:1, 3:4], gm[1:2, 3:4])
+    close(lin, g7['linear'], 1e-3, 'LINEAR fusion')
+    mk = pipeline.linear_blender(gm[0:1, 0:3], gm[1:2, 0:3], gm[0:1, 3:4], gm[1:2, 3:4], mask=True)
+    close(mk, g7['mask1'], 1e-5, 'LINEAR mask1')
+
+
+# ------------------------------------------------------------------ nets / pipeline
+@pytest.fixture(scope='module')
+def hip_nets(dev):
+    from stabstitch2_amd.spatial_network import SpatialNet
+    from stabstitch2_amd.temporal_network import TemporalNet
+    from stabstitch2_amd.smooth_network import SmoothNet
+    nets = []
+    for cls in (SpatialNet, TemporalNet, SmoothNet):
+        m = cls()
+        m.load_state_dict(synth.synthetic_state_dict(m), strict=True)
+        nets.append(m.to(dev))
+    return nets
+
+
+@pytest.fixture(scope='module')
+def clip16():
+    return synth.make_clip(16, 360, 480, seed=0)
+
+
+def test_nets_vs_reference(dev, golden, hip_nets, clip16):
+    from stabstitch2_amd.spatial_network import build_SpatialNet
+    from stabstitch2_amd.temporal_network import build_TemporalNet
+    from stabstitch2_amd.smooth_network import build_SmoothNet
+    assert [len(m.state_dict()) for m in hip_nets] == [130, 104, 14]
+    g = golden('g8_nets')
+    sp, tp, sm = hip_nets
+    _, lr = clip16
+    o1, o2r, o2t = sp(lr[0][0].to(dev), lr[1][0].to(dev))
+    close(o1, g['offset_1'], 1e-3, 'offset_1')
+    close(o2r, g['offset_2_ref'], 1e-3, 'offset_2_ref')
+    close(o2t, g['offset_2_tgt'], 1e-3, 'offset_2_tgt')
+    lr1 = torch.cat(lr[0], 0).to(dev)
+    lr2 = torch.cat(lr[1], 0).to(dev)
+    o = build_SpatialNet(sp, lr1, lr2)                      # whole clip as one batch
+    close(o['motion1'], g['motion1'], 5e-2, 'motion1')
+    close(o['motion2'], g['motion2'], 5e-2, 'motion2')
+    tm = build_TemporalNet(tp, [f.to(dev) for f in lr[0]])['motion_list']
+    close(torch.cat(tm, 0), g['tmotion1'], 1e-3, 'tmotion1')
+    rigid = torch.from_numpy(cases.rigid(360, 480)).to(dev)
+    ts1 = [torch.from_numpy(g['tsmotion1'][i:i + 1]).to(dev) for i in range(7)]
+    ts2 = [torch.from_numpy(g['tsmotion2'][i:i + 1]).to(dev) for i in range(7)]
+    ts1[0] = ts1[0] * 0
+    ts2[0] = ts2[0] * 0
+    sm1 = [rigid + torch.from_numpy(g['motion1'][i:i + 1]).to(dev) for i in range(7)]
+    sm2 = [rigid + torch.from_numpy(g['motion2'][i:i + 1]).to(dev) for i in range(7)]
+    w0 = build_SmoothNet(sm, ts1, ts2, sm1, sm2)
+    assert sorted(w0) == sorted(k[3:] for k in g.files if k.startswith('w0_'))
+    for k, v in w0.items():
+        close(v, g['w0_' + k], 2e-3, 'window0 ' + k)
+
+
+def test_pipeline_vs_reference(dev, golden, hip_nets, clip16):
+    from stabstitch2_amd import pipeline
+    g = golden('g9_pipeline')
+    hr, lr = clip16
+    acc = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+    close(acc['smooth_mesh1'], g['smooth_mesh1'], 5e-2, 'smooth_mesh1')
+    close(acc['smooth_mesh2'], g['smooth_mesh2'], 5e-2, 'smooth_mesh2')
+    close(acc['ori_path2'], g['ori_path2'], 5e-2, 'ori_path2')
+    close(acc['smooth_path2'], g['smooth_path2'], 5e-2, 'smooth_path2')
+    m1 = torch.from_numpy(g['smooth_mesh1']).to(dev)
+    m2 = torch.from_numpy(g['smooth_mesh2']).to(dev)
+    for wm, fm in (('NORMAL', 'AVERAGE'), ('FAST', 'AVERAGE'), ('NORMAL', 'LINEAR')):
+        tag = '%s_%s' % (wm.lower(), fm.lower())
+        frames, ow, oh = pipeline.get_stable_sqe(hr[0], hr[1], m1, m2, wm, fm)
+        assert [int(oh), int(ow)] == list(g['canvas_' + tag])
+        got = np.stack([cases.box_down(f, 16) for f in frames])
+        close(got, g['frames_' + tag], 2e-2, 'frames ' + tag)
+        if tag == 'normal_average':
+            close(frames[0][150:214, 300:396], g['frame0_crop'], 5e-2, 'frame0 crop')
+    # alignment PSNR / SSIM of the metric harness on device warps (fp64 metric arithmetic of the oracle)
+    from stabstitch2_amd import metrics
+    w1 = metrics.warp_lr_with_mask(torch.cat(lr[0], 0).to(dev), m1)
+    w2 = metrics.warp_lr_with_mask(torch.cat(lr[1], 0).to(dev), m2)
+    for i in range(16):
+        p, s = M.alignment_psnr_ssim(w1[i].cpu().numpy(), w2[i].cpu().numpy())
+        assert abs(p - g['psnr'][i]) < 0.01, (i, p, g['psnr'][i])
+        assert abs(s - g['ssim'][i]) < 1e-3, (i, s, g['ssim'][i])
+    # end to end with the pipeline's own meshes
+    frames, hc, wc, sm1, sm2 = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets)
+    assert [hc, wc] == list(g['canvas_normal_average'])
+    got = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), 16) for f in frames])
+    close(got, g['frames_normal_average'], 5e-2, 'end-to-end frames')
+
+
+def test_three_view_vs_reference(dev, golden):
+    from stabstitch2_amd import pipeline
+    g = golden('g10_threeview')
+    meshes = [m.to(dev) for m in cases.g10_meshes()]
+    n = meshes[0].shape[1]
+    hr, _ = synth.make_clip(n, 180, 320, seed=3, views=3)
+    mesh1, mid, mesh3 = pipeline.three_view_compose(*meshes, 180, 320)
+    close(mesh1, g['mesh1'], 5e-2, 'mesh1')
+    close(mid, g['middle'], 5e-2, 'middle')
+    close(mesh3, g['mesh3'], 5e-2, 'mesh3')
+    gm = [torch.from_numpy(g[k]).to(dev) for k in ('mesh1', 'middle', 'mesh3')]
+    for fm in ('AVERAGE', 'LINEAR'):
+        frames, hc, wc = pipeline.three_view_render(hr[0], hr[1], hr[2], *gm, 'NORMAL', fm)
+        assert [hc, wc] == list(g['canvas_' + fm.lower()])
+        got = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), 4) for f in frames])
+        close(got, g['frames_' + fm.lower()], 5e-2, 'three-view ' + fm)
+
+
+def test_missing_device_fails_loudly():
+    from stabstitch2_amd import ops, _hip
+    with pytest.raises(_hip.HipError):
+        ops.maxpool(torch.zeros(1, 4, 4, 4), 2, 2)
