@@ -259,7 +259,13 @@ __global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict_
             if (c == 0) v = 1.0;
             else if (c == 1) v = sx[r];
             else if (c == 2) v = sy[r];
-            else if (c < SS_NT) v = (double)tps_rbf(__fsub_rn(sx[r], sx[c - 3]), __fsub_rn(sy[r], sy[c - 3]));
+            else if (c < SS_NT) {
+                // fp32 kernel entries like the reference, but with a correctly rounded log (via fp64): the
+                // 66x66 system amplifies last-bit differences of logf ~100x into T (measured 3e-5 on |T|<2)
+                float dx = __fsub_rn(sx[r], sx[c - 3]), dy = __fsub_rn(sy[r], sy[c - 3]);
+                float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                v = (double)__fmul_rn(d2, (float)log((double)__fadd_rn(d2, 1e-6f)));
+            }
             else v = tgt[r * 2 + (c - SS_NT)];
         } else if (c >= 3 && c < SS_NT) {
             int k = r - SS_NV;

@@ -112,8 +112,25 @@ def g11_images():
 
 
 def box_down(frame, k=8):
-    """[H,W,C] -> box-downsampled [H//k, W//k, C] (crop remainder)."""
+    """[H,W,C] -> per-box MEDIAN [H//k, W//k, C] (crop remainder).  Median, not mean: the reference's AVERAGE
+    fusion a*a/(a+b+1e-6) is singular where a+b ~ -1e-6 (outside the valid region the clamped-weight sampler leaves
+    +-1e-5 residues instead of exact zeros), so isolated pixels are arbitrarily large in any implementation."""
     h, w, c = frame.shape
     hh, ww = (h // k) * k, (w // k) * k
-    f = frame[:hh, :ww].reshape(hh // k, k, ww // k, k, c)
-    return f.mean(axis=(1, 3)).astype(np.float32)
+    f = frame[:hh, :ww].reshape(hh // k, k, ww // k, k, c).transpose(0, 2, 4, 1, 3).reshape(hh // k, ww // k, c, k * k)
+    return np.median(f, axis=3).astype(np.float32)
+
+
+def box_iqr(frame, k=8):
+    """Value range (max - min) per box.  Boxes straddling a view boundary (part ~0, part image) have a median that
+    flips with a one-pixel shift of the boundary; the comparisons skip them (smooth_boxes).  (Kept under the name
+    `iqr` in the fixtures.)"""
+    h, w, c = frame.shape
+    hh, ww = (h // k) * k, (w // k) * k
+    f = frame[:hh, :ww].reshape(hh // k, k, ww // k, k, c).transpose(0, 2, 4, 1, 3).reshape(hh // k, ww // k, c, k * k)
+    return (f.max(axis=3) - f.min(axis=3)).astype(np.float32)
+
+
+def smooth_boxes(rng, k=16):
+    """Boolean mask of boxes whose golden value range is explained by the smooth synthetic texture (< ~3.5 / px)."""
+    return rng < 3.5 * k + 8.0

@@ -209,6 +209,7 @@ def g8_g9(nets):
         tag = '%s_%s' % (wm.lower(), fm.lower())
         g9['canvas_' + tag] = np.array([int(oh), int(ow)])
         g9['frames_' + tag] = np.stack([cases.box_down(f, 16) for f in frames])
+        g9['iqr_' + tag] = np.stack([cases.box_iqr(f, 16) for f in frames])
         if tag == 'normal_average':
             g9['frame0_crop'] = frames[0][150:214, 300:396].copy()   # full-resolution crop across the seam
     # metric harness: LR warps with masks -> PSNR/SSIM by scikit-image 0.18.3
@@ -274,6 +275,7 @@ def g10():
         res['canvas_' + tag] = np.array([int(ns['out_height'].int()), int(ns['out_width'].int())])
         res['frames_' + tag] = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), 4)
                                          for f in ns['stable_list']])
+        res['iqr_' + tag] = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), 4) for f in ns['stable_list']])
         if fm == 'AVERAGE':
             res['mesh1'] = ns['warp12_mesh1']
             res['middle'] = ns['middle_mesh']
