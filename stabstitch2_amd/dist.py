@@ -1,0 +1,29 @@
+"""Multi-GPU sharding of independent video streams (one process per GPU, torch.distributed; backend "nccl" = RCCL
+over xGMI on ROCm, "gloo" in the CPU tests).  The reference is single-process / single-GPU
+(test_online_tra.py:160-161); independent video pairs have no data dependency, so streams are dealt round-robin to
+ranks and the only collective is one all_gather of a small per-rank record at the end of a run."""
+import torch
+
+
+def shard_streams(n_streams, rank, world_size):
+    """Stream ids handled by `rank`: i with i % world_size == rank (stream i -> GPU i mod N)."""
+    if not 0 <= rank < world_size:
+        raise ValueError('rank %d outside world of %d' % (rank, world_size))
+    return list(range(rank, n_streams, world_size))
+
+
+def gather_records(record, dist=None, device=None):
+    """record: 1-D float64 tensor of fixed length -> [world, len] tensor on the host (identity without dist)."""
+    record = record.to(torch.float64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return record.detach().cpu().unsqueeze(0)
+    if device is not None:
+        record = record.to(device)
+    out = [torch.zeros_like(record) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, record)
+    return torch.stack(out).cpu()
+
+
+def aggregate_fps(records):
+    """records [world, >=2] with columns (frames, seconds, ...): whole-job fps = sum(frames) / max(seconds)."""
+    return float(records[:, 0].sum()) / float(records[:, 1].max())

@@ -139,3 +139,34 @@ def write_synthetic_checkpoints(model_dir, spatial, temporal, smooth):
     os.makedirs(model_dir, exist_ok=True)
     for name, mod in (('spatial_warp', spatial), ('temporal_warp', temporal), ('smooth_warp', smooth)):
         torch.save({'model': synthetic_state_dict(mod)}, os.path.join(model_dir, name + '.pth'))
+
+
+def make_clip_device(n_frames, height, width, seed=0, views=2, device='cuda'):
+    """Same clip as make_clip, evaluated with torch on `device` (fp64 phase, fp32 result) so that 720p clips for
+    the benchmark are produced in milliseconds.  -> (hr [V,N,3,H,W], lr [V,N,3,360,480]) device tensors."""
+    amp, fx, fy, phase = _texture_table()
+    rs = np.random.RandomState(1000 + seed)
+    sigma = 1.5 * height / 360.0
+    x0, y0 = 40.0 + 13.0 * seed, 30.0 + 7.0 * seed
+    dev = torch.device(device)
+    t_amp = torch.tensor(amp, dtype=torch.float64, device=dev).view(8, 1, 1, 1)
+    t_fx = torch.tensor(fx, dtype=torch.float64, device=dev).view(8, 1, 1, 1)
+    t_fy = torch.tensor(fy, dtype=torch.float64, device=dev).view(8, 1, 1, 1)
+    t_ph = torch.tensor(phase, dtype=torch.float64, device=dev).view(8, 3, 1, 1)
+    cols = torch.arange(width, dtype=torch.float64, device=dev).view(1, 1, 1, width)
+    rows = torch.arange(height, dtype=torch.float64, device=dev).view(1, 1, height, 1)
+    hr_all, lr_all = [], []
+    for v in range(views):
+        sx = _ar1(rs, n_frames, sigma)
+        sy = _ar1(rs, n_frames, sigma)
+        hrs = []
+        for t in range(n_frames):
+            xs = x0 + 0.45 * width * v + sx[t] + cols
+            ys = y0 + sy[t] + rows
+            arg = 2 * np.pi * (t_fx * xs + t_fy * ys)
+            img = 127.5 + (t_amp * torch.sin(arg + t_ph)).sum(0)
+            hrs.append(img.clamp(0.0, 255.0).float())
+        hr = torch.stack(hrs, 0)
+        hr_all.append(hr)
+        lr_all.append(torch.cat([to_lr(hr[i:i + 1]) for i in range(n_frames)], 0))
+    return torch.stack(hr_all, 0), torch.stack(lr_all, 0)

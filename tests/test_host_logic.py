@@ -1,0 +1,160 @@
+"""CPU-only checks of the host side: C-ABI surface, checkpoint layout, weight repacking, layout rules, sharding."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    from stabstitch2_amd import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _hip.lib()
+
+
+def test_cabi_exports_every_declared_symbol(built_lib):
+    from stabstitch2_amd import _hip
+    hdr = open(os.path.join(ROOT, 'include', 'stabstitch_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(built_lib, name), name
+    assert sorted(_hip.SIGNATURES) == declared, 'ctypes table and header disagree'
+    assert built_lib.ss_version() >= 100
+    assert built_lib.ss_error_string(-1) == b'bad argument'
+    # argument validation happens before any device work, so it can be exercised without a GPU
+    assert built_lib.ss_conv_nhwc(None, None, None, None, None, *([1] * 15), 1, 0, 0, 0, None) == -1
+    assert built_lib.ss_maxpool_nhwc(None, None, 1, 4, 4, 4, 2, 2, 0, None) == -1
+    assert built_lib.ss_tps_solve(None, None, None, 1, None) == -1
+    assert built_lib.ss_ccl_workspace_floats(2, 23, 30, 256) == 2 * 690 * (512 + 690)
+    assert built_lib.ss_tsmotion_workspace_floats(10) == 126 + 10 * 384
+
+
+def test_product_never_imports_oracle_and_fails_without_gpu():
+    pkg = os.path.join(ROOT, 'stabstitch2_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dirpath, f)
+    assert 'TEST INFRASTRUCTURE ONLY' in open(os.path.join(ROOT, 'oracle', '__init__.py')).read()
+    from stabstitch2_amd import ops, _hip
+    with pytest.raises(_hip.HipError):
+        ops.linear(torch.zeros(1, 4), torch.zeros(2, 4))          # CPU tensors are refused: no CPU path
+    from stabstitch2_amd.spatial_network import SpatialNet
+    with pytest.raises(_hip.HipError):
+        SpatialNet()(torch.zeros(1, 3, 360, 480), torch.zeros(1, 3, 360, 480))
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    from stabstitch2_amd import synth
+    from stabstitch2_amd.spatial_network import SpatialNet
+    from stabstitch2_amd.temporal_network import TemporalNet
+    from stabstitch2_amd.smooth_network import SmoothNet
+    from oracle import nets as ON
+    nets = [SpatialNet(), TemporalNet(), SmoothNet()]
+    synth.write_synthetic_checkpoints(str(tmp_path), *nets)
+    assert sorted(os.listdir(tmp_path)) == ['smooth_warp.pth', 'spatial_warp.pth', 'temporal_warp.pth']
+    for name, net, ocls, count in (('spatial_warp', nets[0], ON.SpatialNet, 130),
+                                   ('temporal_warp', nets[1], ON.TemporalNet, 104),
+                                   ('smooth_warp', nets[2], ON.SmoothNet, 14)):
+        ck = torch.load(os.path.join(tmp_path, name + '.pth'))
+        assert list(ck) == ['model'] and len(ck['model']) == count
+        net.load_state_dict(ck['model'], strict=True)
+        ocls().load_state_dict(ck['model'], strict=True)          # same keys as the oracle (= the reference layout)
+    keys = set(nets[0].state_dict())
+    for k in ('regressNet1_part1.12.weight', 'regressNet2_part1_ref.17.weight', 'regressNet2_part2_tgt.4.bias',
+              'feature_extractor_stage1.0.weight', 'feature_extractor_stage1.1.running_var',
+              'feature_extractor_stage1.5.0.downsample.1.num_batches_tracked',
+              'feature_extractor_stage2.0.1.bn2.weight'):
+        assert k in keys, k
+    assert 'MotionPre.embedding2.0.weight' in nets[2].state_dict()      # unused by forward, required by strict load
+
+
+def test_weight_repacking_matches_eval_semantics():
+    from stabstitch2_amd import layers as L
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(3, 8, 3, 2, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(8).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.normal_(); bn.bias.data.normal_()
+    x = torch.randn(2, 3, 9, 11)
+    w, b = L.pack_conv2d(conv, bn)
+    assert w.shape == (8, 1, 3, 3, 4) and float(w[..., 3].abs().max()) == 0.0
+    y = F.conv2d(x, w[:, 0, :, :, :3].permute(0, 3, 1, 2), b, stride=2, padding=1)
+    assert torch.allclose(y, bn(conv(x)), atol=1e-5)
+    lin = torch.nn.Linear(5 * 6, 7)
+    act = torch.randn(2, 5, 2, 3)                                   # NCHW feature map, c=5, hw=6
+    w2, b2 = L.pack_fc_first(lin, 5, 6)
+    nhwc_flat = act.permute(0, 2, 3, 1).reshape(2, -1)
+    assert torch.allclose(F.linear(nhwc_flat, w2, b2), lin(act.reshape(2, -1)), atol=1e-6)
+    c3 = torch.nn.Conv3d(4, 6, (5, 3, 3), padding=(2, 1, 1))
+    w3, b3 = L.pack_conv3d(c3)
+    assert w3.shape == (6, 5, 3, 3, 4) and torch.equal(w3[2, 4, 1, 0, 3], c3.weight[2, 3, 4, 1, 0])
+
+
+def test_synthetic_inputs_are_deterministic():
+    from stabstitch2_amd import synth
+    a = synth.make_clip(2, 72, 96, seed=3)
+    b = synth.make_clip(2, 72, 96, seed=3)
+    assert torch.equal(a[0][1][1], b[0][1][1]) and a[1][0][0].shape == (1, 3, 360, 480)
+    hr, lr = synth.make_clip_device(2, 72, 96, seed=3, device='cpu')
+    assert float((hr[1, 1] - a[0][1][1][0]).abs().max()) < 1e-3
+    assert float(lr.abs().max()) <= 1.0 + 1e-6
+    from oracle import nets as ON
+    sd1 = synth.synthetic_state_dict(ON.SmoothNet())
+    sd2 = synth.synthetic_state_dict(ON.SmoothNet())
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+
+
+def test_stream_sharding_rules():
+    from stabstitch2_amd import dist as D
+    assert D.shard_streams(8, 3, 8) == [3]
+    assert D.shard_streams(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((D.shard_streams(11, r, 4) for r in range(4)), [])) == list(range(11))
+    with pytest.raises(ValueError):
+        D.shard_streams(4, 4, 4)
+    rec = torch.tensor([[64.0, 2.0], [64.0, 4.0]], dtype=torch.float64)
+    assert D.aggregate_fps(rec) == 32.0
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from stabstitch2_amd import dist as D
+    mine = D.shard_streams(5, rank, world)
+    rec = torch.tensor([32.0 * len(mine), 1.0 + rank, 740.0, 1882.0 + rank], dtype=torch.float64)
+    allrec = D.gather_records(rec, dist)
+    dist.barrier()
+    q.put((rank, mine, allrec.tolist()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    for _, _, allrec in res:
+        assert allrec == [[96.0, 1.0, 740.0, 1882.0], [64.0, 2.0, 740.0, 1883.0]]
+    from stabstitch2_amd import dist as D
+    assert D.aggregate_fps(torch.tensor(res[0][2])) == 160.0 / 2.0
