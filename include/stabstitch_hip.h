@@ -46,12 +46,16 @@ int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, int
  *   wgt  [cout][kt][kh][kw][cin]      (BN folded by the caller)
  *   bias [cout] or NULL, res (same shape as out) or NULL
  *   out  [n][to][ho][wo][out_cs]      first cout channels written (out_cs >= cout)
- * stride applies to h and w (temporal stride is 1).  `groups` > 1 runs `groups` independent
- * problems with element strides in_gs / w_gs / out_gs between them (used by the CCL Gram). */
+ * stride applies to h and w (temporal stride is 1); kernel extents <= 8 per axis.  `groups` > 1 runs
+ * `groups` independent problems with element strides in_gs / w_gs / out_gs between them (used by the
+ * CCL Gram).  ws / ws_floats: optional caller workspace for split-K partial sums of small problems
+ * (ss_conv_workspace_floats() is always enough; NULL disables splitting). */
+long long ss_conv_workspace_floats(void);
 int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const float* res, float* out,
                  int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw, int stride,
                  int pad_t, int pad_h, int pad_w, int relu, int out_cs,
-                 int groups, long long in_gs, long long w_gs, long long out_gs, void* stream);
+                 int groups, long long in_gs, long long w_gs, long long out_gs,
+                 float* ws, long long ws_floats, void* stream);
 
 /* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */
 int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,

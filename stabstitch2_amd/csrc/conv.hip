@@ -4,16 +4,32 @@
 //   GEMM view  D[m][co] = sum_k A[m][k] * Wt[co][k]
 //     m  = (n, to, ho, wo)  output position          (rows, M = n*to*ho*wo)
 //     k  = (dt, dh, dw, ci) filter tap x in-channel  (ci fastest, cin % 4 == 0)
-//   Block = 256 threads = 2x2 waves, each wave owns WM x WN tiles of 32x32 (16 acc VGPRs each).
-//   K is walked in tiles of 16: global -> registers (one float4 per thread per 64 rows, 4 lanes
-//   cover one 64-byte run of a row) -> LDS stored k-major ([16][rows+4]) so that the MFMA
-//   operand read (lane l: row l&31, k = 2j + (l>>5)) is a conflict-free ds_read_b32;
-//   double-buffered LDS, one barrier per K tile, next tile's global loads in flight under the MFMAs.
-//   Epilogue: bias (folded BatchNorm), residual, ReLU; for a fixed accumulator register the 32
-//   lanes of a half-wave hold 32 consecutive output channels -> 128-byte coalesced NHWC stores.
+//   Block = 256 threads = WGM x WGN waves (=4), each wave owns WM x WN tiles of 32x32 (16 accumulator
+//   registers each); block tile BM x BN = (WGM*WM*32) x (WGN*WN*32).
+//   The MFMA pipe only stays busy if the non-MFMA instruction count per MFMA is small (one 64-cycle
+//   v_mfma_f32_32x32x2 hides ~10 other issues; the first version of this kernel issued 10.6 and ran the
+//   pipe at 60 %), so everything around the MFMAs is built to be cheap:
+//     * K is walked 32 at a time; one 16-byte buffer_load per thread per 32 tile rows.  Halo taps, the M
+//       tail and the K tail are handled by the buffer descriptor's bounds check: an invalid lane gets byte
+//       offset 0xFFFFFFFF and the hardware returns zeros -- no branches, no selects on the data;
+//     * per row the thread keeps one base offset and one packed validity word (bit masks of the valid
+//       dt / dh / dw), per K tile one tap offset: address = base + tap, valid = 3 shifts and 2 ands;
+//     * LDS holds rows k-contiguous ([rows][32+4]); the K index inside a tile is permuted so that lane half
+//       h of the MFMA takes k = 16h + j: every lane reads its 16 operands as four ds_read_b128 (row stride
+//       36 dwords = 4*9 keeps each 16-lane group on 16 distinct 16-byte slots: conflict free), and the
+//       staging store is one ds_write_b128;
+//     * LDS double-buffered, one barrier per K tile, next tile's loads in flight under the MFMAs.
+//   Epilogue: bias (folded BatchNorm), residual, ReLU; for a fixed accumulator register the 32 lanes of a
+//   half-wave hold 32 consecutive output channels -> 128-byte coalesced NHWC stores.
+//   Small problems (few tiles, long K) are split along K into `splits` partial sums written to a caller
+//   workspace and combined (deterministically) by splitk_reduce_kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvP {
     const float* in;
@@ -21,68 +37,88 @@ struct ConvP {
     const float* bias;
     const float* res;
     float* out;
+    float* partial;          // split-K workspace [groups*splits][M][Co] or nullptr
     int T, H, W, C;
     int To, Ho, Wo, Co;
-    int kh, kw, s;
+    int kt, kh, kw, s;
     int pt, ph, pw;
     int K, M;
     uint32_t mulC, mulKw, mulKh;
     int relu, out_cs;
+    int splits, tiles_per_split;
     long long in_gs, w_gs, out_gs;
+    unsigned in_bytes, w_bytes;      // per-group extents for the buffer descriptors
+    int ablate;                      // tuning aid (SS_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
 };
 
-#define BK 16
+#define BK 32
+#define LDK 36
 
-template <int WM, int WN>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base, unsigned bytes) {
+    unsigned long long a = (unsigned long long)base;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* ub = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int WGM, int WGN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
-    constexpr int BM = 64 * WM;
-    constexpr int BN = 64 * WN;
-    constexpr int LDA = BM + 4;
-    constexpr int LDB = BN + 4;
-    __shared__ float As[2][BK][LDA];
-    __shared__ float Bs[2][BK][LDB];
+    constexpr int BM = WGM * WM * 32;
+    constexpr int BN = WGN * WN * 32;
+    constexpr int RA = BM / 32;   // A rows staged per thread
+    constexpr int RB = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WGN, wc = wave % WGN;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const float* __restrict__ in = p.in + (long long)blockIdx.z * p.in_gs;
-    const float* __restrict__ wgt = p.wgt + (long long)blockIdx.z * p.w_gs;
+    const int grp = blockIdx.z / p.splits;
+    const int split = blockIdx.z - grp * p.splits;
 
-    const int lrow = tid >> 2;   // 0..63
-    const int kq = tid & 3;      // which float4 of the 16-wide K tile
+    // descriptor inputs through readfirstlane so that the compiler can prove the SRD wave-uniform (otherwise
+    // every buffer_load is wrapped in a waterfall loop)
+    const __amdgpu_buffer_rsrc_t rin = uniform_rsrc(p.in + (long long)grp * p.in_gs, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rw = uniform_rsrc(p.wgt + (long long)grp * p.w_gs, p.w_bytes);
 
-    // per-thread row bookkeeping (fixed over the K loop)
-    int r_ti0[WM], r_hi0[WM], r_wi0[WM], r_nb[WM];
-    bool r_ok[WM];
+    const int lrow = tid >> 3;   // 0..31
+    const int kq = tid & 7;      // which float4 of the 32-wide K tile
+
+    // per-thread row bookkeeping (fixed over the K loop): byte offset of tap (0,0,0) and validity masks
+    int a_off[RA];
+    unsigned a_msk[RA];          // bits 0..7: valid dw, 8..15: valid dh, 16..23: valid dt (0 for rows >= M)
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        int m = m0 + lrow + i * 64;
-        r_ok[i] = m < p.M;
-        int mm = r_ok[i] ? m : 0;
+    for (int i = 0; i < RA; ++i) {
+        int m = m0 + lrow + i * 32;
+        bool ok = m < p.M;
+        int mm = ok ? m : 0;
         int wo = mm % p.Wo;
         int t1 = mm / p.Wo;
         int ho = t1 % p.Ho;
         int t2 = t1 / p.Ho;
         int to = t2 % p.To;
         int n = t2 / p.To;
-        r_ti0[i] = to - p.pt;
-        r_hi0[i] = ho * p.s - p.ph;
-        r_wi0[i] = wo * p.s - p.pw;
-        r_nb[i] = n * p.T;
+        int ti0 = to - p.pt, hi0 = ho * p.s - p.ph, wi0 = wo * p.s - p.pw;
+        a_off[i] = (((n * p.T + ti0) * p.H + hi0) * p.W + wi0) * p.C * 4;     // bytes
+        unsigned msk = 0;
+        for (int d = 0; d < p.kw; ++d) msk |= ((unsigned)(wi0 + d) < (unsigned)p.W ? 1u : 0u) << d;
+        for (int d = 0; d < p.kh; ++d) msk |= ((unsigned)(hi0 + d) < (unsigned)p.H ? 1u : 0u) << (8 + d);
+        for (int d = 0; d < p.kt; ++d) msk |= ((unsigned)(ti0 + d) < (unsigned)p.T ? 1u : 0u) << (16 + d);
+        a_msk[i] = ok ? msk : 0u;
     }
-    long long w_off[WN];
-    bool w_ok[WN];
+    unsigned w_off[RB], w_bad[RB];
 #pragma unroll
-    for (int i = 0; i < WN; ++i) {
-        int co = n0 + lrow + i * 64;
-        w_ok[i] = co < p.Co;
-        w_off[i] = (long long)(w_ok[i] ? co : 0) * p.K;
+    for (int i = 0; i < RB; ++i) {
+        int co = n0 + lrow + i * 32;
+        w_off[i] = (unsigned)co * (unsigned)p.K * 4u;
+        w_bad[i] = co < p.Co ? 0u : 0xFFFFFFFFu;
     }
 
-    float4 ra[WM], rb[WN];
+    u32x4 ra[RA], rb[RB];
     auto gload = [&](int kt) {
         int k = kt * BK + kq * 4;
         bool kok = k < p.K;
@@ -92,42 +128,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         int dw = (int)tap - (int)t2 * p.kw;
         uint32_t dt = ss_fastdiv(t2, p.mulKh);
         int dh = (int)t2 - (int)dt * p.kh;
+        int tapoff = ((((int)dt * p.H + dh) * p.W + dw) * p.C + ci) * 4;     // bytes
+        unsigned sw = (unsigned)dw, sh = 8u + (unsigned)dh, st = 16u + dt;
+        // branch-free: an invalid lane ORs its offset up to 0xFFFFFFFF and the descriptor returns zeros
+        const unsigned kmask = kok ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            int ti = r_ti0[i] + (int)dt, hi = r_hi0[i] + dh, wi = r_wi0[i] + dw;
-            bool ok = kok && r_ok[i] && (unsigned)ti < (unsigned)p.T && (unsigned)hi < (unsigned)p.H &&
-                      (unsigned)wi < (unsigned)p.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                long long a = ((((long long)(r_nb[i] + ti)) * p.H + hi) * p.W + wi) * p.C + ci;
-                v = *reinterpret_cast<const float4*>(in + a);
-            }
-            ra[i] = v;
+        for (int i = 0; i < RA; ++i) {
+            unsigned m = a_msk[i];
+            unsigned v = (m >> sw) & (m >> sh) & (m >> st) & 1u;
+            unsigned off = ((unsigned)(a_off[i] + tapoff)) | (v - 1u) | kmask;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < WN; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kok && w_ok[i]) v = *reinterpret_cast<const float4*>(wgt + w_off[i] + k);
-            rb[i] = v;
+        for (int i = 0; i < RB; ++i) {
+            unsigned off = (w_off[i] + (unsigned)k * 4u) | w_bad[i] | kmask;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            int r = lrow + i * 64;
-            As[buf][kq * 4 + 0][r] = ra[i].x;
-            As[buf][kq * 4 + 1][r] = ra[i].y;
-            As[buf][kq * 4 + 2][r] = ra[i].z;
-            As[buf][kq * 4 + 3][r] = ra[i].w;
-        }
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<u32x4*>(&As[buf][(lrow + i * 32) * LDK + kq * 4]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < WN; ++i) {
-            int r = lrow + i * 64;
-            Bs[buf][kq * 4 + 0][r] = rb[i].x;
-            Bs[buf][kq * 4 + 1][r] = rb[i].y;
-            Bs[buf][kq * 4 + 2][r] = rb[i].z;
-            Bs[buf][kq * 4 + 3][r] = rb[i].w;
-        }
+        for (int i = 0; i < RB; ++i)
+            *reinterpret_cast<u32x4*>(&Bs[buf][(lrow + i * 32) * LDK + kq * 4]) = rb[i];
     };
 
     f32x16 acc[WM][WN];
@@ -138,52 +162,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = split * p.tiles_per_split;
+    const int kt1 = min(nk_all, kt0 + p.tiles_per_split);
     const int li = lane & 31, lh = lane >> 5;
-    const int arow = wr * 32 * WM + li;
-    const int bcol = wc * 32 * WN + li;
+    const int aidx = (wr * WM * 32 + li) * LDK + lh * 16;
+    const int bidx = (wc * WN * 32 + li) * LDK + lh * 16;
 
-    gload(0);
-    lstore(0);
+    if (kt0 < kt1) {
+        gload(kt0);
+        lstore(0);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1 && !(p.ablate & 1)) gload(kt + 1);
+        // K tail: with the k = 16h + j permutation chunk c holds k in {4c..4c+3} u {16+4c..}; chunks past the
+        // end of K only multiply zeros (e.g. conv1: K = 196 -> the 7th tile needs 1 chunk of 4)
+        const int cmax = min(4, (p.K - kt * BK + 3) >> 2);
 #pragma unroll
-        for (int j = 0; j < BK / 2; ++j) {
-            float a[WM], b[WN];
+        for (int c = 0; c < 4; ++c) {
+            if (c >= cmax) break;
+            f32x4 a[WM], b[WN];
 #pragma unroll
-            for (int x = 0; x < WM; ++x) a[x] = As[buf][2 * j + lh][arow + x * 32];
+            for (int x = 0; x < WM; ++x) a[x] = *reinterpret_cast<const f32x4*>(&As[buf][aidx + x * 32 * LDK + c * 4]);
 #pragma unroll
-            for (int y = 0; y < WN; ++y) b[y] = Bs[buf][2 * j + lh][bcol + y * 32];
+            for (int y = 0; y < WN; ++y) b[y] = *reinterpret_cast<const f32x4*>(&Bs[buf][bidx + y * 32 * LDK + c * 4]);
 #pragma unroll
-            for (int x = 0; x < WM; ++x)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int y = 0; y < WN; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+                for (int x = 0; x < WM; ++x)
+#pragma unroll
+                    for (int y = 0; y < WN; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][s], b[y][s], acc[x][y], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < kt1 && !(p.ablate & 2)) lstore(buf ^ 1);
+        if (!(p.ablate & 4)) __syncthreads();
     }
 
     // epilogue
-    float* __restrict__ out = p.out + (long long)blockIdx.z * p.out_gs;
-    const float* __restrict__ res = p.res ? p.res + (long long)blockIdx.z * p.out_gs : nullptr;
+    const bool direct = p.splits == 1;
+    float* __restrict__ out = direct ? p.out + (long long)grp * p.out_gs
+                                     : p.partial + (long long)blockIdx.z * p.M * p.Co;
+    const float* __restrict__ res = (direct && p.res) ? p.res + (long long)grp * p.out_gs : nullptr;
+    const int ocs = direct ? p.out_cs : p.Co;
 #pragma unroll
     for (int y = 0; y < WN; ++y) {
-        int co = n0 + wc * 32 * WN + y * 32 + li;
+        int co = n0 + (wc * WN + y) * 32 + li;
         if (co >= p.Co) continue;
-        float bias = p.bias ? p.bias[co] : 0.f;
+        float bias = (direct && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int x = 0; x < WM; ++x) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m0 + wr * 32 * WM + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int m = m0 + (wr * WM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < p.M) {
-                    long long o = (long long)m * p.out_cs + co;
+                    long long o = (long long)m * ocs + co;
                     float v = acc[x][y][r] + bias;
                     if (res) v += res[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (direct && p.relu) v = fmaxf(v, 0.f);
                     out[o] = v;
                 }
             }
@@ -191,44 +228,112 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
 }
 
+// out[m][co] = relu(sum_s partial[s][m][co] + bias[co] + res[m][co]); fixed summation order
+__global__ void splitk_reduce_kernel(ConvP p) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long per = (long long)p.M * p.Co;
+    int grp = blockIdx.y;
+    if (idx >= per) return;
+    int co = (int)(idx % p.Co);
+    long long m = idx / p.Co;
+    const float* part = p.partial + (long long)grp * p.splits * per + idx;
+    float v = 0.f;
+    for (int s = 0; s < p.splits; ++s) v += part[(long long)s * per];
+    if (p.bias) v += p.bias[co];
+    long long o = (long long)grp * p.out_gs + m * p.out_cs + co;
+    if (p.res) v += p.res[o];
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.out[o] = v;
+}
+
+template <int WGM, int WGN, int WM, int WN>
+static void launch_conv(const ConvP& p, int groups, hipStream_t st) {
+    constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+    dim3 g(ss_cdiv(p.M, BM), ss_cdiv(p.Co, BN), groups * p.splits);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN>), g, dim3(256), 0, st, p);
+}
+
+extern "C" long long ss_conv_workspace_floats(void) { return 16ll << 20; }   // 64 MiB of split-K partials
+
 extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const float* res, float* out,
                             int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw, int stride,
                             int pad_t, int pad_h, int pad_w, int relu, int out_cs, int groups, long long in_gs,
-                            long long w_gs, long long out_gs, void* stream) {
+                            long long w_gs, long long out_gs, float* ws, long long ws_floats, void* stream) {
     if (!in || !wgt || !out || n <= 0 || t <= 0 || h <= 0 || w <= 0 || cin <= 0 || (cin & 3) || cout <= 0 ||
-        kt <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || groups <= 0 || out_cs < cout)
+        kt <= 0 || kh <= 0 || kw <= 0 || kt > 8 || kh > 8 || kw > 8 || stride <= 0 || groups <= 0 || out_cs < cout)
         return SS_ERR_ARG;
     ConvP p;
-    p.in = in; p.wgt = wgt; p.bias = bias; p.res = res; p.out = out;
+    p.in = in; p.wgt = wgt; p.bias = bias; p.res = res; p.out = out; p.partial = nullptr;
     p.T = t; p.H = h; p.W = w; p.C = cin;
     p.To = t + 2 * pad_t - kt + 1;
     p.Ho = (h + 2 * pad_h - kh) / stride + 1;
     p.Wo = (w + 2 * pad_w - kw) / stride + 1;
     p.Co = cout;
     if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return SS_ERR_ARG;
-    p.kh = kh; p.kw = kw; p.s = stride; p.pt = pad_t; p.ph = pad_h; p.pw = pad_w;
+    p.kt = kt; p.kh = kh; p.kw = kw; p.s = stride; p.pt = pad_t; p.ph = pad_h; p.pw = pad_w;
     long long K = (long long)kt * kh * kw * cin;
     long long M = (long long)n * p.To * p.Ho * p.Wo;
-    if (K >= 65536 || M >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
+    long long in_elems = (long long)n * t * h * w * cin;
+    long long w_elems = (long long)cout * K;
+    // 32-bit byte offsets inside one group (buffer addressing); padded halo offsets may be negative but a
+    // valid tap always lands inside [0, in_elems)
+    if (K >= 65536 || M >= (1ll << 31) || in_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31))
+        return SS_ERR_UNSUPPORTED;
     p.K = (int)K; p.M = (int)M;
     p.mulC = ss_fastdiv_magic((uint32_t)cin);
     p.mulKw = ss_fastdiv_magic((uint32_t)kw);
     p.mulKh = ss_fastdiv_magic((uint32_t)kh);
     p.relu = relu; p.out_cs = out_cs;
     p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
+    p.in_bytes = (unsigned)(in_elems * 4);
+    p.w_bytes = (unsigned)(w_elems * 4);
     hipStream_t st = (hipStream_t)stream;
-    // tile choice: keep >= ~2 workgroups per CU where the problem allows it
-    long long t22 = (long long)ss_cdiv(M, 128) * ss_cdiv(cout, 128) * groups;
-    long long t21 = (long long)ss_cdiv(M, 128) * ss_cdiv(cout, 64) * groups;
-    if (cout >= 128 && t22 >= 512) {
-        dim3 g(ss_cdiv(M, 128), ss_cdiv(cout, 128), groups);
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 2>), g, dim3(256), 0, st, p);
-    } else if (t21 >= 512) {
-        dim3 g(ss_cdiv(M, 128), ss_cdiv(cout, 64), groups);
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 1>), g, dim3(256), 0, st, p);
+    const int nk = ss_cdiv(K, BK);
+    p.splits = 1;
+    p.tiles_per_split = nk;
+    static const int ablate = getenv("SS_CONV_ABLATE") ? atoi(getenv("SS_CONV_ABLATE")) : 0;
+    p.ablate = ablate;
+
+    // tile choice by a small cost model: the chip runs `occ` workgroups per CU (LDS-limited) that share the
+    // CU's four MFMA pipes, so a launch takes ceil(blocks / 256) "rounds" of one tile's MFMA work; larger tiles
+    // run the pipe more efficiently (fewer LDS / global instructions per MFMA) but quantise worse.
+    struct Cand { int id; int bm, bn; float eff; };
+    static const Cand cands[3] = {{1, 128, 128, 1.00f}, {3, 128, 64, 0.93f}, {4, 64, 64, 0.74f}};
+    static const int force = getenv("SS_CONV_TILE") ? atoi(getenv("SS_CONV_TILE")) : 0;   // tuning aid only
+    int best = 4;
+    float best_t = 1e30f;
+    for (int i = 0; i < 3; ++i) {
+        const Cand& c = cands[i];
+        if (c.bn > 64 && cout <= 64) continue;
+        long long blocks = (long long)ss_cdiv(M, c.bm) * ss_cdiv(cout, c.bn) * groups;
+        float rounds = (float)((blocks + 255) / 256);
+        float t = rounds * (float)(c.bm * c.bn) / c.eff;
+        if (t < best_t) { best_t = t; best = c.id; }
+    }
+    if (force) best = force;
+    if (best == 1) {
+        launch_conv<2, 2, 2, 2>(p, groups, st);
+    } else if (best == 2) {
+        launch_conv<4, 1, 2, 2>(p, groups, st);
+    } else if (best == 3) {
+        launch_conv<2, 2, 2, 1>(p, groups, st);
     } else {
-        dim3 g(ss_cdiv(M, 64), ss_cdiv(cout, 64), groups);
-        hipLaunchKernelGGL((conv_igemm_kernel<1, 1>), g, dim3(256), 0, st, p);
+        // 64x64 tiles; small problems are additionally split along K so that ~512 workgroups exist
+        long long b64 = (long long)ss_cdiv(M, 64) * ss_cdiv(cout, 64) * groups;
+        int want = (int)((512 + b64 - 1) / b64);
+        int maxs = nk / 4 > 0 ? nk / 4 : 1;
+        int splits = want < maxs ? want : maxs;
+        long long need = (long long)groups * splits * M * cout;
+        if (splits > 1 && ws && need <= ws_floats && need < (1ll << 31)) {
+            p.tiles_per_split = ss_cdiv(nk, splits);
+            p.splits = ss_cdiv(nk, p.tiles_per_split);
+            p.partial = ws;
+        }
+        launch_conv<2, 2, 1, 1>(p, groups, st);
+        if (p.splits > 1) {
+            long long per = M * cout;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, st, p);
+        }
     }
     return ss_launch_status();
 }

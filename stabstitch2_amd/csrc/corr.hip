@@ -3,7 +3,7 @@
 
 extern "C" int ss_conv_nhwc(const float*, const float*, const float*, const float*, float*, int, int, int, int, int,
                             int, int, int, int, int, int, int, int, int, int, int, long long, long long, long long,
-                            void*);
+                            float*, long long, void*);
 
 // ------------------------------------------------------------------------------------------------
 // cost volume.  Block = 4x16 output pixels of one image; channels walked in chunks of 32 staged
@@ -211,7 +211,7 @@ extern "C" int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float*
     if (rc) return rc;
     // D[p][k] = sum_c n1[p][c] n2[k][c]: "image" = n1 as a 1 x P strip, "filters" = n2 rows, one group per batch item
     rc = ss_conv_nhwc(n1, n2, nullptr, nullptr, Dm, 1, 1, 1, P, c, P, 1, 1, 1, 1, 0, 0, 0, 0, P, n, (long long)P * c,
-                      (long long)P * c, (long long)P * P, stream);
+                      (long long)P * c, (long long)P * P, nullptr, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(ccl_softmax_kernel, dim3(ss_cdiv(P, 4), n), dim3(256), 0, st, (const float*)Dm, flow_nchw,
                        flow_nhwc4, h, w, softmax_scale);

@@ -10,6 +10,8 @@ passes run on libstabstitch_hip.so with weights repacked once per load:
 Architecture restated from torchvision 0.14.1 resnet18 (spatial_network.py:123-139) and the
 reference's regressors (spatial_network.py:147-259, temporal_network.py:65-105).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -143,8 +145,12 @@ def run_block(x, p):
     return ops.conv(y, p['c2'][0], p['c2'][1], res=idt, stride=1, pad=(0, 1, 1), relu=True)
 
 
-def run_stage1(x_nchw, p, chunk=32):
+STAGE1_CHUNK = int(os.environ.get('SS_STAGE1_CHUNK', '64'))      # images per trunk pass
+
+
+def run_stage1(x_nchw, p, chunk=None):
     """[n,3,H,W] NCHW in [-1,1] -> nhwc [n,H/8,W/8,128]."""
+    chunk = chunk or STAGE1_CHUNK
     outs = []
     for s in range(0, x_nchw.shape[0], chunk):
         x = ops.nchw_to_nhwc(x_nchw[s:s + chunk], 4)

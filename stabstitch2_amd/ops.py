@@ -29,6 +29,19 @@ def nhwc_to_nchw(x, c=None):
 
 
 # ------------------------------------------------------------------ conv / pool / fc
+_conv_ws = {}
+
+
+def conv_workspace(device):
+    """Per-device split-K scratch (64 MiB), allocated once; safe to share because launches on one stream
+    are ordered and each conv's reduce runs right behind its partial pass."""
+    ws = _conv_ws.get(device)
+    if ws is None:
+        ws = torch.empty(int(H.lib().ss_conv_workspace_floats()), device=device, dtype=torch.float32)
+        _conv_ws[device] = ws
+    return ws
+
+
 def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=None):
     """x nhwc [n,h,w,c] or [n,t,h,w,c]; wgt [cout,kt,kh,kw,cin] (cin == x channels)."""
     five = x.dim() == 5
@@ -46,9 +59,10 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     if out is None:
         shape = (n, to, ho, wo, cout) if five else (n, ho, wo, cout)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    ws = conv_workspace(x.device)
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), out.shape[-1],
-           1, 0, 0, 0, H.stream())
+           1, 0, 0, 0, H.dptr(ws), ws.numel(), H.stream())
     return out
 
 

@@ -10,6 +10,8 @@ over all frames of a view, one batched tsmotion composition per view, all slidin
 as one batch, one batched TPS solve for every (frame, view), then one fused warp+blend launch per
 stitched frame.  The only host round trip is the data-dependent canvas size (test_online_tra.py:122-123).
 """
+import os
+
 import torch
 
 from . import grid_res, ops
@@ -42,9 +44,13 @@ def _stack(lst, dev):
     return torch.stack([t.to(dev, non_blocking=True).float() for t in lst], 0)
 
 
+SPATIAL_CHUNK = int(os.environ.get('SS_SPATIAL_CHUNK', '32'))     # frame pairs per SpatialNet pass
+
+
 @torch.no_grad()
-def spatial_stage(spatial_net, lr1, lr2, chunk=16):
+def spatial_stage(spatial_net, lr1, lr2, chunk=None):
     """lr1, lr2 [N,3,360,480] device -> smotion1, smotion2 [N,7,9,2]."""
+    chunk = chunk or SPATIAL_CHUNK
     m1, m2 = [], []
     for s in range(0, lr1.shape[0], chunk):
         o = build_SpatialNet(spatial_net, lr1[s:s + chunk], lr2[s:s + chunk])
@@ -61,6 +67,15 @@ def temporal_stage(temporal_net, lr):
 
 
 @torch.no_grad()
+def temporal_stage_views(temporal_net, lrs):
+    """Both (all) views of a clip in ONE batched pass: lrs = list of V tensors [N,3,360,480]
+    -> list of V tmotion tensors [N,7,9,2] (frame 0 = 0)."""
+    m = temporal_net.motions(torch.stack(lrs, 1))                 # [N-1,V,7,9,2]
+    z = torch.zeros_like(m[:1, 0])
+    return [torch.cat((z, m[:, v]), 0) for v in range(len(lrs))]
+
+
+@torch.no_grad()
 def estimate_meshes(nets, lr1, lr2):
     """Stages 1-3 of test() (test_online_tra.py:284-392) for one clip.
     lr1, lr2: [N,3,360,480] device tensors (or lists of [1,3,360,480]).
@@ -74,8 +89,7 @@ def estimate_meshes(nets, lr1, lr2):
     if n < WINDOW:
         raise ValueError('need at least %d frames for the sliding smooth window, got %d' % (WINDOW, n))
     s1, s2 = spatial_stage(spatial_net, lr1, lr2)
-    t1 = temporal_stage(temporal_net, lr1)
-    t2 = temporal_stage(temporal_net, lr2)
+    t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
     smesh1, tsm1 = ops.tsmotion(s1, t1, LR_H, LR_W)
     smesh2, tsm2 = ops.tsmotion(s2, t2, LR_H, LR_W)
     nw = n - (WINDOW - 1)

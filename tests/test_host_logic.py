@@ -25,14 +25,14 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     from stabstitch2_amd import _hip
     hdr = open(os.path.join(ROOT, 'include', 'stabstitch_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', hdr)))
-    assert len(declared) >= 28
+    assert len(declared) >= 29
     for name in declared:
         assert hasattr(built_lib, name), name
     assert sorted(_hip.SIGNATURES) == declared, 'ctypes table and header disagree'
     assert built_lib.ss_version() >= 100
     assert built_lib.ss_error_string(-1) == b'bad argument'
     # argument validation happens before any device work, so it can be exercised without a GPU
-    assert built_lib.ss_conv_nhwc(None, None, None, None, None, *([1] * 15), 1, 0, 0, 0, None) == -1
+    assert built_lib.ss_conv_nhwc(None, None, None, None, None, *([1] * 15), 1, 0, 0, 0, None, 0, None) == -1
     assert built_lib.ss_maxpool_nhwc(None, None, 1, 4, 4, 4, 2, 2, 0, None) == -1
     assert built_lib.ss_tps_solve(None, None, None, 1, None) == -1
     assert built_lib.ss_ccl_workspace_floats(2, 23, 30, 256) == 2 * 690 * (512 + 690)
