@@ -77,6 +77,58 @@ __device__ __forceinline__ void tps_eval_interleaved(const float* __restrict__ s
     oy = ay;
 }
 
+// Two splines at once (the two views of a stitched frame) with packed fp32 math; log via the hardware log2
+// (v_log_f32, 1 ulp) times ln2.  The argument d2 + 1e-6 lies in [1e-6, ~16], so no denormal / range handling is
+// needed; the result differs from an accurate logf by <= ~1.5 ulp, the same class as the reference's own vectorised
+// logf, and two orders below the reference's fp32-vs-fp64 coordinate noise.
+typedef float ss_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tps_eval_pair(const float* __restrict__ src0, const float* __restrict__ src1,
+                                              const float* __restrict__ T0, const float* __restrict__ T1, float x,
+                                              float y, ss_f2& ox, ss_f2& oy) {
+    const float* Tx0 = T0;
+    const float* Ty0 = T0 + SS_NT;
+    const float* Tx1 = T1;
+    const float* Ty1 = T1 + SS_NT;
+    ss_f2 ax = {fmaf(Tx0[2], y, fmaf(Tx0[1], x, Tx0[0])), fmaf(Tx1[2], y, fmaf(Tx1[1], x, Tx1[0]))};
+    ss_f2 ay = {fmaf(Ty0[2], y, fmaf(Ty0[1], x, Ty0[0])), fmaf(Ty1[2], y, fmaf(Ty1[1], x, Ty1[0]))};
+    const ss_f2 xx = {x, x}, yy = {y, y};
+    const ss_f2 eps = {1e-6f, 1e-6f};
+#pragma unroll 9
+    for (int k = 0; k < SS_NV; ++k) {
+        ss_f2 sx = {src0[2 * k], src1[2 * k]};
+        ss_f2 sy = {src0[2 * k + 1], src1[2 * k + 1]};
+        ss_f2 dx = xx - sx, dy = yy - sy;
+        ss_f2 d2 = dx * dx + dy * dy;
+        ss_f2 a = d2 + eps;
+        ss_f2 lg = {__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)};
+        ss_f2 r = d2 * (lg * 0.6931471805599453f);
+        ss_f2 tx = {Tx0[3 + k], Tx1[3 + k]};
+        ss_f2 ty = {Ty0[3 + k], Ty1[3 + k]};
+        ax = __builtin_elementwise_fma(tx, r, ax);
+        ay = __builtin_elementwise_fma(ty, r, ay);
+    }
+    ox = ax;
+    oy = ay;
+}
+
+// scalar twin of tps_eval_pair (same operations in the same order -> bit-identical coordinates), used by the
+// generic per-view warp so that the fused render can be checked against it exactly
+__device__ __forceinline__ void tps_eval_fast(const float* __restrict__ src, const float* __restrict__ Tx,
+                                              const float* __restrict__ Ty, float x, float y, float& ox, float& oy) {
+    float ax = fmaf(Tx[2], y, fmaf(Tx[1], x, Tx[0]));
+    float ay = fmaf(Ty[2], y, fmaf(Ty[1], x, Ty[0]));
+#pragma unroll 9
+    for (int k = 0; k < SS_NV; ++k) {
+        float dx = x - src[2 * k], dy = y - src[2 * k + 1];
+        float d2 = dx * dx + dy * dy;
+        float r = d2 * (__builtin_amdgcn_logf(d2 + 1e-6f) * 0.6931471805599453f);
+        ax = fmaf(Tx[3 + k], r, ax);
+        ay = fmaf(Ty[3 + k], r, ay);
+    }
+    ox = ax;
+    oy = ay;
+}
+
 __device__ __forceinline__ float norm1(float v, float size) { return __fsub_rn(__fmul_rn(v, 2.0f) / size, 1.0f); }
 __device__ __forceinline__ float recover1(float v, float size) { return __fmul_rn(__fadd_rn(v, 1.0f), size) / 2.0f; }
 

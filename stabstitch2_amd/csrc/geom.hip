@@ -275,14 +275,21 @@ __global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict_
     }
     __syncthreads();
     for (int col = 0; col < SS_NT; ++col) {
-        if (tid == 0) {
-            int piv = col;
-            double best = fabs(A[col][col]);
-            for (int r = col + 1; r < SS_NT; ++r) {
-                double v = fabs(A[r][col]);
-                if (v > best) { best = v; piv = r; }
+        if (tid < 64) {     // partial pivoting: wave-parallel arg-max of |A[r][col]|, r >= col (lowest r wins ties)
+            int r0 = col + tid, r1 = r0 + 64;
+            double best = r0 < SS_NT ? fabs(A[r0][col]) : -1.0;
+            int piv = r0;
+            if (r1 < SS_NT) {
+                double v1 = fabs(A[r1][col]);
+                if (v1 > best) { best = v1; piv = r1; }
             }
-            s_piv = piv;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                double ob = __shfl_xor(best, o, 64);
+                int op = __shfl_xor(piv, o, 64);
+                if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+            }
+            if (tid == 0) s_piv = piv;
         }
         __syncthreads();
         int piv = s_piv;

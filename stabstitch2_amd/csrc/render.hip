@@ -2,8 +2,8 @@
 //
 // The reference materialises a [B,66,Hc*Wc] basis tensor (~500 MB at 720p) and makes ~15
 // elementwise passes over it before a bmm and a gather.  Here one thread owns one
-// canvas pixel: the 63 RBF terms are evaluated in registers from wave-uniform control points /
-// coefficients (scalar loads, no LDS), the sampling coordinate never leaves the register file, the
+// canvas pixel: the 63 RBF terms of both views are evaluated together in registers (packed fp32 math,
+// hardware log2) from wave-uniform control points / coefficients (scalar loads, no LDS), the sampling coordinate never leaves the register file, the
 // bilinear taps are gathered straight from the planar source frames, and for the AVERAGE mode the
 // two (three) views are fused before the single store.  HBM traffic = source frames once (L2 absorbs
 // the 4-tap overlap) + the canvas once.
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void tps_warp_kernel(const float* __restrict__
     const float* Ty = Tx + SS_NT;
     float gx = linspace_at(-1.f, 1.f, wc, x), gy = linspace_at(-1.f, 1.f, hc, y);
     float xn, yn;
-    tps_eval_interleaved(src, Tx, Ty, gx, gy, xn, yn);
+    tps_eval_fast(src, Tx, Ty, gx, gy, xn, yn);
     const long long hw = (long long)h * w, ohw = (long long)hc * wc;
     const int co = c + (append_mask ? 1 : 0);
     float* o = out + (long long)b * co * ohw + (long long)y * wc + x;
@@ -120,12 +120,19 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
     float gx = linspace_at(-1.f, 1.f, wc, x), gy = linspace_at(-1.f, 1.f, hc, y);
     const long long hw = (long long)h * w, ohw = (long long)hc * wc;
     float v[VIEWS][3];
+    float xs[VIEWS], ys[VIEWS];
+    {
+        ss_f2 px, py;
+        tps_eval_pair(source, source + SS_NV * 2, T, T + 2 * SS_NT, gx, gy, px, py);
+        xs[0] = px.x; xs[1] = px.y; ys[0] = py.x; ys[1] = py.y;
+        if (VIEWS == 3) {
+            tps_eval_pair(source + 2 * SS_NV * 2, source + 2 * SS_NV * 2, T + 4 * SS_NT, T + 4 * SS_NT, gx, gy, px, py);
+            xs[VIEWS - 1] = px.x; ys[VIEWS - 1] = py.x;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < VIEWS; ++k) {
-        const float* src = source + k * SS_NV * 2;
-        const float* Tx = T + k * 2 * SS_NT;
-        float xn, yn;
-        tps_eval_interleaved(src, Tx, Tx + SS_NT, gx, gy, xn, yn);
+        const float xn = xs[k], yn = ys[k];
         const float* in = rv.img[k];
         if (mode == SS_WARP_NORMAL) {
             SsTaps t = taps_normal(xn, yn, w, h);
