@@ -62,14 +62,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int WGM, int WGN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     constexpr int BM = WGM * WM * 32;
     constexpr int BN = WGN * WN * 32;
     constexpr int RA = BM / 32;   // A rows staged per thread
     constexpr int RB = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -169,34 +169,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const int aidx = (wr * WM * 32 + li) * LDK + lh * 16;
     const int bidx = (wc * WN * 32 + li) * LDK + lh * 16;
 
+    auto mma_chunk = [&](int buf, int c) {
+        f32x4 a[WM], b[WN];
+#pragma unroll
+        for (int x = 0; x < WM; ++x) a[x] = *reinterpret_cast<const f32x4*>(&As[buf][aidx + x * 32 * LDK + c * 4]);
+#pragma unroll
+        for (int y = 0; y < WN; ++y) b[y] = *reinterpret_cast<const f32x4*>(&Bs[buf][bidx + y * 32 * LDK + c * 4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][s], b[y][s], acc[x][y], 0, 0, 0);
+    };
+
     if (kt0 < kt1) {
         gload(kt0);
         lstore(0);
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
+        const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
         if (kt + 1 < kt1 && !(p.ablate & 1)) gload(kt + 1);
         // K tail: with the k = 16h + j permutation chunk c holds k in {4c..4c+3} u {16+4c..}; chunks past the
-        // end of K only multiply zeros (e.g. conv1: K = 196 -> the 7th tile needs 1 chunk of 4)
-        const int cmax = min(4, (p.K - kt * BK + 3) >> 2);
+        // end of K only multiply zeros (e.g. conv1: K = 196 -> the 7th tile needs 1 chunk of 4).  The full tile
+        // is a separate, branch-free copy so that the compiler keeps its LDS-read / MFMA software pipeline.
+        const int krem = p.K - kt * BK;
+        if (krem >= 16) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c >= cmax) break;
-            f32x4 a[WM], b[WN];
-#pragma unroll
-            for (int x = 0; x < WM; ++x) a[x] = *reinterpret_cast<const f32x4*>(&As[buf][aidx + x * 32 * LDK + c * 4]);
-#pragma unroll
-            for (int y = 0; y < WN; ++y) b[y] = *reinterpret_cast<const f32x4*>(&Bs[buf][bidx + y * 32 * LDK + c * 4]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int x = 0; x < WM; ++x)
-#pragma unroll
-                    for (int y = 0; y < WN; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][s], b[y][s], acc[x][y], 0, 0, 0);
+            for (int c = 0; c < 4; ++c) mma_chunk(buf, c);
+        } else {
+            const int cmax = (krem + 3) >> 2;
+            for (int c = 0; c < cmax; ++c) mma_chunk(buf, c);
         }
-        if (kt + 1 < kt1 && !(p.ablate & 2)) lstore(buf ^ 1);
+        if (NBUF == 1) __syncthreads();      // single LDS buffer: everyone done reading before it is overwritten
+        if (kt + 1 < kt1 && !(p.ablate & 2)) lstore(NBUF == 2 ? (buf ^ 1) : 0);
         if (!(p.ablate & 4)) __syncthreads();
     }
 
@@ -246,11 +254,19 @@ __global__ void splitk_reduce_kernel(ConvP p) {
     p.out[o] = v;
 }
 
-template <int WGM, int WGN, int WM, int WN>
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1>
 static void launch_conv(const ConvP& p, int groups, hipStream_t st) {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     dim3 g(ss_cdiv(p.M, BM), ss_cdiv(p.Co, BN), groups * p.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN>), g, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW>), g, dim3(256), 0, st, p);
+}
+
+// tuning aids, not part of the public ABI: key 0 = force tile variant, key 1 = ablation mask
+static int g_force_tile = getenv("SS_CONV_TILE") ? atoi(getenv("SS_CONV_TILE")) : 0;
+static int g_ablate = getenv("SS_CONV_ABLATE") ? atoi(getenv("SS_CONV_ABLATE")) : 0;
+extern "C" void ss_debug_set(int key, int value) {
+    if (key == 0) g_force_tile = value;
+    if (key == 1) g_ablate = value;
 }
 
 extern "C" long long ss_conv_workspace_floats(void) { return 16ll << 20; }   // 64 MiB of split-K partials
@@ -291,36 +307,37 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     const int nk = ss_cdiv(K, BK);
     p.splits = 1;
     p.tiles_per_split = nk;
-    static const int ablate = getenv("SS_CONV_ABLATE") ? atoi(getenv("SS_CONV_ABLATE")) : 0;
-    p.ablate = ablate;
+    p.ablate = g_ablate;
 
-    // tile choice by a small cost model: the chip runs `occ` workgroups per CU (LDS-limited) that share the
-    // CU's four MFMA pipes, so a launch takes ceil(blocks / 256) "rounds" of one tile's MFMA work; larger tiles
-    // run the pipe more efficiently (fewer LDS / global instructions per MFMA) but quantise worse.
-    struct Cand { int id; int bm, bn; float eff; };
-    static const Cand cands[3] = {{1, 128, 128, 1.00f}, {3, 128, 64, 0.93f}, {4, 64, 64, 0.74f}};
-    static const int force = getenv("SS_CONV_TILE") ? atoi(getenv("SS_CONV_TILE")) : 0;   // tuning aid only
-    int best = 4;
-    float best_t = 1e30f;
-    for (int i = 0; i < 3; ++i) {
-        const Cand& c = cands[i];
-        if (c.bn > 64 && cout <= 64) continue;
-        long long blocks = (long long)ss_cdiv(M, c.bm) * ss_cdiv(cout, c.bn) * groups;
-        float rounds = (float)((blocks + 255) / 256);
-        float t = rounds * (float)(c.bm * c.bn) / c.eff;
-        if (t < best_t) { best_t = t; best = c.id; }
-    }
+    // Tile choice.  Measured on MI355X (tools/ab_conv.py, interleaved A/B on the layer shapes of the pipeline): the
+    // 64x64 tile with ONE 18 KB LDS buffer (5-6 resident workgroups per CU, i.e. 5-6 waves per SIMD feeding each
+    // MFMA pipe) beats every larger tile (128x64: -8 %, 128x128 / 256x64 with 2 waves per SIMD: -10..-50 %) on every
+    // shape -- latency hiding by occupancy matters more here than LDS reads per MFMA, and the small tile also
+    // quantises best over 256 CUs.  The larger variants stay selectable for tuning (ss_debug_set / SS_CONV_TILE).
+    int best = 6;
+    const int force = g_force_tile;   // tuning aid only (ss_debug_set / SS_CONV_TILE)
     if (force) best = force;
     if (best == 1) {
-        launch_conv<2, 2, 2, 2>(p, groups, st);
+        launch_conv<2, 2, 2, 2, 2>(p, groups, st);
     } else if (best == 2) {
-        launch_conv<4, 1, 2, 2>(p, groups, st);
+        launch_conv<4, 1, 2, 2, 1>(p, groups, st);
+    } else if (best == 5) {
+        launch_conv<2, 2, 2, 2, 1>(p, groups, st);
+    } else if (best == 8) {
+        launch_conv<2, 2, 1, 1, 1, 8>(p, groups, st);
+    } else if (best == 9) {
+        launch_conv<2, 2, 1, 1, 1, 6>(p, groups, st);
+    } else if (best == 7) {
+        launch_conv<2, 2, 2, 1, 1>(p, groups, st);
     } else if (best == 3) {
-        launch_conv<2, 2, 2, 1>(p, groups, st);
+        launch_conv<2, 2, 2, 1, 2>(p, groups, st);
+    } else if (best == 4) {
+        launch_conv<2, 2, 1, 1, 2>(p, groups, st);
     } else {
-        // 64x64 tiles; small problems are additionally split along K so that ~512 workgroups exist
+        // default: 64x64 tiles, single LDS buffer; small problems are additionally split along K so that ~1024
+        // workgroups exist
         long long b64 = (long long)ss_cdiv(M, 64) * ss_cdiv(cout, 64) * groups;
-        int want = (int)((512 + b64 - 1) / b64);
+        int want = (int)((1024 + b64 - 1) / b64);
         int maxs = nk / 4 > 0 ? nk / 4 : 1;
         int splits = want < maxs ? want : maxs;
         long long need = (long long)groups * splits * M * cout;
@@ -329,7 +346,7 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
             p.splits = ss_cdiv(nk, p.tiles_per_split);
             p.partial = ws;
         }
-        launch_conv<2, 2, 1, 1>(p, groups, st);
+        launch_conv<2, 2, 1, 1, 1>(p, groups, st);
         if (p.splits > 1) {
             long long per = M * cout;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, st, p);
