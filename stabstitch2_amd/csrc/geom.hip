@@ -297,12 +297,20 @@ __global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict_
             double t = A[col][tid]; A[col][tid] = A[piv][tid]; A[piv][tid] = t;
         }
         __syncthreads();
-        double pinv = 1.0 / A[col][col];
-        // Gauss-Jordan: eliminate column `col` from every other row (columns > col only)
-        int ncols = TPS_LD - (col + 1);
-        for (int e = tid; e < SS_NT * ncols; e += 256) {
-            int r = e / ncols, c = col + 1 + (e - r * ncols);
-            if (r != col) A[r][c] -= (A[r][col] * pinv) * A[col][c];
+        const double pinv = 1.0 / A[col][col];
+        // Gauss-Jordan: eliminate column `col` from every other row (columns > col only).  Wave w owns rows
+        // w, w+4, ...; lanes own the columns (<= 67 to go, i.e. at most two passes) -- no integer divisions.
+        {
+            const int wv = tid >> 6, ln = tid & 63;
+            const int c0 = col + 1 + ln, c1 = c0 + 64;
+            const double p0 = c0 < TPS_LD ? A[col][c0] : 0.0;
+            const double p1 = c1 < TPS_LD ? A[col][c1] : 0.0;
+            for (int r = wv; r < SS_NT; r += 4) {
+                if (r == col) continue;
+                const double f = A[r][col] * pinv;
+                if (c0 < TPS_LD) A[r][c0] -= f * p0;
+                if (c1 < TPS_LD) A[r][c1] -= f * p1;
+            }
         }
         __syncthreads();
     }

@@ -149,12 +149,20 @@ STAGE1_CHUNK = int(os.environ.get('SS_STAGE1_CHUNK', '64'))      # images per tr
 
 
 def run_stage1(x_nchw, p, chunk=None):
-    """[n,3,H,W] NCHW in [-1,1] -> nhwc [n,H/8,W/8,128]."""
+    """NCHW input(s) in [-1,1] -> nhwc [n,H/8,W/8,128].  `x_nchw` may be a list of [n_i,3,H,W] tensors: they are
+    laid out back to back in one NHWC buffer (no torch.cat of the inputs) and run as one batch."""
     chunk = chunk or STAGE1_CHUNK
+    xs = x_nchw if isinstance(x_nchw, (list, tuple)) else [x_nchw]
+    total = sum(x.shape[0] for x in xs)
+    h, w = xs[0].shape[2], xs[0].shape[3]
+    buf = torch.empty((total, h, w, 4), device=xs[0].device, dtype=torch.float32)
+    o = 0
+    for x in xs:
+        ops.nchw_to_nhwc(x, 4, out=buf[o:o + x.shape[0]])
+        o += x.shape[0]
     outs = []
-    for s in range(0, x_nchw.shape[0], chunk):
-        x = ops.nchw_to_nhwc(x_nchw[s:s + chunk], 4)
-        x = ops.conv(x, p['conv1'][0], p['conv1'][1], stride=2, pad=(0, 3, 3), relu=True)
+    for s in range(0, total, chunk):
+        x = ops.conv(buf[s:s + chunk], p['conv1'][0], p['conv1'][1], stride=2, pad=(0, 3, 3), relu=True)
         x = ops.maxpool(x, 3, 2, 1)
         for b in p['layer1']:
             x = run_block(x, b)

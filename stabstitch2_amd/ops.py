@@ -12,10 +12,12 @@ def _f(t):
 
 
 # ------------------------------------------------------------------ layout
-def nchw_to_nhwc(x, c_pad=None):
+def nchw_to_nhwc(x, c_pad=None, out=None):
     n, c, h, w = x.shape
     c_pad = c_pad or ((c + 3) // 4) * 4
-    out = torch.empty((n, h, w, c_pad), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, h, w, c_pad), device=x.device, dtype=torch.float32)
+    assert tuple(out.shape) == (n, h, w, c_pad)
     H.call('ss_nchw_to_nhwc', H.dptr(_f(x)), H.dptr(out), n, c, h, w, c_pad, H.stream())
     return out
 
@@ -96,12 +98,14 @@ def ccl(f1, f2, scale=10.0, want_nchw=True, want_nhwc4=True):
     return a, b
 
 
-def cost_volume(x1, x2, r):
+def cost_volume(x1, x2, r, out=None):
     """nhwc in -> nhwc [n,h,w,pad4((2r+1)^2)] (padding channels are zero)."""
     n, h, w, c = x1.shape
     d = (2 * r + 1) ** 2
     cs = ((d + 3) // 4) * 4
-    out = torch.empty((n, h, w, cs), device=x1.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, h, w, cs), device=x1.device, dtype=torch.float32)
+    assert tuple(out.shape) == (n, h, w, cs)
     H.call('ss_cost_volume', H.dptr(x1), H.dptr(x2), H.dptr(out), n, h, w, c, r, cs, H.stream())
     return out
 

@@ -70,9 +70,9 @@ def temporal_stage(temporal_net, lr):
 def temporal_stage_views(temporal_net, lrs):
     """Both (all) views of a clip in ONE batched pass: lrs = list of V tensors [N,3,360,480]
     -> list of V tmotion tensors [N,7,9,2] (frame 0 = 0)."""
-    m = temporal_net.motions(torch.stack(lrs, 1))                 # [N-1,V,7,9,2]
-    z = torch.zeros_like(m[:1, 0])
-    return [torch.cat((z, m[:, v]), 0) for v in range(len(lrs))]
+    ms = temporal_net.motions_views(lrs)                          # V x [N-1,7,9,2]
+    z = torch.zeros_like(ms[0][:1])
+    return [torch.cat((z, m), 0) for m in ms]
 
 
 @torch.no_grad()

@@ -68,8 +68,7 @@ class SpatialNet(L.PreparedMixin, nn.Module):
         """[B,3,360,480] x2 in [-1,1] -> (offset_1 [B,8], offset_2_ref [B,126], offset_2_tgt [B,126])."""
         p = self._prepared()
         b, _, img_h, img_w = input1_tensor.shape
-        x = torch.cat((input1_tensor, input2_tensor), 0).float()
-        f64 = L.run_stage1(x, p['s1'])                     # [2B,45,60,128] nhwc
+        f64 = L.run_stage1([input1_tensor, input2_tensor], p['s1'])      # [2B,45,60,128] nhwc
         f32 = L.run_stage2(f64, p['s2'])                   # [2B,23,30,256]
         # stage 1: contextual correlation -> global homography offsets
         _, flow = ops.ccl(f32[:b], f32[b:], 10.0, want_nchw=False, want_nhwc4=True)

@@ -39,6 +39,20 @@ class TemporalNet(L.PreparedMixin, nn.Module):
         off = L.run_regressor(ops.cost_volume(x1, x2, 3), p['r2'])
         return off.view(n - 1, b, grid_h + 1, grid_w + 1, 2)
 
+    @torch.no_grad()
+    def motions_views(self, views):
+        """views: list of V device tensors [N,3,360,480] (one clip per view) -> list of V tensors [N-1,7,9,2].
+        All views share one trunk pass and one regressor pass; no copy of the input frames is made."""
+        p = self._prepared()
+        n = views[0].shape[0]
+        v = len(views)
+        f = L.run_stage1(list(views), p['s1'])                      # [V*N,45,60,128], view-major
+        cv = torch.empty((v * (n - 1), f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
+        for i in range(v):
+            ops.cost_volume(f[i * n:i * n + n - 1], f[i * n + 1:i * n + n], 3, out=cv[i * (n - 1):(i + 1) * (n - 1)])
+        off = L.run_regressor(cv, p['r2']).view(v, n - 1, grid_h + 1, grid_w + 1, 2)
+        return [off[i] for i in range(v)]
+
     def forward(self, img_tensor_list):
         dev = next(self.parameters()).device
         frames = torch.stack([t.to(dev, non_blocking=True).float() for t in img_tensor_list], 0)
