@@ -61,8 +61,9 @@ class ConvProbe:
             m = out.numel() // out.shape[-1]
             cout, kt, kh, kw, cin = wgt.shape
             # algorithmic MACs use the channels that carry data (zero-padded taps excluded)
-            cin_real = {4: None}.get(cin, cin)
-            probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, tuple(wgt.shape)))
+            res = k.get('res')
+            nbytes = 4 * (x.numel() + wgt.numel() + out.numel() + (res.numel() if res is not None else 0))
+            probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes))
             return out
         ops.conv = timed_conv
         from stabstitch2_amd import layers, smooth_network
@@ -72,7 +73,7 @@ class ConvProbe:
     def report(self):
         real_cin = {4: 3, 124: 121, 52: 49}
         agg = {}
-        for e0, e1, m, cout, taps, cin, shape in self.records:
+        for e0, e1, m, cout, taps, cin, nbytes in self.records:
             c = real_cin.get(cin, cin)
             if cin == 4 and taps == 9:
                 c = 2
@@ -89,16 +90,17 @@ class ConvProbe:
 
     def summary(self):
         real_cin = {4: 3, 124: 121, 52: 49}
-        tot_ms, tot_flop, n = 0.0, 0.0, 0
-        for e0, e1, m, cout, taps, cin, shape in self.records:
+        tot_ms, tot_flop, n, tot_bytes = 0.0, 0.0, 0, 0.0
+        for e0, e1, m, cout, taps, cin, nbytes in self.records:
             ms = e0.elapsed_time(e1)
             c = real_cin.get(cin, cin)
             if cin == 4 and taps == 9:
                 c = 2      # CCL flow (dx, dy) regressor input
             tot_ms += ms
             tot_flop += 2.0 * m * cout * taps * c
+            tot_bytes += nbytes
             n += 1
-        return tot_ms, tot_flop, n
+        return tot_ms, tot_flop, n, tot_bytes
 
 
 def cpu_baseline(sds, frames, height, width, threads):
@@ -193,12 +195,20 @@ def main():
     tmax = float(allrec[:, 1].max())
     fps = ssdist.aggregate_fps(allrec)
 
-    conv_ms, conv_flop, conv_n = probe.summary()
+    conv_ms, conv_flop, conv_n, conv_bytes = probe.summary()
     if args.conv_report:
         probe.report()
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # algorithmic HBM bytes per stitched frame: fp32 frames in, fp32 canvas out, weights once
     io_bytes = 2 * (3 * args.height * args.width + 3 * 360 * 480) * 4 + 3 * hc * wc * 4 + 70.6e6
+    # HBM bytes per conv launch from the committed PMC passes of this same command (profiles/r01_pmc_hbm.json;
+    # FETCH_SIZE / WRITE_SIZE cannot be read live from inside the process)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')) as f:
+            traffic = json.load(f)['kernels']['conv_igemm_kernel']['hbm_bytes_per_launch']
+    except Exception:
+        pass
     result = {
         'metric': 'stitched frames/sec, 720p 2-view (StabStitch++ inference hot path)',
         'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -212,7 +222,11 @@ def main():
                                           'and hardware, not comparable'},
         'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<WM,WN> (fp32 implicit-GEMM conv, %d launches/clip)'
                      % conv_n, 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                     'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm.json)',
+                     'algorithmic_flop_per_launch': round(conv_flop / max(conv_n, 1)),
+                     'algorithmic_bytes_per_launch': round(conv_bytes / max(conv_n, 1)),
+                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_n, 1), 2),
                      'kernel_ms_per_step': round(conv_ms, 3),
                      'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5)},
     }

@@ -46,6 +46,7 @@ struct ConvP {
     uint32_t mulC, mulKw, mulKh;
     int relu, out_cs;
     int splits, tiles_per_split;
+    unsigned ntiles;                 // Cout tiles (grid.x = M tiles * ntiles)
     long long in_gs, w_gs, out_gs;
     unsigned in_bytes, w_bytes;      // per-group extents for the buffer descriptors
     int ablate;                      // tuning aid (SS_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
@@ -75,8 +76,22 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave / WGN, wc = wave % WGN;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (private L2s).
+    // Give every XCD one contiguous run of M tiles (all Cout tiles of an M tile back to back) so that the 3x3 halo
+    // rows and the Cout-tile re-reads of an input tile hit that XCD's L2 instead of being fetched 8 times.
+    int mt, nt;
+    {
+        const unsigned nwg = gridDim.x, b = blockIdx.x;
+        unsigned lin = b;
+        if (!(p.ablate & 8) && nwg >= 16) {
+            const unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
+            lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        mt = (int)(lin / p.ntiles);
+        nt = (int)(lin - (unsigned)mt * p.ntiles);
+    }
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
     const int grp = blockIdx.z / p.splits;
     const int split = blockIdx.z - grp * p.splits;
 
@@ -257,8 +272,10 @@ __global__ void splitk_reduce_kernel(ConvP p) {
 template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1>
 static void launch_conv(const ConvP& p, int groups, hipStream_t st) {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
-    dim3 g(ss_cdiv(p.M, BM), ss_cdiv(p.Co, BN), groups * p.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW>), g, dim3(256), 0, st, p);
+    ConvP q = p;
+    q.ntiles = (unsigned)ss_cdiv(p.Co, BN);
+    dim3 g((unsigned)ss_cdiv(p.M, BM) * q.ntiles, 1, groups * p.splits);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW>), g, dim3(256), 0, st, q);
 }
 
 // tuning aids, not part of the public ABI: key 0 = force tile variant, key 1 = ablation mask

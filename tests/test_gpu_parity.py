@@ -363,3 +363,72 @@ def test_missing_device_fails_loudly():
     from stabstitch2_amd import ops, _hip
     with pytest.raises(_hip.HipError):
         ops.maxpool(torch.zeros(1, 4, 4, 4), 2, 2)
+
+
+# ------------------------------------------------------------------ size-independent properties at full benchmark sizes
+def test_full_size_properties_720p(dev):
+    """720x1280 (BASELINE configs[2]) is too large for fixtures; check properties that hold at any size."""
+    from stabstitch2_amd import ops, pipeline
+    from stabstitch2_amd.spatial_network import get_rigid_mesh, get_norm_mesh
+    h, w = 720, 1280
+    hr, _ = synth.make_clip_device(2, h, w, seed=5, device=dev)
+    img = hr[0, 0:1]                                                   # [1,3,720,1280]
+    nrigid = get_norm_mesh(get_rigid_mesh(1, h, w, device=dev), h, w).contiguous()
+    T = ops.tps_solve(nrigid, nrigid)
+    # identity spline: affine part = identity, RBF weights ~ 0
+    assert float((T[0, 0, :3] - torch.tensor([0., 1., 0.], device=dev)).abs().max()) < 1e-5
+    assert float(T[0, :, 3:].abs().max()) < 1e-5
+    # FAST + identity mesh = the image itself (align_corners=True); NORMAL = zoom by W/(W-1), last row/col exactly 0
+    fast = ops.tps_warp(img, nrigid, T, h, w, 'FAST')
+    assert float((fast - img).abs().max()) < 2e-2
+    normal = ops.tps_warp(img, nrigid, T, h, w, 'NORMAL')
+    assert float(normal[..., -1, :].abs().max()) < 1e-3 and float(normal[..., :, -1].abs().max()) < 1e-3
+    # linearity of the sampler in the image: warp(a U1 + b U2) = a warp(U1) + b warp(U2)
+    rs = np.random.RandomState(0)
+    mesh = get_rigid_mesh(1, h, w, device=dev) + torch.from_numpy(rs.normal(0, 4, (1, 7, 9, 2)).astype(np.float32)).to(dev)
+    src = get_norm_mesh(mesh, h, w).contiguous()
+    T2 = ops.tps_solve(src, nrigid)
+    u1, u2 = hr[0, 0:1], hr[1, 1:2]
+    lhs = ops.tps_warp(0.25 * u1 + 0.5 * u2, src, T2, h, w, 'FAST')
+    rhs = 0.25 * ops.tps_warp(u1, src, T2, h, w, 'FAST') + 0.5 * ops.tps_warp(u2, src, T2, h, w, 'FAST')
+    assert float((lhs - rhs).abs().max()) < 1e-3
+    # fused render == formula on the generic per-view warps, bit for bit, at the full canvas
+    srcs = torch.cat((src, nrigid), 0)
+    Ts = torch.cat((T2, T), 0)
+    wv = ops.tps_warp(torch.cat((u1, u2), 0), srcs, Ts, h + 20, w + 500, 'NORMAL')
+    f = wv[0] * (wv[0] / (wv[0] + wv[1] + 1e-6)) + wv[1] * (wv[1] / (wv[0] + wv[1] + 1e-6))
+    assert torch.equal(ops.render_average([u1, u2], srcs, Ts, h + 20, w + 500, 'NORMAL'), f)
+    # whole pipeline on a 720p clip: canvas bigger than the frame, every output finite, meshes reproducible
+    from bench import build_nets
+    nets, _ = build_nets(dev)
+    hr8, lr8 = synth.make_clip_device(8, h, w, seed=2, device=dev)
+    fr, hc, wc, m1, m2 = pipeline.run_two_view(hr8[0], hr8[1], lr8[0], lr8[1], nets)
+    assert hc >= h and wc > w and fr.shape == (8, 3, hc, wc) and bool(torch.isfinite(fr).all())
+    fr2, hc2, wc2, m1b, _ = pipeline.run_two_view(hr8[0], hr8[1], lr8[0], lr8[1], nets)
+    assert (hc2, wc2) == (hc, wc) and torch.equal(m1, m1b) and torch.equal(fr, fr2)       # deterministic (fixed-order split-K)
+
+
+def test_conv_properties_and_edges(dev):
+    from stabstitch2_amd import ops
+    torch.manual_seed(1)
+    x1 = torch.randn(3, 11, 15, 128, device=dev)
+    x2 = torch.randn(3, 11, 15, 128, device=dev)
+    w = torch.randn(128, 1, 3, 3, 128, device=dev) * 0.03
+    lin = ops.conv(2.0 * x1 - 3.0 * x2, w, None)
+    ref = 2.0 * ops.conv(x1, w, None) - 3.0 * ops.conv(x2, w, None)
+    assert float((lin - ref).abs().max()) < 2e-4                       # linearity (split-K path: M = 495)
+    one = ops.conv(x1[:1, :1, :1].contiguous(), w, None)                # 1x1 image: only the centre tap is in bounds
+    assert one.shape == (1, 1, 1, 128)
+    exp = (x1[0, 0, 0] * w[:, 0, 1, 1, :]).sum(1)
+    assert float((one.view(-1) - exp).abs().max()) < 1e-4
+    with pytest.raises(Exception):
+        ops.conv(torch.randn(1, 4, 4, 6, device=dev), torch.randn(8, 1, 3, 3, 6, device=dev))   # cin % 4 != 0
+    with pytest.raises(Exception):
+        ops.conv(torch.randn(1, 2, 2, 4, device=dev), torch.randn(8, 1, 5, 5, 4, device=dev), pad=(0, 0, 0))  # empty output
+
+
+def test_short_clip_is_rejected(dev, hip_nets):
+    from stabstitch2_amd import pipeline
+    _, lr = synth.make_clip(6, 360, 480, seed=0)
+    with pytest.raises(ValueError):
+        pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
