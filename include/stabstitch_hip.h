@@ -159,6 +159,19 @@ int ss_smooth_finalize(const float* smesh1, const float* smesh2, const float* ts
                        float* ori_path2, float* smooth_mesh1, float* smooth_mesh2, float* smooth_path1,
                        float* smooth_path2, int nw, int t, int wstride, int zero_first, void* stream);
 
+/* ---- metric harness (test_metric_ssd.py:444-482, 513-527) -------------------------------------
+ * w1, w2: [frames][4][h][w] = 3 colour planes (0..255) + validity-mask plane, as ss_tps_warp_mask_nchw
+ * writes them.  out (device, fp64) [frames][2] = alignment PSNR (dB), SSIM of (w1*ov, w2*ov), ov = m1*m2,
+ * computed in fp64 with scikit-image 0.15 compare_psnr / compare_ssim semantics (data_range 255, 7x7
+ * uniform window, multichannel).  ws: 2*frames doubles. */
+int ss_alignment_psnr_ssim(const float* w1, const float* w2, double* out, double* ws, int frames, int h,
+                           int w, void* stream);
+/* path [t][63][2] (stitched smooth path of view 2) -> out[0] = stability score (test_metric_ssd.py:459-468) */
+int ss_stability_score(const float* path, float* out, int t, void* stream);
+/* mesh [t][7][9][2] (LR px) -> out[0] = max over frames of inter + intra grid loss (:38-87, 473-482);
+ * ws: t floats */
+int ss_distortion_score(const float* mesh, float* out, float* ws, int t, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,9 @@ SIGNATURES = {
     'ss_mesh_normalize': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
     'ss_smooth_embed': (c_i, [c_fp] * 9 + [c_i] * 4 + [c_st]),
     'ss_smooth_finalize': (c_i, [c_fp] * 13 + [c_i] * 4 + [c_st]),
+    'ss_alignment_psnr_ssim': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_st]),
+    'ss_stability_score': (c_i, [c_fp, c_fp, c_i, c_st]),
+    'ss_distortion_score': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
 }
 
 _lib = None

@@ -35,12 +35,13 @@ _conv_ws = {}
 
 
 def conv_workspace(device):
-    """Per-device split-K scratch (64 MiB), allocated once; safe to share because launches on one stream
-    are ordered and each conv's reduce runs right behind its partial pass."""
-    ws = _conv_ws.get(device)
+    """Split-K scratch (64 MiB) per (device, stream), allocated once; launches on one stream are ordered and each
+    conv's reduce runs right behind its partial pass, so one buffer per stream is race free."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _conv_ws.get(key)
     if ws is None:
         ws = torch.empty(int(H.lib().ss_conv_workspace_floats()), device=device, dtype=torch.float32)
-        _conv_ws[device] = ws
+        _conv_ws[key] = ws
     return ws
 
 

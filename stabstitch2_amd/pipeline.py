@@ -44,6 +44,18 @@ def _stack(lst, dev):
     return torch.stack([t.to(dev, non_blocking=True).float() for t in lst], 0)
 
 
+OVERLAP_STREAMS = os.environ.get('SS_OVERLAP_STREAMS', '0') == '1'
+_side = {}
+
+
+def _side_stream(dev):
+    s = _side.get(dev)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _side[dev] = s
+    return s
+
+
 SPATIAL_CHUNK = int(os.environ.get('SS_SPATIAL_CHUNK', '32'))     # frame pairs per SpatialNet pass
 
 
@@ -88,8 +100,21 @@ def estimate_meshes(nets, lr1, lr2):
     n = lr1.shape[0]
     if n < WINDOW:
         raise ValueError('need at least %d frames for the sliding smooth window, got %d' % (WINDOW, n))
-    s1, s2 = spatial_stage(spatial_net, lr1, lr2)
-    t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
+    if OVERLAP_STREAMS:
+        # SpatialNet and TemporalNet are independent until tsmotion: run them on two HIP streams so that the
+        # partially filled last round of one net's kernels is topped up with the other's workgroups
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
+        s1, s2 = spatial_stage(spatial_net, lr1, lr2)
+        main.wait_stream(side)
+        for t in (t1, t2):
+            t.record_stream(main)
+    else:
+        s1, s2 = spatial_stage(spatial_net, lr1, lr2)
+        t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
     smesh1, tsm1 = ops.tsmotion(s1, t1, LR_H, LR_W)
     smesh2, tsm2 = ops.tsmotion(s2, t2, LR_H, LR_W)
     nw = n - (WINDOW - 1)

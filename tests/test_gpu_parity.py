@@ -313,14 +313,22 @@ def test_pipeline_vs_reference(dev, golden, hip_nets, clip16):
         close_boxes(got, g['frames_' + tag], g['iqr_' + tag], 5e-2, 'frames ' + tag)
         if tag == 'normal_average':
             close(frames[0][150:214, 300:396], g['frame0_crop'], 5e-2, 'frame0 crop')
-    # alignment PSNR / SSIM of the metric harness on device warps (fp64 metric arithmetic of the oracle)
+    # metric harness on device: LR warps with masks, fp64 PSNR / SSIM, stability, distortion vs the reference values
     from stabstitch2_amd import metrics
-    w1 = metrics.warp_lr_with_mask(torch.cat(lr[0], 0).to(dev), m1)
-    w2 = metrics.warp_lr_with_mask(torch.cat(lr[1], 0).to(dev), m2)
-    for i in range(16):
-        p, s = M.alignment_psnr_ssim(w1[i].cpu().numpy(), w2[i].cpu().numpy())
-        assert abs(p - g['psnr'][i]) < 0.01, (i, p, g['psnr'][i])
-        assert abs(s - g['ssim'][i]) < 1e-3, (i, s, g['ssim'][i])
+    w1 = metrics.warp_lr_planes(torch.cat(lr[0], 0).to(dev), m1)
+    w2 = metrics.warp_lr_planes(torch.cat(lr[1], 0).to(dev), m2)
+    ps, ss = metrics.alignment_psnr_ssim(w1, w2)
+    assert float((ps.cpu() - torch.from_numpy(g['psnr'])).abs().max()) < 0.01, (ps.cpu(), g['psnr'])
+    assert float((ss.cpu() - torch.from_numpy(g['ssim'])).abs().max()) < 1e-3, (ss.cpu(), g['ssim'])
+    six = metrics.warp_lr_with_mask(torch.cat(lr[0], 0).to(dev), m1)
+    p0, s0 = M.alignment_psnr_ssim(six[0].cpu().numpy(), metrics.warp_lr_with_mask(torch.cat(lr[1], 0).to(dev), m2)[0].cpu().numpy())
+    assert abs(p0 - float(ps[0])) < 1e-6 and abs(s0 - float(ss[0])) < 1e-9      # device fp64 == oracle fp64 arithmetic
+    assert abs(metrics.stability_score(torch.from_numpy(g['smooth_path2']).to(dev)) - float(g['stability'])) < 1e-4
+    assert abs(metrics.distortion_score(m2) - float(g['distortion'])) < 1e-5
+    ev = metrics.evaluate_clip(hip_nets, lr[0], lr[1])
+    assert float((ev['psnr'].cpu() - torch.from_numpy(g['psnr'])).abs().max()) < 0.01
+    assert float((ev['ssim'].cpu() - torch.from_numpy(g['ssim'])).abs().max()) < 1e-3
+    assert abs(ev['stability'] - float(g['stability'])) < 1e-3 and abs(ev['distortion'] - float(g['distortion'])) < 1e-4
     # end to end with the pipeline's own meshes
     frames, hc, wc, sm1, sm2 = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets)
     assert [hc, wc] == list(g['canvas_normal_average'])
@@ -432,3 +440,15 @@ def test_short_clip_is_rejected(dev, hip_nets):
     _, lr = synth.make_clip(6, 360, 480, seed=0)
     with pytest.raises(ValueError):
         pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+
+
+def test_psnr_ssim_vs_skimage(dev, golden):
+    """G11: scikit-image 0.18.3 values on two seeded images (mask plane = 1)."""
+    from stabstitch2_amd import metrics
+    g = golden('g11_metrics')
+    a, b = cases.g11_images()
+    def planes(x):
+        t = torch.from_numpy(x).permute(2, 0, 1)
+        return torch.cat((t, torch.ones(1, *t.shape[1:])), 0).unsqueeze(0).contiguous().to(dev)
+    p, s = metrics.alignment_psnr_ssim(planes(a), planes(b))
+    assert abs(float(p[0]) - float(g['psnr'])) < 1e-6 and abs(float(s[0]) - float(g['ssim'])) < 1e-6
