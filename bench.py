@@ -133,6 +133,7 @@ def main():
     ap.add_argument('--frames', type=int, default=32)
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
+    ap.add_argument('--views', type=int, default=2, choices=(2, 3))
     ap.add_argument('--warp_mode', default='NORMAL')
     ap.add_argument('--fusion_mode', default='AVERAGE')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -160,11 +161,14 @@ def main():
     _hip.lib()
     torch.set_grad_enabled(False)
     nets, sds = build_nets(dev)
-    hr, lr = synth.make_clip_device(args.frames, args.height, args.width, seed=rank, device=dev)
+    hr, lr = synth.make_clip_device(args.frames, args.height, args.width, seed=rank, views=args.views, device=dev)
     probe = ConvProbe()
     probe.install()
 
     def step():
+        if args.views == 3:       # BASELINE configs[4]: two 2-view passes (v1,v2),(v2,v3) + three-view composition
+            return pipeline.run_three_view(hr[0], hr[1], hr[2], lr[0], lr[1], lr[2], nets, args.warp_mode,
+                                           args.fusion_mode)[:3]
         return pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets, args.warp_mode, args.fusion_mode)
 
     def sync():
@@ -200,7 +204,7 @@ def main():
         probe.report()
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # algorithmic HBM bytes per stitched frame: fp32 frames in, fp32 canvas out, weights once
-    io_bytes = 2 * (3 * args.height * args.width + 3 * 360 * 480) * 4 + 3 * hc * wc * 4 + 70.6e6
+    io_bytes = args.views * (3 * args.height * args.width + 3 * 360 * 480) * 4 + 3 * hc * wc * 4 + 70.6e6
     # HBM bytes per conv launch from the committed PMC passes of this same command (profiles/r01_pmc_hbm.json;
     # FETCH_SIZE / WRITE_SIZE cannot be read live from inside the process)
     traffic = None
@@ -210,13 +214,14 @@ def main():
     except Exception:
         pass
     result = {
-        'metric': 'stitched frames/sec, 720p 2-view (StabStitch++ inference hot path)',
+        'metric': 'stitched frames/sec, %dp %d-view (StabStitch++ inference hot path)' % (args.height, args.views),
         'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(tmax / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[2]: %dx%d 2-view, %d-frame clip per step per GPU, 7-frame SmoothWarp sliding '
+        'config': {'workload': '%s: %dx%d %d-view, %d-frame clip per step per GPU, 7-frame SmoothWarp sliding '
                                'window, warp %s / fusion %s, synthetic checkpoints' % (
-                                   args.height, args.width, args.frames, args.warp_mode, args.fusion_mode),
+                                   'configs[4]' if args.views == 3 else ('configs[2]' if args.height == 720 else 'configs[1]'),
+                                   args.height, args.width, args.views, args.frames, args.warp_mode, args.fusion_mode),
                    'frames_per_step': args.frames, 'canvas': [int(hc), int(wc)], 'parallelism': 'streams%d' % world,
                    'published_reference': '28.3 fps on 1x RTX 4090 at 360x480 (README.md:30); different resolution '
                                           'and hardware, not comparable'},
@@ -230,7 +235,7 @@ def main():
                      'kernel_ms_per_step': round(conv_ms, 3),
                      'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5)},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.views == 2:
         threads = max(1, min(args.cpu_threads, os.cpu_count()))
         cfps, cout = cpu_baseline(sds, args.cpu_frames, args.height, args.width, threads)
         result['cpu_baseline'] = {'value': round(cfps, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
