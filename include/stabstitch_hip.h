@@ -120,6 +120,10 @@ int ss_tps_warp_nchw(const float* U, const float* source, const float* T, float*
  * test_online_tra.py:144-147): out [b][c+1][hc][wc] */
 int ss_tps_warp_mask_nchw(const float* U, const float* source, const float* T, float* out, int b, int c,
                           int h, int w, int hc, int wc, int mode, void* stream);
+/* all views of one frame in one launch, per-view image pointers (host array of `views` <= 3 device pointers to
+ * [3][h][w]); out [views][4][hc][wc] = 3 colour planes + ones-mask plane (test_online_tra.py:144-147) */
+int ss_tps_warp_views(const float* const* imgs, const float* source, const float* T, float* out, int views,
+                      int h, int w, int hc, int wc, int mode, void* stream);
 /* fused render of one stitched frame, AVERAGE fusion, 2 or 3 views (chained (1+2)+3):
  * imgs: array of `views` device pointers (host array) to [3][h][w]; source [views][63][2];
  * T [views][2][66]; out [3][hc][wc]. */
@@ -158,6 +162,11 @@ int ss_smooth_finalize(const float* smesh1, const float* smesh2, const float* ts
                        const float* delta, float* ori_mesh1, float* ori_mesh2, float* ori_path1,
                        float* ori_path2, float* smooth_mesh1, float* smooth_mesh2, float* smooth_path1,
                        float* smooth_path2, int nw, int t, int wstride, int zero_first, void* stream);
+
+/* canvas-sized elementwise helpers of the harnesses: out = (in + add) * mul  ((img+1)*127.5,
+ * test_metric_ssd.py:166);  out = a + b - a*b  (three-view mask union, test_online_tra_threeview.py:501) */
+int ss_add_mul(const float* in, float* out, float add, float mul, long long n, void* stream);
+int ss_mask_union(const float* a, const float* b, float* out, long long n, void* stream);
 
 /* ---- metric harness (test_metric_ssd.py:444-482, 513-527) -------------------------------------
  * w1, w2: [frames][4][h][w] = 3 colour planes (0..255) + validity-mask plane, as ss_tps_warp_mask_nchw

@@ -41,6 +41,9 @@ SIGNATURES = {
     'ss_tsmotion': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_f, c_fp, c_st]),
     'ss_tps_warp_nchw': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_tps_warp_mask_nchw': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
+    'ss_tps_warp_views': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_add_mul': (c_i, [c_fp, c_fp, c_f, c_f, c_ll, c_st]),
+    'ss_mask_union': (c_i, [c_fp, c_fp, c_fp, c_ll, c_st]),
     'ss_render_average': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
     'ss_linear_blend_workspace_floats': (c_ll, [c_i, c_i]),
     'ss_linear_blend': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_st]),

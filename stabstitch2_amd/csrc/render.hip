@@ -30,6 +30,22 @@ __device__ __forceinline__ float sample_fast(const float* __restrict__ pl, float
     return r;
 }
 
+// zero padding on an all-ones plane: sum of the in-range tap weights (grid_sample of a ones image)
+__device__ __forceinline__ float fast_mask(float xn, float yn, int w, int h) {
+    float xx = ((xn + 1.f) / 2.f) * (float)(w - 1), yy = ((yn + 1.f) / 2.f) * (float)(h - 1);
+    float xf = fminf(fmaxf(floorf(xx), -4.f), (float)w + 4.f);
+    float yf = fminf(fmaxf(floorf(yy), -4.f), (float)h + 4.f);
+    int x0 = (int)xf, y0 = (int)yf;
+    bool vx0 = (unsigned)x0 < (unsigned)w, vx1 = (unsigned)(x0 + 1) < (unsigned)w;
+    bool vy0 = (unsigned)y0 < (unsigned)h, vy1 = (unsigned)(y0 + 1) < (unsigned)h;
+    float r = 0.f;
+    if (vx0 && vy0) r += (xf + 1.f - xx) * (yf + 1.f - yy);
+    if (vx1 && vy0) r += (xx - xf) * (yf + 1.f - yy);
+    if (vx0 && vy1) r += (xf + 1.f - xx) * (yy - yf);
+    if (vx1 && vy1) r += (xx - xf) * (yy - yf);
+    return r;
+}
+
 // append_mask: emit one extra channel = warp of an all-ones plane (test_online_tra.py:144-147)
 __global__ __launch_bounds__(256) void tps_warp_kernel(const float* __restrict__ U, const float* __restrict__ source,
                                                        const float* __restrict__ T, float* __restrict__ out, int c,
@@ -59,22 +75,7 @@ __global__ __launch_bounds__(256) void tps_warp_kernel(const float* __restrict__
         if (append_mask) o[c * ohw] = blend4(t, 1.f, 1.f, 1.f, 1.f);
     } else {
         for (int ch = 0; ch < c; ++ch) o[ch * ohw] = sample_fast(in + ch * hw, xn, yn, w, h);
-        if (append_mask) {
-            // zero padding on an all-ones plane: sum of the in-range tap weights
-            float xx = ((xn + 1.f) / 2.f) * (float)(w - 1), yy = ((yn + 1.f) / 2.f) * (float)(h - 1);
-            float xf = floorf(xx), yf = floorf(yy), tx = xx - xf, ty = yy - yf;
-            xf = fminf(fmaxf(xf, -4.f), (float)w + 4.f);
-            yf = fminf(fmaxf(yf, -4.f), (float)h + 4.f);
-            int x0 = (int)xf, y0 = (int)yf;
-            bool vx0 = (unsigned)x0 < (unsigned)w, vx1 = (unsigned)(x0 + 1) < (unsigned)w;
-            bool vy0 = (unsigned)y0 < (unsigned)h, vy1 = (unsigned)(y0 + 1) < (unsigned)h;
-            float r = 0.f;
-            if (vx0 && vy0) r += (1.f - tx) * (1.f - ty);
-            if (vx1 && vy0) r += tx * (1.f - ty);
-            if (vx0 && vy1) r += (1.f - tx) * ty;
-            if (vx1 && vy1) r += tx * ty;
-            o[c * ohw] = r;
-        }
+        if (append_mask) o[c * ohw] = fast_mask(xn, yn, w, h);
     }
 }
 
@@ -104,6 +105,74 @@ extern "C" int ss_tps_warp_mask_nchw(const float* U, const float* source, const 
 struct RenderViews {
     const float* img[3];
 };
+
+__global__ __launch_bounds__(256) void tps_warp_views_kernel(RenderViews rv, const float* __restrict__ source,
+                                                             const float* __restrict__ T, float* __restrict__ out,
+                                                             int h, int w, int hc, int wc, int mode) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= wc || y >= hc) return;
+    const float* src = source + (long long)b * SS_NV * 2;
+    const float* Tx = T + (long long)b * 2 * SS_NT;
+    float gx = linspace_at(-1.f, 1.f, wc, x), gy = linspace_at(-1.f, 1.f, hc, y);
+    float xn, yn;
+    tps_eval_fast(src, Tx, Tx + SS_NT, gx, gy, xn, yn);
+    const long long hw = (long long)h * w, ohw = (long long)hc * wc;
+    float* o = out + (long long)b * 4 * ohw + (long long)y * wc + x;
+    const float* in = b == 0 ? rv.img[0] : (b == 1 ? rv.img[1] : rv.img[2]);
+    if (mode == SS_WARP_NORMAL) {
+        SsTaps t = taps_normal(xn, yn, w, h);
+        long long ia = (long long)t.y0 * w + t.x0, ib = (long long)t.y1 * w + t.x0;
+        long long ic = (long long)t.y0 * w + t.x1, id = (long long)t.y1 * w + t.x1;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float* pl = in + ch * hw;
+            o[ch * ohw] = blend4(t, pl[ia], pl[ib], pl[ic], pl[id]);
+        }
+        o[3 * ohw] = blend4(t, 1.f, 1.f, 1.f, 1.f);
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[ch * ohw] = sample_fast(in + ch * hw, xn, yn, w, h);
+        o[3 * ohw] = fast_mask(xn, yn, w, h);
+    }
+}
+
+extern "C" int ss_tps_warp_views(const float* const* imgs, const float* source, const float* T, float* out, int views,
+                                 int h, int w, int hc, int wc, int mode, void* stream) {
+    if (!imgs || !source || !T || !out || views < 1 || views > 3 || h <= 1 || w <= 1 || hc <= 1 || wc <= 1 ||
+        (mode != SS_WARP_NORMAL && mode != SS_WARP_FAST))
+        return SS_ERR_ARG;
+    RenderViews rv;
+    for (int i = 0; i < 3; ++i) rv.img[i] = i < views ? imgs[i] : nullptr;
+    for (int i = 0; i < views; ++i)
+        if (!rv.img[i]) return SS_ERR_ARG;
+    dim3 g(ss_cdiv(wc, 64), ss_cdiv(hc, 4), views);
+    hipLaunchKernelGGL(tps_warp_views_kernel, g, dim3(256), 0, (hipStream_t)stream, rv, source, T, out, h, w, hc, wc,
+                       mode);
+    return ss_launch_status();
+}
+
+// small canvas-sized elementwise helpers of the harnesses
+__global__ void affine_kernel(const float* __restrict__ in, float* __restrict__ out, float add, float mul, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __fmul_rn(__fadd_rn(in[i], add), mul);
+}
+extern "C" int ss_add_mul(const float* in, float* out, float add, float mul, long long n, void* stream) {
+    if (!in || !out || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(affine_kernel, dim3(ss_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, add, mul, n);
+    return ss_launch_status();
+}
+__global__ void mask_union_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                  long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __fsub_rn(__fadd_rn(a[i], b[i]), __fmul_rn(a[i], b[i]));
+}
+extern "C" int ss_mask_union(const float* a, const float* b, float* out, long long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(mask_union_kernel, dim3(ss_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return ss_launch_status();
+}
 
 __device__ __forceinline__ float avg_fuse(float a, float b) {
     float s = __fadd_rn(__fadd_rn(a, b), 1e-6f);

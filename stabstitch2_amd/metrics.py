@@ -18,7 +18,7 @@ def warp_lr_planes(lr, smooth_mesh):
     """lr [N,3,360,480] device in [-1,1]; smooth_mesh [1,N,7,9,2] -> [N,4,360,480] (3 colour 0..255 + mask)."""
     n, _, h, w = lr.shape
     dev = lr.device
-    img = ((lr + 1) * 127.5).contiguous()
+    img = ops.add_mul(lr.contiguous().float(), 1.0, 127.5)
     nm = get_norm_mesh(smooth_mesh[0], h, w).contiguous()
     nrigid = get_norm_mesh(get_rigid_mesh(1, h, w, device=dev), h, w).expand(n, -1, -1).contiguous()
     T = ops.tps_solve(nm, nrigid)

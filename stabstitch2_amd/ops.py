@@ -202,11 +202,40 @@ def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None):
     return out
 
 
-def linear_blend(ref, tgt, ref_m, tgt_m, want_mask=False):
+def tps_warp_views(imgs, source, T, hc, wc, mode='NORMAL'):
+    """imgs: list of V <= 3 device tensors [1,3,h,w] / [3,h,w] -> [V,4,hc,wc] (3 colour planes + ones-mask plane)."""
+    v = len(imgs)
+    imgs = [_f(i) for i in imgs]
+    h, w = imgs[0].shape[-2:]
+    for i in imgs:
+        H.dptr(i)
+    arr = (ctypes.c_void_p * v)(*[i.data_ptr() for i in imgs])
+    out = torch.empty((v, 4, hc, wc), device=imgs[0].device, dtype=torch.float32)
+    H.call('ss_tps_warp_views', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(out), v, h, w, hc, wc, MODES[mode],
+           H.stream())
+    return out
+
+
+def add_mul(x, add, mul):
+    out = torch.empty_like(x)
+    H.call('ss_add_mul', H.dptr(x), H.dptr(out), float(add), float(mul), x.numel(), H.stream())
+    return out
+
+
+def mask_union(a, b):
+    out = torch.empty_like(a)
+    H.call('ss_mask_union', H.dptr(a), H.dptr(b), H.dptr(out), a.numel(), H.stream())
+    return out
+
+
+def linear_blend(ref, tgt, ref_m, tgt_m, want_mask=False, out=None):
     """ref,tgt [3,hc,wc]; ref_m,tgt_m [hc,wc] -> fused [3,hc,wc] (or mask1 [hc,wc])."""
     hc, wc = ref_m.shape[-2:]
     ws = torch.empty(int(H.lib().ss_linear_blend_workspace_floats(hc, wc)), device=ref_m.device, dtype=torch.float32)
-    out = None if want_mask else torch.empty((3, hc, wc), device=ref_m.device, dtype=torch.float32)
+    if not want_mask and out is None:
+        out = torch.empty((3, hc, wc), device=ref_m.device, dtype=torch.float32)
+    if want_mask:
+        out = None
     mk = torch.empty((hc, wc), device=ref_m.device, dtype=torch.float32) if want_mask else None
     H.call('ss_linear_blend', H.dptr(ref, True), H.dptr(tgt, True), H.dptr(_f(ref_m)), H.dptr(_f(tgt_m)),
            H.dptr(out, True), H.dptr(mk, True), hc, wc, H.dptr(ws), H.stream())

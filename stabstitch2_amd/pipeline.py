@@ -173,13 +173,12 @@ def render_frames(img_lists, meshes, warp_mode='NORMAL', fusion_mode='AVERAGE', 
         if fusion_mode == 'AVERAGE':
             ops.render_average(imgs, src[i], T[i], hc, wc, warp_mode, out=out[i])
         else:
-            U = torch.stack([im.reshape(3, img_h, img_w) for im in imgs], 0)
-            w = ops.tps_warp(U, src[i], T[i], hc, wc, warp_mode, with_mask=True)     # [V,4,Hc,Wc]
-            f = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
-            if v == 3:
-                m12 = w[0, 3] + w[1, 3] - w[0, 3] * w[1, 3]
-                f = ops.linear_blend(f, w[2, 0:3], m12.contiguous(), w[2, 3])
-            out[i].copy_(f)
+            w = ops.tps_warp_views(imgs, src[i], T[i], hc, wc, warp_mode)            # [V,4,Hc,Wc]
+            if v == 2:
+                ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3], out=out[i])
+            else:
+                f = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
+                ops.linear_blend(f, w[2, 0:3], ops.mask_union(w[0, 3], w[1, 3]), w[2, 3], out=out[i])
     return out, hc, wc
 
 
