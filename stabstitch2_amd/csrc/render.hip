@@ -264,19 +264,29 @@ __global__ void lb_init_kernel(unsigned long long* s) {
     if (threadIdx.x == 0) { u[12] = 0xffffffffu; u[13] = 0u; }
 }
 
+// 2-D indexing (block = 64 columns x 4 rows, grid-stride over row groups): no per-pixel integer division
 __global__ __launch_bounds__(256) void lb_centroid_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
                                                           unsigned long long* s, int hc, int wc) {
     __shared__ unsigned long long red[6];
     if (threadIdx.x < 6) red[threadIdx.x] = 0ull;
     __syncthreads();
-    unsigned long long loc[6] = {0, 0, 0, 0, 0, 0};
-    long long n = (long long)hc * wc;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        int r = (int)(i / wc), c = (int)(i - (long long)r * wc);
-        if (m1[i] != 0.f) { loc[0] += 1; loc[1] += r; loc[2] += c; }
-        if (m2[i] != 0.f) { loc[3] += 1; loc[4] += r; loc[5] += c; }
+    unsigned c1 = 0, r1 = 0, k1 = 0, c2 = 0, r2 = 0, k2 = 0;      // per-thread partials fit 32 bits (<= hc/ (4 gridDim.y) rows)
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c < wc) {
+        for (int r = blockIdx.y * 4 + (threadIdx.x >> 6); r < hc; r += gridDim.y * 4) {
+            long long i = (long long)r * wc + c;
+            if (m1[i] != 0.f) { k1 += 1; r1 += r; c1 += c; }
+            if (m2[i] != 0.f) { k2 += 1; r2 += r; c2 += c; }
+        }
     }
-    for (int k = 0; k < 6; ++k) atomicAdd(&red[k], loc[k]);
+    unsigned v[6] = {k1, r1, c1, k2, r2, c2};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        unsigned long long t = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], t);
+    }
     __syncthreads();
     if (threadIdx.x < 6) atomicAdd(&s[threadIdx.x], red[threadIdx.x]);
 }
@@ -303,13 +313,15 @@ __global__ __launch_bounds__(256) void lb_range_kernel(const float* __restrict__
                                                        unsigned long long* s, int hc, int wc) {
     LbCenters L = lb_centers(s);
     float mn = INFINITY, mx = -INFINITY;
-    long long n = (long long)hc * wc;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        if (lb_overlap(m1[i], m2[i])) {
-            int r = (int)(i / wc), c = (int)(i - (long long)r * wc);
-            float p = lb_proj(L, r, c);
-            mn = fminf(mn, p);
-            mx = fmaxf(mx, p);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c < wc) {
+        for (int r = blockIdx.y * 4 + (threadIdx.x >> 6); r < hc; r += gridDim.y * 4) {
+            long long i = (long long)r * wc + c;
+            if (lb_overlap(m1[i], m2[i])) {
+                float p = lb_proj(L, r, c);
+                mn = fminf(mn, p);
+                mx = fmaxf(mx, p);
+            }
         }
     }
     mn = ss_wave_min(mn);
@@ -324,8 +336,9 @@ __global__ __launch_bounds__(256) void lb_range_kernel(const float* __restrict__
 // X = ref_only + (1 - ovl_mask) * m1
 __global__ void lb_premask_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
                                   const unsigned long long* s, float* __restrict__ X, int hc, int wc) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)hc * wc) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= wc || r >= hc) return;
+    const long long i = (long long)r * wc + c;
     const unsigned* u = reinterpret_cast<const unsigned*>(s);
     float a = m1[i], b = m2[i];
     float ovl = rintf(__fmul_rn(a, b));
@@ -334,7 +347,6 @@ __global__ void lb_premask_kernel(const float* __restrict__ m1, const float* __r
     if (ovl != 0.f) {
         LbCenters L = lb_centers(s);
         float pmin = key2f(u[12]), pmax = key2f(u[13]);
-        int r = (int)(i / wc), c = (int)(i - (long long)r * wc);
         om = __fsub_rn(lb_proj(L, r, c), pmin) / __fadd_rn(__fsub_rn(pmax, pmin), 1e-3f);
     }
     X[i] = __fadd_rn(ref_only, __fmul_rn(__fsub_rn(1.f, om), a));
@@ -353,9 +365,9 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // separable 21-tap Gaussian, reflect border (torchvision GaussianBlur((21,21), 20))
 __global__ void lb_blur_kernel(const float* __restrict__ in, float* __restrict__ out, int hc, int wc, int vertical,
                                Gauss21 g) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)hc * wc) return;
-    int r = (int)(i / wc), c = (int)(i - (long long)r * wc);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= wc || r >= hc) return;
+    const long long i = (long long)r * wc + c;
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 21; ++k) {
@@ -370,9 +382,10 @@ __global__ void lb_final_kernel(const float* __restrict__ ref, const float* __re
                                 const float* __restrict__ m1, const float* __restrict__ m2,
                                 const float* __restrict__ blur, float* __restrict__ out, float* __restrict__ mask1_out,
                                 int hc, int wc) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long n = (long long)hc * wc;
-    if (i >= n) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const long long n = (long long)hc * wc;
+    if (c >= wc || r >= hc) return;
+    const long long i = (long long)r * wc + c;
     float a = m1[i], b = m2[i];
     float ovl = rintf(__fmul_rn(a, b));
     float ref_only = __fsub_rn(a, ovl);
@@ -407,16 +420,15 @@ extern "C" int ss_linear_blend(const float* ref, const float* tgt, const float* 
     unsigned long long* sc = reinterpret_cast<unsigned long long*>(ws);
     float* X = ws + 32;
     float* tmp = X + (long long)hc * wc;
-    long long n = (long long)hc * wc;
-    int nb = ss_cdiv(n, 256);
-    int rb = nb < 1024 ? nb : 1024;
     hipLaunchKernelGGL(lb_init_kernel, dim3(1), dim3(64), 0, st, sc);
-    hipLaunchKernelGGL(lb_centroid_kernel, dim3(rb), dim3(256), 0, st, ref_m, tgt_m, sc, hc, wc);
-    hipLaunchKernelGGL(lb_range_kernel, dim3(rb), dim3(256), 0, st, ref_m, tgt_m, sc, hc, wc);
-    hipLaunchKernelGGL(lb_premask_kernel, dim3(nb), dim3(256), 0, st, ref_m, tgt_m, (const unsigned long long*)sc, X, hc, wc);
-    hipLaunchKernelGGL(lb_blur_kernel, dim3(nb), dim3(256), 0, st, (const float*)X, tmp, hc, wc, 0, g);
-    hipLaunchKernelGGL(lb_blur_kernel, dim3(nb), dim3(256), 0, st, (const float*)tmp, X, hc, wc, 1, g);
-    hipLaunchKernelGGL(lb_final_kernel, dim3(nb), dim3(256), 0, st, ref, tgt, ref_m, tgt_m, (const float*)X, out,
+    dim3 rg(ss_cdiv(wc, 64), ss_cdiv(hc, 16) < 64 ? ss_cdiv(hc, 16) : 64);
+    hipLaunchKernelGGL(lb_centroid_kernel, rg, dim3(256), 0, st, ref_m, tgt_m, sc, hc, wc);
+    hipLaunchKernelGGL(lb_range_kernel, rg, dim3(256), 0, st, ref_m, tgt_m, sc, hc, wc);
+    const dim3 pg(ss_cdiv(wc, 64), ss_cdiv(hc, 4));
+    hipLaunchKernelGGL(lb_premask_kernel, pg, dim3(256), 0, st, ref_m, tgt_m, (const unsigned long long*)sc, X, hc, wc);
+    hipLaunchKernelGGL(lb_blur_kernel, pg, dim3(256), 0, st, (const float*)X, tmp, hc, wc, 0, g);
+    hipLaunchKernelGGL(lb_blur_kernel, pg, dim3(256), 0, st, (const float*)tmp, X, hc, wc, 1, g);
+    hipLaunchKernelGGL(lb_final_kernel, pg, dim3(256), 0, st, ref, tgt, ref_m, tgt_m, (const float*)X, out,
                        mask1_out, hc, wc);
     return ss_launch_status();
 }
