@@ -49,11 +49,10 @@ struct ConvP {
     unsigned ntiles;                 // Cout tiles (grid.x = M tiles * ntiles)
     long long in_gs, w_gs, out_gs;
     unsigned in_bytes, w_bytes;      // per-group extents for the buffer descriptors
-    int ablate;                      // tuning aid (SS_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
+    int ablate;                      // tuning aid (SS_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier,
+                                     // 8 no XCD tile order, 16 s_setprio around the MFMA cluster
 };
 
-#define BK 32
-#define LDK 36
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base, unsigned bytes) {
     unsigned long long a = (unsigned long long)base;
@@ -63,12 +62,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1>
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     constexpr int BM = WGM * WM * 32;
     constexpr int BN = WGN * WN * 32;
-    constexpr int RA = BM / 32;   // A rows staged per thread
-    constexpr int RB = BN / 32;
+    constexpr int LDK = BK + 4;          // row stride in dwords: 4 * odd -> conflict-free ds_read_b128
+    constexpr int TPR = BK / 4;          // threads (float4s) per tile row
+    constexpr int RPP = 256 / TPR;       // rows staged per pass
+    constexpr int RA = BM / RPP;         // A rows staged per thread
+    constexpr int RB = BN / RPP;
+    constexpr int NCH = BK / 8;          // 4-wide operand chunks per lane half
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
 
@@ -100,15 +103,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     const __amdgpu_buffer_rsrc_t rin = uniform_rsrc(p.in + (long long)grp * p.in_gs, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rw = uniform_rsrc(p.wgt + (long long)grp * p.w_gs, p.w_bytes);
 
-    const int lrow = tid >> 3;   // 0..31
-    const int kq = tid & 7;      // which float4 of the 32-wide K tile
+    const int lrow = tid / TPR;
+    const int kq = tid % TPR;    // which float4 of the BK-wide K tile
 
     // per-thread row bookkeeping (fixed over the K loop): byte offset of tap (0,0,0) and validity masks
     int a_off[RA];
     unsigned a_msk[RA];          // bits 0..7: valid dw, 8..15: valid dh, 16..23: valid dt (0 for rows >= M)
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        int m = m0 + lrow + i * 32;
+        int m = m0 + lrow + i * RPP;
         bool ok = m < p.M;
         int mm = ok ? m : 0;
         int wo = mm % p.Wo;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     unsigned w_off[RB], w_bad[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        int co = n0 + lrow + i * 32;
+        int co = n0 + lrow + i * RPP;
         w_off[i] = (unsigned)co * (unsigned)p.K * 4u;
         w_bad[i] = co < p.Co ? 0u : 0xFFFFFFFFu;
     }
@@ -163,10 +166,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<u32x4*>(&As[buf][(lrow + i * 32) * LDK + kq * 4]) = ra[i];
+            *reinterpret_cast<u32x4*>(&As[buf][(lrow + i * RPP) * LDK + kq * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            *reinterpret_cast<u32x4*>(&Bs[buf][(lrow + i * 32) * LDK + kq * 4]) = rb[i];
+            *reinterpret_cast<u32x4*>(&Bs[buf][(lrow + i * RPP) * LDK + kq * 4]) = rb[i];
     };
 
     f32x16 acc[WM][WN];
@@ -177,12 +180,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;   // == host-side nk for this BK
     const int kt0 = split * p.tiles_per_split;
     const int kt1 = min(nk_all, kt0 + p.tiles_per_split);
     const int li = lane & 31, lh = lane >> 5;
-    const int aidx = (wr * WM * 32 + li) * LDK + lh * 16;
-    const int bidx = (wc * WN * 32 + li) * LDK + lh * 16;
+    const int aidx = (wr * WM * 32 + li) * LDK + lh * (BK / 2);
+    const int bidx = (wc * WN * 32 + li) * LDK + lh * (BK / 2);
 
     auto mma_chunk = [&](int buf, int c) {
         f32x4 a[WM], b[WN];
@@ -211,9 +214,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         // end of K only multiply zeros (e.g. conv1: K = 196 -> the 7th tile needs 1 chunk of 4).  The full tile
         // is a separate, branch-free copy so that the compiler keeps its LDS-read / MFMA software pipeline.
         const int krem = p.K - kt * BK;
-        if (krem >= 16) {
+        if (krem >= BK / 2) {
+            if (p.ablate & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mma_chunk(buf, c);
+            for (int c = 0; c < NCH; ++c) mma_chunk(buf, c);
+            if (p.ablate & 16) __builtin_amdgcn_s_setprio(0);
         } else {
             const int cmax = (krem + 3) >> 2;
             for (int c = 0; c < cmax; ++c) mma_chunk(buf, c);
@@ -269,13 +274,13 @@ __global__ void splitk_reduce_kernel(ConvP p) {
     p.out[o] = v;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1>
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32>
 static void launch_conv(const ConvP& p, int groups, hipStream_t st) {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     ConvP q = p;
     q.ntiles = (unsigned)ss_cdiv(p.Co, BN);
     dim3 g((unsigned)ss_cdiv(p.M, BM) * q.ntiles, 1, groups * p.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW>), g, dim3(256), 0, st, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK>), g, dim3(256), 0, st, q);
 }
 
 // tuning aids, not part of the public ABI: key 0 = force tile variant, key 1 = ablation mask
@@ -321,7 +326,7 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     p.in_bytes = (unsigned)(in_elems * 4);
     p.w_bytes = (unsigned)(w_elems * 4);
     hipStream_t st = (hipStream_t)stream;
-    const int nk = ss_cdiv(K, BK);
+    const int nk = ss_cdiv(K, 32);
     p.splits = 1;
     p.tiles_per_split = nk;
     p.ablate = g_ablate;
@@ -340,6 +345,10 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
         launch_conv<4, 1, 2, 2, 1>(p, groups, st);
     } else if (best == 5) {
         launch_conv<2, 2, 2, 2, 1>(p, groups, st);
+    } else if (best == 10) {
+        ConvP q = p;
+        q.tiles_per_split = ss_cdiv(K, 64);
+        launch_conv<2, 2, 1, 1, 1, 1, 64>(q, groups, st);
     } else if (best == 8) {
         launch_conv<2, 2, 1, 1, 1, 8>(p, groups, st);
     } else if (best == 9) {

@@ -240,90 +240,106 @@ extern "C" int ss_homo_warp_nchw(const float* in, const float* theta, float* out
 // ------------------------------------------------------------------------------------------------
 // TPS: 66x66 system [[P,R],[0,P^T]] assembled in fp32 as the reference does, solved in fp64.
 #define TPS_LD 68
-// one block of 256 threads per system; src_stride = 0 shares one source mesh across the batch
-__global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
+#define TPS_TQ 17        // columns per thread: 4 x 17 = 66 system columns + 2 right-hand sides
+// One workgroup of 320 threads per system, the augmented 66x68 matrix lives in REGISTERS: thread (r, q) = (tid>>2,
+// tid&3) owns columns 17q..17q+16 of row r.  Gauss-Jordan with partial pivoting and no physical row swaps (a used-row
+// flag instead); per column: publish |A[r][col]| -> wave-0 arg-max -> pivot row broadcast through LDS -> every row
+// subtracts f * pivot_row with f fetched from its 4-lane row group by a shuffle.  All register indices are static
+// (steps unrolled per 17-column quarter); three barriers per step, 94 us per system vs 196 us LDS-resident.  src_stride = 0 shares one source mesh across the batch.
+__global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
                                                         const float* __restrict__ target,
                                                         float* __restrict__ T) {
-    __shared__ double A[SS_NT][TPS_LD];
     __shared__ float sx[SS_NV], sy[SS_NV];
+    __shared__ double colabs[SS_NT], prow[TPS_LD], diag[SS_NT];
     __shared__ int s_piv;
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int r = tid >> 2, q = tid & 3;
+    const bool rowok = r < SS_NT;
     const float* src = source + (long long)b * src_stride;
     const float* tgt = target + (long long)b * SS_NV * 2;
     if (tid < SS_NV) { sx[tid] = src[tid * 2]; sy[tid] = src[tid * 2 + 1]; }
     __syncthreads();
-    for (int e = tid; e < SS_NT * TPS_LD; e += 256) {
-        int r = e / TPS_LD, c = e - r * TPS_LD;
+    double a[TPS_TQ];
+#pragma unroll
+    for (int j = 0; j < TPS_TQ; ++j) {
+        const int c = q * TPS_TQ + j;
         double v = 0.0;
-        if (r < SS_NV) {
-            if (c == 0) v = 1.0;
-            else if (c == 1) v = sx[r];
-            else if (c == 2) v = sy[r];
-            else if (c < SS_NT) {
-                // fp32 kernel entries like the reference, but with a correctly rounded log (via fp64): the
-                // 66x66 system amplifies last-bit differences of logf ~100x into T (measured 3e-5 on |T|<2)
-                float dx = __fsub_rn(sx[r], sx[c - 3]), dy = __fsub_rn(sy[r], sy[c - 3]);
-                float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-                v = (double)__fmul_rn(d2, (float)log((double)__fadd_rn(d2, 1e-6f)));
+        if (rowok) {
+            if (r < SS_NV) {
+                if (c == 0) v = 1.0;
+                else if (c == 1) v = sx[r];
+                else if (c == 2) v = sy[r];
+                else if (c < SS_NT) {
+                    // fp32 kernel entries like the reference, but with a correctly rounded log (via fp64): the
+                    // 66x66 system amplifies last-bit differences of logf ~100x into T (measured 3e-5 on |T|<2)
+                    float dx = __fsub_rn(sx[r], sx[c - 3]), dy = __fsub_rn(sy[r], sy[c - 3]);
+                    float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                    v = (double)__fmul_rn(d2, (float)log((double)__fadd_rn(d2, 1e-6f)));
+                } else v = tgt[r * 2 + (c - SS_NT)];
+            } else if (c >= 3 && c < SS_NT) {
+                const int k = r - SS_NV;
+                v = k == 0 ? 1.0 : (k == 1 ? (double)sx[c - 3] : (double)sy[c - 3]);
             }
-            else v = tgt[r * 2 + (c - SS_NT)];
-        } else if (c >= 3 && c < SS_NT) {
-            int k = r - SS_NV;
-            v = k == 0 ? 1.0 : (k == 1 ? (double)sx[c - 3] : (double)sy[c - 3]);
         }
-        A[r][c] = v;
+        a[j] = v;
+    }
+    bool used = false;
+    int mycol = 0;
+    // (measured: letting every wave redo the arg-max to save the broadcast barrier, with all 66 steps unrolled into
+    //  one straight-line body, is 1.7x SLOWER -- instruction-cache bound; this form runs 94 us per system)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+        for (int j = 0; j < TPS_TQ; ++j) {
+            const int col = qq * TPS_TQ + j;
+            if (col < SS_NT) {
+                if (rowok && q == qq) colabs[r] = used ? -1.0 : fabs(a[j]);
+                __syncthreads();
+                if (tid < 64) {     // arg-max over the unused rows (lowest row wins ties)
+                    double best = colabs[tid];
+                    int piv = tid;
+                    if (tid + 64 < SS_NT) {
+                        double v1 = colabs[tid + 64];
+                        if (v1 > best) { best = v1; piv = tid + 64; }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        double ob = __shfl_xor(best, o, 64);
+                        int op = __shfl_xor(piv, o, 64);
+                        if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+                    }
+                    if (tid == 0) s_piv = piv;
+                }
+                __syncthreads();
+                const int piv = s_piv;
+                if (r == piv) {
+#pragma unroll
+                    for (int jj = 0; jj < TPS_TQ; ++jj) prow[q * TPS_TQ + jj] = a[jj];
+                    if (q == qq) diag[r] = a[j];
+                    used = true;
+                    mycol = col;
+                }
+                __syncthreads();
+                const double pinv = 1.0 / prow[col];
+                const double f = __shfl(a[j], (tid & 60) | qq, 64) * pinv;   // A[r][col] sits in lane (row group, qq)
+                if (rowok && r != piv) {
+#pragma unroll
+                    for (int jj = 0; jj < TPS_TQ; ++jj) a[jj] -= f * prow[q * TPS_TQ + jj];
+                }
+            }
+        }
     }
     __syncthreads();
-    for (int col = 0; col < SS_NT; ++col) {
-        if (tid < 64) {     // partial pivoting: wave-parallel arg-max of |A[r][col]|, r >= col (lowest r wins ties)
-            int r0 = col + tid, r1 = r0 + 64;
-            double best = r0 < SS_NT ? fabs(A[r0][col]) : -1.0;
-            int piv = r0;
-            if (r1 < SS_NT) {
-                double v1 = fabs(A[r1][col]);
-                if (v1 > best) { best = v1; piv = r1; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                double ob = __shfl_xor(best, o, 64);
-                int op = __shfl_xor(piv, o, 64);
-                if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
-            }
-            if (tid == 0) s_piv = piv;
-        }
-        __syncthreads();
-        int piv = s_piv;
-        if (piv != col && tid < TPS_LD) {
-            double t = A[col][tid]; A[col][tid] = A[piv][tid]; A[piv][tid] = t;
-        }
-        __syncthreads();
-        const double pinv = 1.0 / A[col][col];
-        // Gauss-Jordan: eliminate column `col` from every other row (columns > col only).  Wave w owns rows
-        // w, w+4, ...; lanes own the columns (<= 67 to go, i.e. at most two passes) -- no integer divisions.
-        {
-            const int wv = tid >> 6, ln = tid & 63;
-            const int c0 = col + 1 + ln, c1 = c0 + 64;
-            const double p0 = c0 < TPS_LD ? A[col][c0] : 0.0;
-            const double p1 = c1 < TPS_LD ? A[col][c1] : 0.0;
-            for (int r = wv; r < SS_NT; r += 4) {
-                if (r == col) continue;
-                const double f = A[r][col] * pinv;
-                if (c0 < TPS_LD) A[r][c0] -= f * p0;
-                if (c1 < TPS_LD) A[r][c1] -= f * p1;
-            }
-        }
-        __syncthreads();
-    }
-    if (tid < SS_NT) {
-        double d = A[tid][tid];
-        T[(long long)b * 2 * SS_NT + tid] = (float)(A[tid][SS_NT] / d);
-        T[(long long)b * 2 * SS_NT + SS_NT + tid] = (float)(A[tid][SS_NT + 1] / d);
+    if (rowok && q == 3) {     // right-hand sides are columns 66, 67 = entries 15, 16 of quarter 3
+        const double d = diag[r];
+        T[(long long)b * 2 * SS_NT + mycol] = (float)(a[SS_NT - 3 * TPS_TQ] / d);
+        T[(long long)b * 2 * SS_NT + SS_NT + mycol] = (float)(a[SS_NT + 1 - 3 * TPS_TQ] / d);
     }
 }
 
 extern "C" int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream) {
     if (!source || !target || !T || n <= 0) return SS_ERR_ARG;
-    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
                        target, T);
     return ss_launch_status();
 }
@@ -414,7 +430,7 @@ extern "C" int ss_tsmotion(const float* smotion, const float* tmotion, float* sm
                        n, img_h, img_w);
     float* ntgt = ws + 126;
     float* T = ntgt + (long long)n * 252;
-    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(256), 0, st, (const float*)ws, 0ll, (const float*)ntgt, T);
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, st, (const float*)ws, 0ll, (const float*)ntgt, T);
     hipLaunchKernelGGL(tsm_finish_kernel, dim3(n), dim3(128), 0, st, (const float*)ws, (const float*)smesh, tsmotion,
                        n, img_h, img_w);
     return ss_launch_status();

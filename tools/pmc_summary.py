@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE), written as JSON.
+    python tools/pmc_summary.py <dir with FETCH csv> <dir with WRITE csv> > profiles/rNN_pmc_hbm.json"""
+import collections
+import csv
+import json
+import sys
+
+KEYS = (('conv_igemm', 'conv_igemm_kernel'), ('render_average', 'render_average_kernel'), ('cost_volume', 'cost_volume_kernel'),
+        ('maxpool', 'maxpool_kernel'), ('linear_kernel', 'linear_kernel'))
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path + '/p_counter_collection.csv')):
+        for pat, key in KEYS:
+            if pat in r['Kernel_Name']:
+                agg[key].append(float(r['Counter_Value']))
+    return agg
+
+
+f, w = load(sys.argv[1]), load(sys.argv[2])
+out = {'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py --steps 2 '
+                  '--warmup 1 --no-cpu-baseline (one pass per counter)',
+       'units': 'counter value x 1000 = bytes.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-B '
+                'requests of a 16-B/lane stream at 64 B, so the conv engine (buffer_load_dwordx4) and maxpool/linear (float4 '
+                'loads) fetch bytes = 2 x FETCH_SIZE; dword gathers (render, cost volume) and WRITE_SIZE are used as reported.',
+       'kernels': {}}
+for key in f:
+    corr = 2.0 if key in ('conv_igemm_kernel', 'maxpool_kernel', 'linear_kernel') else 1.0
+    fa, wa = sum(f[key]) / len(f[key]), sum(w[key]) / len(w[key])
+    out['kernels'][key] = {'launches': len(f[key]), 'FETCH_SIZE_avg': round(fa, 1), 'WRITE_SIZE_avg': round(wa, 1),
+                           'fetch_correction': corr, 'hbm_bytes_per_launch': round((corr * fa + wa) * 1000.0)}
+print(json.dumps(out, indent=1))
