@@ -134,6 +134,7 @@ def main():
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--views', type=int, default=2, choices=(2, 3))
+    ap.add_argument('--online', action='store_true', help='streaming mode: one frame pair per push (batch 1), fixed canvas')
     ap.add_argument('--warp_mode', default='NORMAL')
     ap.add_argument('--fusion_mode', default='AVERAGE')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -165,7 +166,19 @@ def main():
     probe = ConvProbe()
     probe.install()
 
+    def step_online():
+        from stabstitch2_amd.online import OnlineStitcher
+        st = OnlineStitcher(nets, args.height, args.width, warp_mode=args.warp_mode, fusion_mode=args.fusion_mode)
+        last = None
+        for t in range(args.frames):
+            got = st.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
+            if got:
+                last = got[-1]
+        return last.unsqueeze(0), st.hc, st.wc
+
     def step():
+        if args.online:
+            return step_online()
         if args.views == 3:       # BASELINE configs[4]: two 2-view passes (v1,v2),(v2,v3) + three-view composition
             return pipeline.run_three_view(hr[0], hr[1], hr[2], lr[0], lr[1], lr[2], nets, args.warp_mode,
                                            args.fusion_mode)[:3]
@@ -220,7 +233,8 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %dx%d %d-view, %d-frame clip per step per GPU, 7-frame SmoothWarp sliding '
                                'window, warp %s / fusion %s, synthetic checkpoints' % (
-                                   'configs[4]' if args.views == 3 else ('configs[2]' if args.height == 720 else 'configs[1]'),
+                                   ('streaming (batch 1) ' if args.online else '') +
+                                   ('configs[4]' if args.views == 3 else ('configs[2]' if args.height == 720 else 'configs[1]')),
                                    args.height, args.width, args.views, args.frames, args.warp_mode, args.fusion_mode),
                    'frames_per_step': args.frames, 'canvas': [int(hc), int(wc)], 'parallelism': 'streams%d' % world,
                    'published_reference': '28.3 fps on 1x RTX 4090 at 360x480 (README.md:30); different resolution '
@@ -235,7 +249,7 @@ def main():
                      'kernel_ms_per_step': round(conv_ms, 3),
                      'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5)},
     }
-    if world == 1 and not args.no_cpu_baseline and args.views == 2:
+    if world == 1 and not args.no_cpu_baseline and args.views == 2 and not args.online:
         threads = max(1, min(args.cpu_threads, os.cpu_count()))
         cfps, cout = cpu_baseline(sds, args.cpu_frames, args.height, args.width, threads)
         result['cpu_baseline'] = {'value': round(cfps, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',

@@ -1,0 +1,100 @@
+"""True streaming mode: frames are pushed one pair at a time, the 7-frame SmoothNet window
+slides over a ring buffer, TemporalNet features of the previous frame are cached, and every push renders at most one new
+frame onto a FIXED canvas.
+
+The reference is only "online" up to the smoothing window: its renderer waits for the whole clip because the canvas is
+the bounding box over all frames (test_online_tra.py:106-120).  Here the canvas is fixed when the first window is
+complete (bbox of its 7 frames grown by `margin`), or given by the caller; with the offline bbox passed in, the stream
+reproduces the offline frames (tests/test_gpu_parity.py::test_online_matches_offline).  Per pushed pair the arithmetic is
+exactly the reference's per-frame arithmetic (test_online_tra.py:284-392 with k = t).
+"""
+import torch
+
+from . import ops, pipeline
+from .spatial_network import build_SpatialNet, get_rigid_mesh, get_norm_mesh
+
+WINDOW = pipeline.WINDOW
+
+
+class OnlineStitcher:
+    def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE'):
+        """canvas: optional (wmin, wmax, hmin, hmax) in HR pixels (e.g. the offline bbox)."""
+        self.spatial, self.temporal, self.smooth = nets
+        self.dev = next(self.spatial.parameters()).device
+        self.h, self.w = height, width
+        self.margin = margin
+        self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
+        self.bbox = None if canvas is None else torch.tensor(canvas, dtype=torch.float32, device=self.dev)
+        self.hc = self.wc = None
+        self.nrigid = get_norm_mesh(get_rigid_mesh(1, height, width, device=self.dev), height, width).contiguous()
+        self.frames_in = 0
+        self.prev_feat = None            # TemporalNet stage-1 features of the previous frame, both views [2,45,60,128]
+        self.prev_smotion = None         # [2,7,9,2]
+        self.ring_smesh = [[], []]       # last WINDOW spatial meshes per view, each [1,7,9,2]
+        self.ring_tsm = [[], []]
+        self.ring_hr = []                # HR frames waiting for their smoothed mesh (only until the first window)
+
+    def _set_canvas(self):
+        bb = self.bbox.cpu()
+        self.hc = int((bb[3] - bb[2]).int())
+        self.wc = int((bb[1] - bb[0]).int())
+
+    @torch.no_grad()
+    def _render(self, hr1, hr2, mesh1, mesh2):
+        """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc]."""
+        src = torch.cat((ops.mesh_normalize(mesh1, self.bbox, self.h, self.w),
+                         ops.mesh_normalize(mesh2, self.bbox, self.h, self.w)), 0)
+        T = ops.tps_solve(src, self.nrigid.expand(2, -1, -1).contiguous())
+        if self.fusion_mode == 'AVERAGE':
+            return ops.render_average([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode)
+        w = ops.tps_warp_views([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode)
+        return ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
+
+    @torch.no_grad()
+    def push(self, hr1, hr2, lr1, lr2):
+        """One frame pair: hr* [1,3,H,W] (0..255), lr* [1,3,360,480] ([-1,1]), device tensors.
+        -> list of newly stitched frames (empty for the first 6 pushes, 7 frames on the 7th, then one per push)."""
+        t = self.frames_in
+        # spatial warp of this pair
+        o = build_SpatialNet(self.spatial, lr1, lr2)
+        smotion = torch.cat((o['motion1'], o['motion2']), 0)                        # [2,7,9,2]
+        # temporal warp: only the new frame goes through the trunk, the previous features are cached
+        feat = self.temporal.features([lr1, lr2])                                   # [2,45,60,128]
+        if t == 0:
+            tmotion = torch.zeros_like(smotion)
+        else:
+            tmotion = self.temporal.motions_from_features(self.prev_feat, feat)
+        self.prev_feat = feat
+        # tsmotion of frame t from smotion_{t-1} (frame 0: zero)
+        for v in range(2):
+            if t == 0:
+                smesh = get_rigid_mesh(1, pipeline.LR_H, pipeline.LR_W, device=self.dev) + smotion[v:v + 1]
+                tsm = torch.zeros_like(smesh)
+            else:
+                pair_s = torch.cat((self.prev_smotion[v:v + 1], smotion[v:v + 1]), 0)
+                pair_t = torch.cat((torch.zeros_like(tmotion[v:v + 1]), tmotion[v:v + 1]), 0)
+                sm2, ts2 = ops.tsmotion(pair_s, pair_t, pipeline.LR_H, pipeline.LR_W)
+                smesh, tsm = sm2[1:2], ts2[1:2]
+            self.ring_smesh[v] = (self.ring_smesh[v] + [smesh])[-WINDOW:]
+            self.ring_tsm[v] = (self.ring_tsm[v] + [tsm])[-WINDOW:]
+        self.prev_smotion = smotion
+        self.frames_in += 1
+        if self.hc is None:
+            self.ring_hr.append((hr1, hr2))
+        if self.frames_in < WINDOW:
+            return []
+        # smooth the current window (first tsmotion of the window counts as zero)
+        sm = [torch.cat(self.ring_smesh[v], 0).contiguous() for v in range(2)]
+        ts = [torch.cat(self.ring_tsm[v], 0).contiguous() for v in range(2)]
+        outs, _ = self.smooth.run_windows(sm[0], sm[1], ts[0], ts[1], 1, WINDOW, 1, 1)
+        m1, m2 = outs['smooth_mesh1'][0], outs['smooth_mesh2'][0]                   # [7,7,9,2]
+        if self.hc is None:                                                        # first window: fix the canvas, emit 7
+            if self.bbox is None:
+                bb = ops.mesh_bbox([m1, m2], self.h, self.w).cpu()
+                gw, gh = self.margin * (bb[1] - bb[0]), self.margin * (bb[3] - bb[2])
+                self.bbox = torch.stack((bb[0] - gw, bb[1] + gw, bb[2] - gh, bb[3] + gh)).to(self.dev)
+            self._set_canvas()
+            frames = [self._render(h1, h2, m1[i:i + 1], m2[i:i + 1]) for i, (h1, h2) in enumerate(self.ring_hr)]
+            self.ring_hr = []
+            return frames
+        return [self._render(hr1, hr2, m1[-1:], m2[-1:])]

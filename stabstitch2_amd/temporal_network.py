@@ -53,6 +53,18 @@ class TemporalNet(L.PreparedMixin, nn.Module):
         off = L.run_regressor(cv, p['r2']).view(v, n - 1, grid_h + 1, grid_w + 1, 2)
         return [off[i] for i in range(v)]
 
+    @torch.no_grad()
+    def features(self, frames):
+        """Stage-1 features of a list of [n_i,3,360,480] device tensors -> nhwc [sum n_i,45,60,128] (for callers that
+        keep the previous frame's features, as the reference's loop does at temporal_network.py:144)."""
+        return L.run_stage1(list(frames), self._prepared()['s1'])
+
+    @torch.no_grad()
+    def motions_from_features(self, f_prev, f_cur):
+        """nhwc features of consecutive frames [n,45,60,128] x2 -> mesh motions [n,7,9,2]."""
+        off = L.run_regressor(ops.cost_volume(f_prev, f_cur, 3), self._prepared()['r2'])
+        return off.view(-1, grid_h + 1, grid_w + 1, 2)
+
     def forward(self, img_tensor_list):
         dev = next(self.parameters()).device
         frames = torch.stack([t.to(dev, non_blocking=True).float() for t in img_tensor_list], 0)
