@@ -62,7 +62,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32>
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     constexpr int BM = WGM * WM * 32;
     constexpr int BN = WGN * WN * 32;
@@ -122,10 +122,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         int n = t2 / p.To;
         int ti0 = to - p.pt, hi0 = ho * p.s - p.ph, wi0 = wo * p.s - p.pw;
         a_off[i] = (((n * p.T + ti0) * p.H + hi0) * p.W + wi0) * p.C * 4;     // bytes
-        unsigned msk = 0;
-        for (int d = 0; d < p.kw; ++d) msk |= ((unsigned)(wi0 + d) < (unsigned)p.W ? 1u : 0u) << d;
-        for (int d = 0; d < p.kh; ++d) msk |= ((unsigned)(hi0 + d) < (unsigned)p.H ? 1u : 0u) << (8 + d);
-        for (int d = 0; d < p.kt; ++d) msk |= ((unsigned)(ti0 + d) < (unsigned)p.T ? 1u : 0u) << (16 + d);
+        // valid taps along each axis form one interval [lo, hi): bit mask = (1 << hi) - (1 << lo)
+        auto span = [](int x0, int k, int size) -> unsigned {
+            int lo = max(0, -x0), hi = min(k, size - x0);
+            return hi > lo ? (1u << hi) - (1u << lo) : 0u;
+        };
+        unsigned msk = span(wi0, p.kw, p.W) | (span(hi0, p.kh, p.H) << 8) | (span(ti0, p.kt, p.T) << 16);
         a_msk[i] = ok ? msk : 0u;
     }
     unsigned w_off[RB], w_bad[RB];
@@ -213,14 +215,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         // K tail: with the k = 16h + j permutation chunk c holds k in {4c..4c+3} u {16+4c..}; chunks past the
         // end of K only multiply zeros (e.g. conv1: K = 196 -> the 7th tile needs 1 chunk of 4).  The full tile
         // is a separate, branch-free copy so that the compiler keeps its LDS-read / MFMA software pipeline.
-        const int krem = p.K - kt * BK;
-        if (krem >= BK / 2) {
+        // (TAIL is a template flag, set by the host only when K % BK < BK/2: a runtime branch here makes hipcc keep two
+        //  accumulator copies and shuffle 16 v_accvgpr_mov through every K tile of every layer)
+        if (!TAIL || p.K - kt * BK >= BK / 2) {
             if (p.ablate & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) mma_chunk(buf, c);
             if (p.ablate & 16) __builtin_amdgcn_s_setprio(0);
         } else {
-            const int cmax = (krem + 3) >> 2;
+            const int cmax = (p.K - kt * BK + 3) >> 2;
             for (int c = 0; c < cmax; ++c) mma_chunk(buf, c);
         }
         if (NBUF == 1) __syncthreads();      // single LDS buffer: everyone done reading before it is overwritten
@@ -274,13 +277,13 @@ __global__ void splitk_reduce_kernel(ConvP p) {
     p.out[o] = v;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32>
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false>
 static void launch_conv(const ConvP& p, int groups, hipStream_t st) {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     ConvP q = p;
     q.ntiles = (unsigned)ss_cdiv(p.Co, BN);
     dim3 g((unsigned)ss_cdiv(p.M, BM) * q.ntiles, 1, groups * p.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK>), g, dim3(256), 0, st, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK, TAIL>), g, dim3(256), 0, st, q);
 }
 
 // tuning aids, not part of the public ABI: key 0 = force tile variant, key 1 = ablation mask
@@ -372,7 +375,9 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
             p.splits = ss_cdiv(nk, p.tiles_per_split);
             p.partial = ws;
         }
-        launch_conv<2, 2, 1, 1, 1>(p, groups, st);
+        const int krem = (int)(K % 32);
+        if (krem != 0 && krem < 16) launch_conv<2, 2, 1, 1, 1, 1, 32, true>(p, groups, st);
+        else launch_conv<2, 2, 1, 1, 1>(p, groups, st);
         if (p.splits > 1) {
             long long per = M * cout;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, st, p);
