@@ -17,14 +17,18 @@ static inline int ss_launch_status() {
 
 static inline int ss_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// exact n / d for n < 65536, 1 <= d < 65536:  q = umulhi(n, ceil(2^32 / d)); d == 1 -> mul = 0 (identity)
-static inline uint32_t ss_fastdiv_magic(uint32_t d) {
-    if (d <= 1) return 0u;
-    return (uint32_t)(((1ull << 32) + d - 1) / d);
+// exact n / d for n < 65536, 1 <= d < 65536, branch free:  q = umulhi(n, mul) + (n & mask)
+//   d > 1: mul = ceil(2^32 / d), mask = 0;   d == 1: mul = 0, mask = ~0 (identity)
+struct SsFastDiv {
+    uint32_t mul, mask;
+};
+static inline SsFastDiv ss_fastdiv_make(uint32_t d) {
+    SsFastDiv f;
+    if (d <= 1) { f.mul = 0u; f.mask = 0xFFFFFFFFu; }
+    else { f.mul = (uint32_t)(((1ull << 32) + d - 1) / d); f.mask = 0u; }
+    return f;
 }
-__device__ __forceinline__ uint32_t ss_fastdiv(uint32_t n, uint32_t mul) {
-    return mul ? __umulhi(n, mul) : n;
-}
+__device__ __forceinline__ uint32_t ss_fastdiv(uint32_t n, SsFastDiv f) { return __umulhi(n, f.mul) + (n & f.mask); }
 
 __device__ __forceinline__ float ss_wave_sum(float v) {
 #pragma unroll

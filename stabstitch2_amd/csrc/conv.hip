@@ -43,14 +43,13 @@ struct ConvP {
     int kt, kh, kw, s;
     int pt, ph, pw;
     int K, M;
-    uint32_t mulC, mulKw, mulKh;
+    SsFastDiv divC, divKw, divKh;
     int relu, out_cs;
     int splits, tiles_per_split;
     unsigned ntiles;                 // Cout tiles (grid.x = M tiles * ntiles)
     long long in_gs, w_gs, out_gs;
     unsigned in_bytes, w_bytes;      // per-group extents for the buffer descriptors
-    int ablate;                      // tuning aid (SS_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier,
-                                     // 8 no XCD tile order, 16 s_setprio around the MFMA cluster
+    int ablate;                      // tuning aid (SS_CONV_ABLATE): 8 = row-major tile order instead of XCD-aware
 };
 
 
@@ -142,11 +141,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     auto gload = [&](int kt) {
         int k = kt * BK + kq * 4;
         bool kok = k < p.K;
-        uint32_t tap = ss_fastdiv((uint32_t)k, p.mulC);
+        uint32_t tap = ss_fastdiv((uint32_t)k, p.divC);
         int ci = k - (int)tap * p.C;
-        uint32_t t2 = ss_fastdiv(tap, p.mulKw);
+        uint32_t t2 = ss_fastdiv(tap, p.divKw);
         int dw = (int)tap - (int)t2 * p.kw;
-        uint32_t dt = ss_fastdiv(t2, p.mulKh);
+        uint32_t dt = ss_fastdiv(t2, p.divKh);
         int dh = (int)t2 - (int)dt * p.kh;
         int tapoff = ((((int)dt * p.H + dh) * p.W + dw) * p.C + ci) * 4;     // bytes
         unsigned sw = (unsigned)dw, sh = 8u + (unsigned)dh, st = 16u + dt;
@@ -209,26 +208,30 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         lstore(0);
     }
     __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
+    // main loop: straight-line body (no branches) so that hipcc can interleave the next tile's address arithmetic and
+    // loads with the MFMAs; the last tile is peeled (nothing to prefetch, and only it can be a partial K tile)
+    int kt = kt0;
+    for (; kt + 1 < kt1; ++kt) {
         const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
-        if (kt + 1 < kt1 && !(p.ablate & 1)) gload(kt + 1);
-        // K tail: with the k = 16h + j permutation chunk c holds k in {4c..4c+3} u {16+4c..}; chunks past the
-        // end of K only multiply zeros (e.g. conv1: K = 196 -> the 7th tile needs 1 chunk of 4).  The full tile
-        // is a separate, branch-free copy so that the compiler keeps its LDS-read / MFMA software pipeline.
-        // (TAIL is a template flag, set by the host only when K % BK < BK/2: a runtime branch here makes hipcc keep two
-        //  accumulator copies and shuffle 16 v_accvgpr_mov through every K tile of every layer)
+        gload(kt + 1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) mma_chunk(buf, c);
+        if (NBUF == 1) __syncthreads();      // single LDS buffer: everyone done reading before it is overwritten
+        lstore(NBUF == 2 ? (buf ^ 1) : 0);
+        __syncthreads();
+    }
+    if (kt < kt1) {
+        const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
+        // K tail: with the k = (BK/2)h + j permutation chunk c holds k in {4c..4c+3} u {BK/2+4c..}; chunks past the end
+        // of K only multiply zeros (conv1: K = 196 -> the 7th tile needs 1 chunk of 4).  TAIL is a template flag set
+        // by the host only when K % BK < BK/2.
         if (!TAIL || p.K - kt * BK >= BK / 2) {
-            if (p.ablate & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) mma_chunk(buf, c);
-            if (p.ablate & 16) __builtin_amdgcn_s_setprio(0);
         } else {
             const int cmax = (p.K - kt * BK + 3) >> 2;
             for (int c = 0; c < cmax; ++c) mma_chunk(buf, c);
         }
-        if (NBUF == 1) __syncthreads();      // single LDS buffer: everyone done reading before it is overwritten
-        if (kt + 1 < kt1 && !(p.ablate & 2)) lstore(NBUF == 2 ? (buf ^ 1) : 0);
-        if (!(p.ablate & 4)) __syncthreads();
     }
 
     // epilogue
@@ -321,9 +324,9 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     if (K >= 65536 || M >= (1ll << 31) || in_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31))
         return SS_ERR_UNSUPPORTED;
     p.K = (int)K; p.M = (int)M;
-    p.mulC = ss_fastdiv_magic((uint32_t)cin);
-    p.mulKw = ss_fastdiv_magic((uint32_t)kw);
-    p.mulKh = ss_fastdiv_magic((uint32_t)kh);
+    p.divC = ss_fastdiv_make((uint32_t)cin);
+    p.divKw = ss_fastdiv_make((uint32_t)kw);
+    p.divKh = ss_fastdiv_make((uint32_t)kh);
     p.relu = relu; p.out_cs = out_cs;
     p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
     p.in_bytes = (unsigned)(in_elems * 4);
