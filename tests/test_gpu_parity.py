@@ -354,7 +354,7 @@ def test_three_view_vs_reference(dev, golden):
         # see tests/test_oracle_golden.py::test_g10_three_view for why AVERAGE is only loosely comparable
         # LINEAR: nonzero() centroids count the +-1e-3 out-of-range residues of the masks, so the blend weights move
         # by ~1e-3 between CPUs already (0.12 grey levels oracle-vs-golden across two x86 hosts)
-        tol, cover = (1.5, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
+        tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
         close_boxes(got, g['frames_' + fm.lower()], g['iqr_' + fm.lower()], tol, 'three-view ' + fm, k=4, cover=cover)
     # the fused 3-view kernel must equal the chained formula applied to the generic per-view warp, bit for bit
     from stabstitch2_amd import ops
