@@ -292,9 +292,11 @@ static void launch_conv(const ConvP& p, int groups, hipStream_t st) {
 // tuning aids, not part of the public ABI: key 0 = force tile variant, key 1 = ablation mask
 static int g_force_tile = getenv("SS_CONV_TILE") ? atoi(getenv("SS_CONV_TILE")) : 0;
 static int g_ablate = getenv("SS_CONV_ABLATE") ? atoi(getenv("SS_CONV_ABLATE")) : 0;
+static int g_split_target = 512;    // workgroups a split-K launch aims for (key 2); 512 measured best (tools/ab_splitk.py)
 extern "C" void ss_debug_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     if (key == 1) g_ablate = value;
+    if (key == 2) g_split_target = value;
 }
 
 extern "C" long long ss_conv_workspace_floats(void) { return 16ll << 20; }   // 64 MiB of split-K partials
@@ -366,10 +368,10 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     } else if (best == 4) {
         launch_conv<2, 2, 1, 1, 2>(p, groups, st);
     } else {
-        // default: 64x64 tiles, single LDS buffer; small problems are additionally split along K so that ~1024
+        // default: 64x64 tiles, single LDS buffer; small problems are additionally split along K so that ~512
         // workgroups exist
         long long b64 = (long long)ss_cdiv(M, 64) * ss_cdiv(cout, 64) * groups;
-        int want = (int)((1024 + b64 - 1) / b64);
+        int want = (int)((g_split_target + b64 - 1) / b64);
         int maxs = nk / 4 > 0 ? nk / 4 : 1;
         int splits = want < maxs ? want : maxs;
         long long need = (long long)groups * splits * M * cout;
