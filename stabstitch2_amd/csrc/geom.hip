@@ -287,8 +287,7 @@ __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict_
     int mycol = 0;
     // (measured: letting every wave redo the arg-max to save the broadcast barrier, with all 66 steps unrolled into
     //  one straight-line body, is 1.7x SLOWER -- instruction-cache bound; this form runs 94 us per system)
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
+    for (int qq = 0; qq < 4; ++qq) {         // rolled on purpose (see above); the 17 steps of a quarter are unrolled
 #pragma unroll
         for (int j = 0; j < TPS_TQ; ++j) {
             const int col = qq * TPS_TQ + j;
