@@ -141,6 +141,9 @@ def main():
     ap.add_argument('--cpu-frames', type=int, default=48)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--conv-report', action='store_true')
+    ap.add_argument('--io', default='f32', choices=('f32', 'u8', 'u8host'),
+                    help="f32: fp32 frames resident in HBM (the headline metric); u8: uint8 frames resident, ingest + "
+                         "uint8 sink inside the step; u8host: uint8 frames in pinned host memory, H2D + D2H inside the step")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -176,9 +179,31 @@ def main():
                 last = got[-1]
         return last.unsqueeze(0), st.hc, st.wc
 
+    u8 = None
+    runner = None
+    if args.io != 'f32':
+        assert args.views == 2 and not args.online, '--io u8 covers the offline 2-view path'
+        u8 = [hr[v].permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).contiguous() for v in range(2)]
+        if args.io == 'u8host':
+            u8 = [t.cpu().pin_memory() for t in u8]
+            runner = pipeline.HostClipRunner(nets, dev, args.warp_mode, args.fusion_mode)
+
+    def step_u8():
+        fr, hc_, wc_, _, _ = pipeline.run_two_view_u8(u8[0], u8[1], nets, args.warp_mode, args.fusion_mode, device=dev)
+        return fr, hc_, wc_
+
+    def steps_host(k):
+        """k clips through the overlapped upload / compute / download pipeline; -> last (video, Hc, Wc)."""
+        last = None
+        for last in runner.run((u8[0], u8[1]) for _ in range(k)):
+            pass
+        return last
+
     def step():
         if args.online:
             return step_online()
+        if u8 is not None:
+            return step_u8()
         if args.views == 3:       # BASELINE configs[4]: two 2-view passes (v1,v2),(v2,v3) + three-view composition
             return pipeline.run_three_view(hr[0], hr[1], hr[2], lr[0], lr[1], lr[2], nets, args.warp_mode,
                                            args.fusion_mode)[:3]
@@ -190,13 +215,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
+    if runner is not None:
+        if args.warmup:
+            steps_host(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            out = step()
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        probe.active = (i == args.steps - 1)     # HIP events around every conv launch of the last timed step
-        out = step()
+    if runner is not None:
+        out = steps_host(args.steps)
+    else:
+        for i in range(args.steps):
+            probe.active = (i == args.steps - 1)     # HIP events around every conv launch of the last timed step
+            out = step()
     probe.active = False
     sync()
     dt = time.perf_counter() - t0
@@ -233,7 +265,7 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %dx%d %d-view, %d-frame clip per step per GPU, 7-frame SmoothWarp sliding '
                                'window, warp %s / fusion %s, synthetic checkpoints' % (
-                                   ('streaming (batch 1) ' if args.online else '') +
+                                   ('streaming (batch 1) ' if args.online else '') + ('' if args.io == 'f32' else '[io=%s] ' % args.io) +
                                    ('configs[4]' if args.views == 3 else ('configs[2]' if args.height == 720 else 'configs[1]')),
                                    args.height, args.width, args.views, args.frames, args.warp_mode, args.fusion_mode),
                    'frames_per_step': args.frames, 'canvas': [int(hc), int(wc)], 'parallelism': 'streams%d' % world,

@@ -168,6 +168,21 @@ int ss_smooth_finalize(const float* smesh1, const float* smesh2, const float* ts
 int ss_add_mul(const float* in, float* out, float add, float mul, long long n, void* stream);
 int ss_mask_union(const float* a, const float* b, float* out, long long n, void* stream);
 
+/* ---- frame I/O either side of the path ----------------------------------
+ * ss_ingest_u8 replaces the per-frame host code of test_online_tra.py:252-278: `frames` is DEVICE uint8
+ * [n][h][w][3] (decoded frames as cv2.imread returns them, channel order preserved);
+ *   hr  [n][3][h][w]        = float(frame)                     (NULL to skip)
+ *   lr  [n][3][lr_h][lr_w]  = cv2.resize(frame, (lr_w, lr_h)) / 127.5 - 1.0
+ * with OpenCV 4.5.1's (environment.yml:343) uint8 INTER_LINEAR arithmetic restated bit for bit: 11-bit fixed-point
+ * taps, ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2, the exact-2x2 case routed to INTER_AREA ((a+b+c+d+2)>>2),
+ * equal sizes copied.  Parity of this entry point is UNPINNED against cv2 itself (absent from the image); see
+ * oracle/frame_io.py.
+ * ss_canvas_to_u8 replaces `stable_list[k].astype(np.uint8)` (:413): [n][3][h][w] fp32 -> uint8 [n][h][w][3]
+ * (truncation toward zero, low 8 bits of the int32 value outside 0..255). */
+int ss_ingest_u8(const unsigned char* frames, float* hr, float* lr, int n, int h, int w, int lr_h, int lr_w,
+                 void* stream);
+int ss_canvas_to_u8(const float* canvas, unsigned char* out, int n, int h, int w, void* stream);
+
 /* ---- metric harness (test_metric_ssd.py:444-482, 513-527) -------------------------------------
  * w1, w2: [frames][4][h][w] = 3 colour planes (0..255) + validity-mask plane, as ss_tps_warp_mask_nchw
  * writes them.  out (device, fp64) [frames][2] = alignment PSNR (dB), SSIM of (w1*ov, w2*ov), ov = m1*m2,

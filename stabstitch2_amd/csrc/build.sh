@@ -8,5 +8,6 @@ OUT="$HERE/../libstabstitch_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
     "$HERE/conv.hip" "$HERE/corr.hip" "$HERE/geom.hip" "$HERE/render.hip" "$HERE/smooth.hip" "$HERE/metrics.hip" \
+    "$HERE/frameio.hip" \
     -o "$OUT"
 echo "built $OUT"

@@ -228,6 +228,41 @@ def mask_union(a, b):
     return out
 
 
+def _u8ptr(t):
+    if not t.is_cuda:
+        raise H.HipError('stabstitch2_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
+    if t.dtype != torch.uint8 or not t.is_contiguous():
+        raise H.HipError('expected a contiguous uint8 device tensor (got %s, contiguous=%s)'
+                         % (t.dtype, t.is_contiguous()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ingest_u8(frames, lr_h=360, lr_w=480, want_hr=True, hr_out=None, lr_out=None):
+    """frames uint8 [n,h,w,3] (decoded, cv2 channel order) -> (hr [n,3,h,w] in 0..255 | None,
+    lr [n,3,lr_h,lr_w] = cv2.resize(...)/127.5-1).  Replaces test_online_tra.py:252-278."""
+    n, h, w, c = frames.shape
+    if c != 3:
+        raise ValueError('frames must be [n,h,w,3] uint8')
+    dev = frames.device
+    hr = None
+    if want_hr:
+        hr = hr_out if hr_out is not None else torch.empty((n, 3, h, w), device=dev, dtype=torch.float32)
+    lr = lr_out if lr_out is not None else torch.empty((n, 3, lr_h, lr_w), device=dev, dtype=torch.float32)
+    H.call('ss_ingest_u8', _u8ptr(frames), H.dptr(hr, allow_none=True), H.dptr(lr), n, h, w, lr_h, lr_w, H.stream())
+    return hr, lr
+
+
+def canvas_to_u8(canvas, out=None):
+    """fp32 [n,3,h,w] -> uint8 [n,h,w,3] with `.astype(np.uint8)` semantics (test_online_tra.py:413)."""
+    n, c, h, w = canvas.shape
+    if c != 3:
+        raise ValueError('canvas must be [n,3,h,w]')
+    if out is None:
+        out = torch.empty((n, h, w, 3), device=canvas.device, dtype=torch.uint8)
+    H.call('ss_canvas_to_u8', H.dptr(canvas), _u8ptr(out), n, h, w, H.stream())
+    return out
+
+
 def linear_blend(ref, tgt, ref_m, tgt_m, want_mask=False, out=None):
     """ref,tgt [3,hc,wc]; ref_m,tgt_m [hc,wc] -> fused [3,hc,wc] (or mask1 [hc,wc])."""
     hc, wc = ref_m.shape[-2:]

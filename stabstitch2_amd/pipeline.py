@@ -253,3 +253,113 @@ def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusio
                                      a23['smooth_mesh2'], img_h, img_w)
     frames, hc, wc = three_view_render(hr1, hr2, hr3, m1, mid, m3, warp_mode, fusion_mode)
     return frames, hc, wc, m1, mid, m3
+
+
+# ------------------------------------------------------------------ frame I/O front-end / sink
+@torch.no_grad()
+def load_frames_u8(frames, lr_h=360, lr_w=480, device=None):
+    """test_online_tra.py:250-278 for one view on the device: decoded uint8 frames [N,H,W,3] (ndarray or tensor,
+    cv2 channel order) -> (hr [N,3,H,W] fp32 0..255, lr [N,3,lr_h,lr_w] fp32 in [-1,1] via the cv2-exact resize).
+    Only the uint8 bytes cross PCIe (2.8 MB per 720p frame instead of 11 MB of fp32)."""
+    if not torch.is_tensor(frames):
+        frames = torch.from_numpy(frames)
+    if device is not None:
+        frames = frames.to(device, non_blocking=True)
+    return ops.ingest_u8(frames.contiguous(), lr_h, lr_w)
+
+
+@torch.no_grad()
+def to_video_frames(frames, to_host=False):
+    """`stable_list[k].astype(np.uint8)` (test_online_tra.py:413) for a whole clip on the device:
+    [N,3,Hc,Wc] fp32 -> uint8 [N,Hc,Wc,3] (what cv2.VideoWriter.write consumes); to_host=True returns an ndarray."""
+    u8 = ops.canvas_to_u8(frames.contiguous())
+    return u8.cpu().numpy() if to_host else u8
+
+
+@torch.no_grad()
+def run_two_view_u8(frames1, frames2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', device='cuda', to_host=False):
+    """uint8 in, uint8 out: ingest -> estimate -> render -> video frames.  -> (uint8 [N,Hc,Wc,3], Hc, Wc, m1, m2)."""
+    hr1, lr1 = load_frames_u8(frames1, device=device)
+    hr2, lr2 = load_frames_u8(frames2, device=device)
+    frames, hc, wc, m1, m2 = run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode, fusion_mode)
+    return to_video_frames(frames, to_host), hc, wc, m1, m2
+
+
+class HostClipRunner:
+    """uint8 clips in pinned host memory -> stitched uint8 clips in pinned host memory, with the PCIe copies of
+    neighbouring clips hidden behind the compute of the current one (three HIP streams: upload, compute, download).
+
+        for video, hc, wc in HostClipRunner(nets).run(clips):     # clips yields (frames1, frames2) uint8 [N,H,W,3]
+            writer.write(video[k]) ...
+
+    The upload of clip k+1 is enqueued before the host starts issuing clip k's kernels (whose canvas-size read-back is
+    the path's one host sync), the download of clip k runs while clip k+1 computes.  Yields (ndarray-backed pinned
+    uint8 tensor [N,Hc,Wc,3], Hc, Wc) one clip late at most; a yielded tensor stays valid until `depth` more clips
+    have been yielded."""
+
+    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', depth=2):
+        self.nets, self.dev = nets, torch.device(device)
+        self.warp_mode, self.fusion_mode, self.depth = warp_mode, fusion_mode, depth
+        self.up, self.comp, self.down = (torch.cuda.Stream(self.dev) for _ in range(3))
+        self._host = [dict() for _ in range(depth + 1)]
+
+    def _upload(self, clip):
+        with torch.cuda.stream(self.up):
+            d = [(torch.from_numpy(f) if not torch.is_tensor(f) else f).to(self.dev, non_blocking=True) for f in clip]
+            ev = torch.cuda.Event()
+            ev.record(self.up)
+        return d, ev
+
+    def _compute(self, d, ev):
+        self.comp.wait_event(ev)
+        with torch.cuda.stream(self.comp):
+            for t in d:
+                t.record_stream(self.comp)
+            d = [t if t.is_contiguous() else t.contiguous() for t in d]
+            hr1, lr1 = ops.ingest_u8(d[0])
+            hr2, lr2 = ops.ingest_u8(d[1])
+            frames, hc, wc, _, _ = run_two_view(hr1, hr2, lr1, lr2, self.nets, self.warp_mode, self.fusion_mode)
+            u8 = ops.canvas_to_u8(frames)
+            ev2 = torch.cuda.Event()
+            ev2.record(self.comp)
+        return u8, hc, wc, ev2
+
+    def _download(self, k, u8, ev):
+        key = tuple(u8.shape)
+        if key not in self._host[0]:         # new canvas size: pin every slot now, not one clip at a time
+            for s_ in self._host:
+                s_.clear()
+                s_[key] = torch.empty(key, dtype=torch.uint8).pin_memory()
+        slot = self._host[k % (self.depth + 1)]
+        self.down.wait_event(ev)
+        with torch.cuda.stream(self.down):
+            u8.record_stream(self.down)
+            slot[key].copy_(u8, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.down)
+        return slot[key], done
+
+    @torch.no_grad()
+    def run(self, clips):
+        it = iter(clips)
+        try:
+            nxt = self._upload(next(it))
+        except StopIteration:
+            return
+        pending = None
+        k = 0
+        while nxt is not None:
+            cur = nxt
+            try:
+                nxt = self._upload(next(it))
+            except StopIteration:
+                nxt = None
+            u8, hc, wc, ev = self._compute(*cur)
+            host, done = self._download(k, u8, ev)
+            if pending is not None:
+                pending[3].synchronize()
+                yield pending[0], pending[1], pending[2]
+            pending = (host, hc, wc, done)
+            k += 1
+        pending[3].synchronize()
+        yield pending[0], pending[1], pending[2]

@@ -484,3 +484,86 @@ def test_online_matches_offline(dev, hip_nets, clip16):
     for t in range(9):
         outs += st2.push(hrd[0][t], hrd[1][t], lrd[0][t], lrd[1][t])
     assert len(outs) == 9 and all(bool(torch.isfinite(f).all()) for f in outs) and st2.hc >= hc and st2.wc >= wc
+
+
+# ------------------------------------------------------------------ frame I/O
+@pytest.mark.parametrize('h,w,lr_h,lr_w', [
+    (720, 1280, 360, 480),      # the benchmark size: general fixed-point linear path
+    (720, 960, 360, 480),       # exact 2x2 -> OpenCV routes INTER_LINEAR to the fast area average
+    (360, 480, 360, 480),       # StabStitch-D native size: copy
+    (101, 203, 360, 480),       # upscale, width not a multiple of 4 (scalar HR path, clamped taps both ends)
+    (1080, 1920, 360, 480),     # 3x / 4x decimation
+    (37, 52, 20, 31),
+])
+def test_ingest_u8_bit_exact(dev, h, w, lr_h, lr_w):
+    """ss_ingest_u8 == the numpy restatement of cv2.imread->float / cv2.resize->/127.5-1 (test_online_tra.py:252-264),
+    bit for bit, including extreme-valued and constant frames."""
+    from oracle import frame_io as FIO
+    from stabstitch2_amd import ops
+    rng = np.random.RandomState(h * 7 + w)
+    frames = rng.randint(0, 256, (3, h, w, 3)).astype(np.uint8)
+    frames[1] = 255
+    frames[2, ::2] = 0
+    hr, lr = ops.ingest_u8(torch.from_numpy(frames).to(dev), lr_h, lr_w)
+    for i in range(3):
+        rh, rl = FIO.load_frame(frames[i], lr_h, lr_w)
+        assert np.array_equal(hr[i].cpu().numpy(), rh), 'hr planes differ'
+        got = lr[i].cpu().numpy()
+        assert np.array_equal(got, rl), ('lr differs', float(np.abs(got - rl).max()) * 127.5)
+    _, lr_only = ops.ingest_u8(torch.from_numpy(frames).to(dev), lr_h, lr_w, want_hr=False)
+    assert torch.equal(lr_only, lr)
+
+
+def test_canvas_to_u8_bit_exact(dev):
+    """ss_canvas_to_u8 == `.astype(np.uint8)` of the HWC canvas (test_online_tra.py:413), aligned and ragged sizes."""
+    from oracle import frame_io as FIO
+    from stabstitch2_amd import ops
+    rng = np.random.RandomState(3)
+    for (h, w) in ((64, 128), (37, 53), (1, 1), (730, 1414)):
+        x = (rng.rand(2, 3, h, w) * 256).astype(np.float32)
+        x[0, :, 0, 0] = [255.99998, 0.0, 254.99998]
+        if h > 1:
+            x[1, :, -1, -1] = [-0.5, 256.0, -3.7]          # outside 0..255: low byte of the truncated int32
+        got = ops.canvas_to_u8(torch.from_numpy(x).to(dev)).cpu().numpy()
+        for i in range(2):
+            assert np.array_equal(got[i], FIO.to_video_frame(x[i])), (h, w)
+
+
+def test_u8_pipeline_matches_float_pipeline(dev, hip_nets):
+    """uint8 in -> uint8 out equals the fp32 path fed with the oracle-loaded frames, truncated: the front-end and
+    the sink add no arithmetic of their own."""
+    from oracle import frame_io as FIO
+    from stabstitch2_amd import pipeline
+    clip = synth.make_clip(9, 540, 720, seed=5)
+    u8 = [np.stack([np.clip(np.rint(f[0].numpy().transpose(1, 2, 0)), 0, 255).astype(np.uint8) for f in v])
+          for v in clip[0]]
+    out, hc, wc, m1, m2 = pipeline.run_two_view_u8(u8[0], u8[1], hip_nets, device=dev)
+    loaded = [[FIO.load_frame(f) for f in v] for v in u8]
+    hr = [torch.from_numpy(np.stack([a for a, _ in v])).to(dev) for v in loaded]
+    lr = [torch.from_numpy(np.stack([b for _, b in v])).to(dev) for v in loaded]
+    ref, hc2, wc2, r1, r2 = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets)
+    assert (hc, wc) == (hc2, wc2) and torch.equal(m1, r1) and torch.equal(m2, r2)
+    want = np.stack([FIO.to_video_frame(f) for f in ref.cpu().numpy()])
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (9, hc, wc, 3)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_host_clip_runner_overlapped_copies(dev, hip_nets):
+    """The three-stream host pipeline (upload / compute / download overlapped) returns, clip for clip, exactly what
+    the synchronous uint8 path returns."""
+    from stabstitch2_amd import pipeline
+    clips = []
+    for seed in (1, 2, 3):
+        c = synth.make_clip(8, 360, 480, seed=seed)
+        clips.append(tuple(np.stack([np.clip(np.rint(f[0].numpy().transpose(1, 2, 0)), 0, 255).astype(np.uint8)
+                                     for f in v]) for v in c[0]))
+    want = [pipeline.run_two_view_u8(a, b, hip_nets, device=dev, to_host=True) for a, b in clips]
+    runner = pipeline.HostClipRunner(hip_nets, dev)
+    got = []
+    for video, hc, wc in runner.run((torch.from_numpy(a).pin_memory(), torch.from_numpy(b).pin_memory())
+                                    for a, b in clips):
+        got.append((video.numpy().copy(), hc, wc))
+    assert len(got) == 3
+    for (v, hc, wc), (w, hc2, wc2, _, _) in zip(got, want):
+        assert (hc, wc) == (hc2, wc2) and np.array_equal(v, w)
+    assert list(runner.run(iter(()))) == []

@@ -240,3 +240,43 @@ def test_g11_psnr_ssim(golden):
     a, b = cases.g11_images()
     assert abs(M.psnr(a, b) - float(g['psnr'])) < 1e-6
     assert abs(M.ssim(a, b) - float(g['ssim'])) < 1e-6
+
+
+# ------------------------------------------------------------------ frame I/O restatement (parity unpinned vs cv2)
+def test_frame_io_resize_properties():
+    """cv2 is absent from the image, so the OpenCV 4.5.1 INTER_LINEAR restatement is held to hand-worked vectors and
+    to the properties the fixed-point algorithm guarantees (oracle/frame_io.py header)."""
+    from oracle import frame_io as FIO
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    # same size: copy; exact 2x2: (a+b+c+d+2)>>2
+    assert np.array_equal(FIO.cv2_resize_linear_u8(img, (64, 48)), img)
+    half = FIO.cv2_resize_linear_u8(img, (32, 24))
+    s = img.astype(np.int32)
+    assert np.array_equal(half, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2))
+    # hand-worked: row [0,100,200,255] -> width 2: taps (1024,1024): ((2048*((100*1024)>>4))>>16 + 2)>>2 = 50, 228
+    row = np.array([0, 100, 200, 255], np.uint8)[None, :, None].repeat(3, 2)
+    assert FIO.cv2_resize_linear_u8(row, (2, 1))[0, :, 0].tolist() == [50, 228]
+    # x taps at 1280 -> 480 (scale 8/3): dx=0 -> fx=5/6 at sx=0: weights round(2048/6)=341, round(2048*5/6)=1707
+    xo, a0, a1 = FIO.linear_tables(1280, 480)
+    assert (xo[0], a0[0], a1[0]) == (0, 341, 1707) and (xo[1], a0[1], a1[1]) == (3, 1024, 1024)
+    assert (a0 + a1 == 2048).all() and xo.max() <= 1279
+    # constants are preserved, results stay within 1 LSB of real-valued half-pixel-centre bilinear
+    for (dw, dh) in ((48, 36), (100, 70), (31, 17)):
+        const = np.full((48, 64, 3), 201, np.uint8)
+        assert (FIO.cv2_resize_linear_u8(const, (dw, dh)) == 201).all()
+        got = FIO.cv2_resize_linear_u8(img, (dw, dh)).astype(np.float64)
+        fx = np.clip((np.arange(dw) + 0.5) * 64 / dw - 0.5, 0, 63)
+        fy = np.clip((np.arange(dh) + 0.5) * 48 / dh - 0.5, 0, 47)
+        x0 = np.floor(fx).astype(int); x1 = np.minimum(x0 + 1, 63); ax = fx - x0
+        y0 = np.floor(fy).astype(int); y1 = np.minimum(y0 + 1, 47); ay = fy - y0
+        f = img.astype(np.float64)
+        top = f[y0][:, x0] * (1 - ax)[None, :, None] + f[y0][:, x1] * ax[None, :, None]
+        bot = f[y1][:, x0] * (1 - ax)[None, :, None] + f[y1][:, x1] * ax[None, :, None]
+        real = top * (1 - ay)[:, None, None] + bot * ay[:, None, None]
+        assert np.abs(got - real).max() <= 1.0, (dw, dh, np.abs(got - real).max())
+    hr, lr = FIO.load_frame(img, 36, 48)
+    assert hr.shape == (3, 48, 64) and lr.shape == (3, 36, 48) and lr.dtype == np.float32
+    assert hr[1, 5, 7] == img[5, 7, 1] and -1.0 <= lr.min() and lr.max() <= 1.0
+    vid = FIO.to_video_frame(np.array([[[255.99998, -0.5]], [[0.999, 256.0]], [[17.5, -3.7]]], np.float32))
+    assert vid.shape == (1, 2, 3) and vid[0, 0].tolist() == [255, 0, 17] and vid[0, 1].tolist() == [0, 0, 253]
