@@ -49,6 +49,7 @@ struct ConvP {
     unsigned ntiles;                 // Cout tiles (grid.x = M tiles * ntiles)
     long long in_gs, w_gs, out_gs;
     unsigned in_bytes, w_bytes;      // per-group extents for the buffer descriptors
+    unsigned long long* dbg;         // tuning aid (ss_debug_ptr): per-workgroup phase timestamps, or nullptr
     int ablate;                      // tuning aid (SS_CONV_ABLATE): 8 = row-major tile order instead of XCD-aware
 };
 
@@ -61,7 +62,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false>
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false, int SCHED = 0,
+          int AMODE = 0>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     constexpr int BM = WGM * WM * 32;
     constexpr int BN = WGN * WN * 32;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     constexpr int NCH = BK / 8;          // 4-wide operand chunks per lane half
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
+    extern __shared__ __attribute__((aligned(16))) uint2 tap_tab[];   // AMODE > 0: one entry per 4 k of this block's K range
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -92,6 +95,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         mt = (int)(lin / p.ntiles);
         nt = (int)(lin - (unsigned)mt * p.ntiles);
     }
+    // Waves outside the K loop (row setup, epilogue) issue only VALU / memory instructions; beside 6 waves that keep the
+    // MFMA pipe busy they would get one issue slot per 64-cycle MFMA and take longer than the K loop itself (measured:
+    // 31k + 44k cycles around a 75k-cycle loop).  Raised priority lets them through.
+    if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(3);
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int grp = blockIdx.z / p.splits;
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 
     // per-thread row bookkeeping (fixed over the K loop): byte offset of tap (0,0,0) and validity masks
     int a_off[RA];
+    unsigned a_inv_lo[RA], a_inv_hi[RA];
     unsigned a_msk[RA];          // bits 0..7: valid dw, 8..15: valid dh, 16..23: valid dt (0 for rows >= M)
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -128,6 +138,19 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         };
         unsigned msk = span(wi0, p.kw, p.W) | (span(hi0, p.kh, p.H) << 8) | (span(ti0, p.kt, p.T) << 16);
         a_msk[i] = ok ? msk : 0u;
+        if (AMODE > 0) {
+            // table mode: one bit per filter tap (index (dt*kh + dh)*kw + dw < 64), SET where the tap falls outside the
+            // input (or the row is past M)
+            unsigned long long valid = 0ull;
+            if (ok) {
+                const unsigned long long mw = msk & 0xFFu;
+                for (int dt = 0; dt < p.kt; ++dt)
+                    for (int dh = 0; dh < p.kh; ++dh)
+                        if ((msk >> (8 + dh)) & (msk >> (16 + dt)) & 1u) valid |= mw << ((dt * p.kh + dh) * p.kw);
+            }
+            a_inv_lo[i] = ~(unsigned)valid;
+            a_inv_hi[i] = ~(unsigned)(valid >> 32);
+        }
     }
     unsigned w_off[RB], w_bad[RB];
 #pragma unroll
@@ -137,8 +160,51 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         w_bad[i] = co < p.Co ? 0u : 0xFFFFFFFFu;
     }
 
+    const int nk_all = (p.K + BK - 1) / BK;   // == host-side nk for this BK
+    const int kt0 = split * p.tiles_per_split;
+    const int kt1 = min(nk_all, kt0 + p.tiles_per_split);
+
+    if (AMODE > 0) {
+        // per-block tap table: entry e describes k = kt0*BK + 4e: {byte offset of the tap relative to tap (0,0,0),
+        // tap bit index | 64 for k >= K}.  Replaces three divisions per K tile per thread by one ds_read_b64.
+        const int tab_n = (kt1 - kt0) * TPR;
+        for (int e = tid; e < tab_n; e += 256) {
+            int k = kt0 * BK + e * 4;
+            uint32_t tap = ss_fastdiv((uint32_t)k, p.divC);
+            int ci = k - (int)tap * p.C;
+            uint32_t t2 = ss_fastdiv(tap, p.divKw);
+            int dw = (int)tap - (int)t2 * p.kw;
+            uint32_t dt = ss_fastdiv(t2, p.divKh);
+            int dh = (int)t2 - (int)dt * p.kh;
+            int tapoff = ((((int)dt * p.H + dh) * p.W + dw) * p.C + ci) * 4;
+            tap_tab[e] = k < p.K ? make_uint2((unsigned)tapoff, tap) : make_uint2(0u, 64u);
+        }
+        __syncthreads();
+    }
+    unsigned wk[RB];             // table mode: running byte offset of each filter row's next K tile
+#pragma unroll
+    for (int i = 0; i < RB; ++i) wk[i] = w_off[i] + (unsigned)(kt0 * BK + kq * 4) * 4u;
+
     u32x4 ra[RA], rb[RB];
-    auto gload = [&](int kt) {
+    unsigned oa[RA], ob[RB];     // byte offsets of the next tile's loads (0xFFFFFFFF = out of range -> zeros)
+    auto gaddr = [&](int kt) {
+        if (AMODE > 0) {
+            const uint2 e = tap_tab[(kt - kt0) * TPR + kq];
+            const unsigned kinv = (unsigned)__builtin_amdgcn_sbfe((int)e.y, 6u, 1u);      // all ones for k >= K
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                unsigned word = a_inv_lo[i];
+                if (AMODE == 2) word = (e.y & 32u) ? a_inv_hi[i] : word;
+                const unsigned inv = (unsigned)__builtin_amdgcn_sbfe((int)word, e.y, 1u);   // v_bfe_i32 uses idx[4:0]
+                oa[i] = ((unsigned)a_off[i] + e.x) | inv | kinv;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                ob[i] = wk[i] | w_bad[i] | kinv;
+                wk[i] += BK * 4u;
+            }
+            return;
+        }
         int k = kt * BK + kq * 4;
         bool kok = k < p.K;
         uint32_t tap = ss_fastdiv((uint32_t)k, p.divC);
@@ -155,14 +221,20 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         for (int i = 0; i < RA; ++i) {
             unsigned m = a_msk[i];
             unsigned v = (m >> sw) & (m >> sh) & (m >> st) & 1u;
-            unsigned off = ((unsigned)(a_off[i] + tapoff)) | (v - 1u) | kmask;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+            oa[i] = ((unsigned)(a_off[i] + tapoff)) | (v - 1u) | kmask;
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            unsigned off = (w_off[i] + (unsigned)k * 4u) | w_bad[i] | kmask;
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
-        }
+        for (int i = 0; i < RB; ++i) ob[i] = (w_off[i] + (unsigned)k * 4u) | w_bad[i] | kmask;
+    };
+    auto gissue = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, oa[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, ob[i], 0, 0);
+    };
+    auto gload = [&](int kt) {
+        gaddr(kt);
+        gissue();
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -181,9 +253,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk_all = (p.K + BK - 1) / BK;   // == host-side nk for this BK
-    const int kt0 = split * p.tiles_per_split;
-    const int kt1 = min(nk_all, kt0 + p.tiles_per_split);
     const int li = lane & 31, lh = lane >> 5;
     const int aidx = (wr * WM * 32 + li) * LDK + lh * (BK / 2);
     const int bidx = (wc * WN * 32 + li) * LDK + lh * (BK / 2);
@@ -208,12 +277,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         lstore(0);
     }
     __syncthreads();
+    if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
+    if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(0);
     // main loop: straight-line body (no branches) so that hipcc can interleave the next tile's address arithmetic and
     // loads with the MFMAs; the last tile is peeled (nothing to prefetch, and only it can be a partial K tile)
     int kt = kt0;
     for (; kt + 1 < kt1; ++kt) {
         const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
         gload(kt + 1);
+        if (SCHED == 1) __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the MFMAs
 #pragma unroll
         for (int c = 0; c < NCH; ++c) mma_chunk(buf, c);
         if (NBUF == 1) __syncthreads();      // single LDS buffer: everyone done reading before it is overwritten
@@ -234,31 +306,52 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         }
     }
 
-    // epilogue
+    if (p.dbg) ts2 = __builtin_amdgcn_s_memtime();
+    if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(3);
+    // epilogue: bias (folded BatchNorm), residual, ReLU.  Branch free and without waits between the 16 rows a lane
+    // owns: offsets of rows past M / channels past Cout are forced out of range (buffer loads return 0, stores are
+    // dropped), all residual loads are issued before the first use and all stores after the last.  (The first
+    // version tested `m < M` per row and the compiler serialised load -> wait -> store 16 times: 44k cycles per
+    // workgroup beside a 75k-cycle K loop.)
     const bool direct = p.splits == 1;
     float* __restrict__ out = direct ? p.out + (long long)grp * p.out_gs
                                      : p.partial + (long long)blockIdx.z * p.M * p.Co;
     const float* __restrict__ res = (direct && p.res) ? p.res + (long long)grp * p.out_gs : nullptr;
     const int ocs = direct ? p.out_cs : p.Co;
+    const unsigned obytes = (unsigned)p.M * (unsigned)ocs * 4u;      // < 2^32 checked by the host
+    const __amdgpu_buffer_rsrc_t rout = uniform_rsrc(out, obytes);
+    const __amdgpu_buffer_rsrc_t rres = uniform_rsrc(res ? res : out, obytes);
 #pragma unroll
     for (int y = 0; y < WN; ++y) {
-        int co = n0 + (wc * WN + y) * 32 + li;
-        if (co >= p.Co) continue;
-        float bias = (direct && p.bias) ? p.bias[co] : 0.f;
+        const int co = n0 + (wc * WN + y) * 32 + li;
+        const bool cok = co < p.Co;
+        const float bias = (direct && p.bias && cok) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int x = 0; x < WM; ++x) {
+            unsigned off[16];
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m0 + (wr * WM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M) {
-                    long long o = (long long)m * ocs + co;
-                    float v = acc[x][y][r] + bias;
-                    if (res) v += res[o];
-                    if (direct && p.relu) v = fmaxf(v, 0.f);
-                    out[o] = v;
-                }
+                const int m = m0 + (wr * WM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                off[r] = (m < p.M && cok) ? ((unsigned)m * (unsigned)ocs + (unsigned)co) * 4u : 0xFFFFFFFFu;
+            }
+            if (res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, off[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[x][y][r] + bias;
+                if (res) v += rv[r];
+                if (direct && p.relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off[r], 0, 0);
             }
         }
+    }
+    if (p.dbg && tid == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 5;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
 }
 
@@ -280,23 +373,49 @@ __global__ void splitk_reduce_kernel(ConvP p) {
     p.out[o] = v;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false>
-static void launch_conv(const ConvP& p, int groups, hipStream_t st) {
+template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false, int SCHED = 0,
+          int AMODE = 0>
+static void launch_conv(const ConvP& p, int groups, hipStream_t st, unsigned dyn_lds = 0) {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     ConvP q = p;
     q.ntiles = (unsigned)ss_cdiv(p.Co, BN);
     dim3 g((unsigned)ss_cdiv(p.M, BM) * q.ntiles, 1, groups * p.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK, TAIL>), g, dim3(256), 0, st, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK, TAIL, SCHED, AMODE>), g, dim3(256), dyn_lds,
+                       st, q);
+}
+
+static int g_amode_off = 0;         // ss_debug_set key 3: 1 = arithmetic addressing instead of the LDS tap table
+
+// Address mode: per-block tap table in LDS (8 bytes per 4 k of the block's K range) when the filter has <= 64 taps
+// and the table stays small; otherwise the arithmetic path (three divisions per K tile per thread).  `tail` selects
+// the variant whose peeled last K tile may be shorter than BK/2 (only instantiated for the default tile).
+template <int WGM, int WGN, int WM, int WN, int NBUF, int BK = 32, int SCHED = 0>
+static void launch_auto(const ConvP& p, int groups, hipStream_t st, int taps, bool tail) {
+    const unsigned tab_bytes = (unsigned)p.tiles_per_split * (unsigned)(BK / 4) * 8u;
+    const int amode = (g_amode_off || taps > 64 || tab_bytes > 24576u) ? 0 : (taps <= 32 ? 1 : 2);
+    constexpr bool DEF = WGM == 2 && WGN == 2 && WM == 1 && WN == 1 && NBUF == 1 && BK == 32 && SCHED == 1;
+    if (DEF && tail) {
+        if (amode == 1) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 1>(p, groups, st, tab_bytes);
+        else if (amode == 2) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 2>(p, groups, st, tab_bytes);
+        else launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 0>(p, groups, st);
+    } else {
+        if (amode == 1) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 1>(p, groups, st, tab_bytes);
+        else if (amode == 2) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 2>(p, groups, st, tab_bytes);
+        else launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 0>(p, groups, st);
+    }
 }
 
 // tuning aids, not part of the public ABI: key 0 = force tile variant, key 1 = ablation mask
 static int g_force_tile = getenv("SS_CONV_TILE") ? atoi(getenv("SS_CONV_TILE")) : 0;
 static int g_ablate = getenv("SS_CONV_ABLATE") ? atoi(getenv("SS_CONV_ABLATE")) : 0;
 static int g_split_target = 512;    // workgroups a split-K launch aims for (key 2); 512 measured best (tools/ab_splitk.py)
+static unsigned long long* g_dbg = nullptr;
+extern "C" void ss_debug_ptr(void* ptr) { g_dbg = (unsigned long long*)ptr; }
 extern "C" void ss_debug_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     if (key == 1) g_ablate = value;
     if (key == 2) g_split_target = value;
+    if (key == 3) g_amode_off = value;
 }
 
 extern "C" long long ss_conv_workspace_floats(void) { return 16ll << 20; }   // 64 MiB of split-K partials
@@ -323,7 +442,8 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     long long w_elems = (long long)cout * K;
     // 32-bit byte offsets inside one group (buffer addressing); padded halo offsets may be negative but a
     // valid tap always lands inside [0, in_elems)
-    if (K >= 65536 || M >= (1ll << 31) || in_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31))
+    if (K >= 65536 || M >= (1ll << 31) || in_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31) ||
+        M * (long long)(out_cs > cout ? out_cs : cout) * 4 >= (1ll << 32))
         return SS_ERR_UNSUPPORTED;
     p.K = (int)K; p.M = (int)M;
     p.divC = ss_fastdiv_make((uint32_t)cin);
@@ -338,6 +458,7 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     p.splits = 1;
     p.tiles_per_split = nk;
     p.ablate = g_ablate;
+    p.dbg = g_dbg;
 
     // Tile choice.  Measured on MI355X (tools/ab_conv.py, interleaved A/B on the layer shapes of the pipeline): the
     // 64x64 tile with ONE 18 KB LDS buffer (5-6 resident workgroups per CU, i.e. 5-6 waves per SIMD feeding each
@@ -347,26 +468,19 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     int best = 6;
     const int force = g_force_tile;   // tuning aid only (ss_debug_set / SS_CONV_TILE)
     if (force) best = force;
-    if (best == 1) {
-        launch_conv<2, 2, 2, 2, 2>(p, groups, st);
-    } else if (best == 2) {
-        launch_conv<4, 1, 2, 2, 1>(p, groups, st);
+    const int taps = kt * kh * kw;
+    const bool tail = (K % 32) != 0 && (K % 32) < 16;
+    if (best == 2) {
+        launch_auto<4, 1, 2, 2, 1>(p, groups, st, taps, false);
     } else if (best == 5) {
-        launch_conv<2, 2, 2, 2, 1>(p, groups, st);
+        launch_auto<2, 2, 2, 2, 1>(p, groups, st, taps, false);
     } else if (best == 10) {
-        ConvP q = p;
-        q.tiles_per_split = ss_cdiv(K, 64);
-        launch_conv<2, 2, 1, 1, 1, 1, 64>(q, groups, st);
-    } else if (best == 8) {
-        launch_conv<2, 2, 1, 1, 1, 8>(p, groups, st);
-    } else if (best == 9) {
-        launch_conv<2, 2, 1, 1, 1, 6>(p, groups, st);
+        p.tiles_per_split = ss_cdiv(K, 64);
+        launch_auto<2, 2, 1, 1, 1, 64>(p, groups, st, taps, false);
     } else if (best == 7) {
-        launch_conv<2, 2, 2, 1, 1>(p, groups, st);
+        launch_auto<2, 2, 2, 1, 1>(p, groups, st, taps, false);
     } else if (best == 3) {
-        launch_conv<2, 2, 2, 1, 2>(p, groups, st);
-    } else if (best == 4) {
-        launch_conv<2, 2, 1, 1, 2>(p, groups, st);
+        launch_auto<2, 2, 1, 2, 1>(p, groups, st, taps, false);
     } else {
         // default: 64x64 tiles, single LDS buffer; small problems are additionally split along K so that ~512
         // workgroups exist
@@ -380,9 +494,9 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
             p.splits = ss_cdiv(nk, p.tiles_per_split);
             p.partial = ws;
         }
-        const int krem = (int)(K % 32);
-        if (krem != 0 && krem < 16) launch_conv<2, 2, 1, 1, 1, 1, 32, true>(p, groups, st);
-        else launch_conv<2, 2, 1, 1, 1>(p, groups, st);
+        if (best == 11) launch_auto<2, 2, 1, 1, 1, 32, 0>(p, groups, st, taps, false);
+        else if (best == 4) launch_auto<2, 2, 1, 1, 2>(p, groups, st, taps, false);
+        else launch_auto<2, 2, 1, 1, 1, 32, 1>(p, groups, st, taps, tail);   // loads pinned ahead of the MFMAs: +2-3 %
         if (p.splits > 1) {
             long long per = M * cout;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, st, p);

@@ -1,0 +1,50 @@
+// Micro-benchmark: what does the fp32 MFMA pipe of gfx950 sustain?  Pure v_mfma_f32_32x32x2_f32 loops, NACC
+// independent accumulators per wave, W waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 mfma_peak.hip -o mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float a0, float b0) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-9f, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16 / NACC; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int NACC>
+void run(int wps, float* d) {
+    int iters = 4000;
+    dim3 grid(256 * wps), block(256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_loop<NACC>, grid, block, 0, 0, d, 100, 1.f, 1.f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(mfma_loop<NACC>, grid, block, 0, 0, d, iters, 1.f, 1.f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)grid.x * 4 * iters * 16 * 4096.0;
+    printf("NACC=%d waves/SIMD=%d: %.3f ms  %.1f TFLOP/s\n", NACC, wps, ms, flops / ms / 1e9);
+}
+
+int main() {
+    float* d; hipMalloc(&d, 4096);
+    for (int wps : {1, 2, 4, 8}) { run<1>(wps, d); run<2>(wps, d); run<4>(wps, d); }
+    return 0;
+}

@@ -1,0 +1,57 @@
+// Micro-benchmark: do VALU instructions issue in the shadow of fp32 MFMAs on gfx950?
+// Each iteration: 16 dependent MFMAs, with NV extra integer VALU ops after each (KIND 0: v_add/xor full rate,
+// KIND 1: v_mul_lo_u32 quarter rate).  Build: hipcc --offload-arch=gfx950 -O3 mfma_valu.hip -o mfma_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NV, int KIND>
+__global__ __launch_bounds__(256) void k(float* out, int iters, float a0, unsigned seed) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-9f, b = a0;
+    unsigned x[4] = {seed + threadIdx.x, seed * 3 + 1, seed * 5 + 2, seed * 7 + 3};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (KIND == 0) x[v & 3] = (x[v & 3] + 0x9E3779B9u) ^ x[(v + 1) & 3];
+                else x[v & 3] = x[v & 3] * 0x9E3779B1u + 1u;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    unsigned xs = x[0] ^ x[1] ^ x[2] ^ x[3];
+    if (s == 12345.678f || xs == 0x12345u) out[threadIdx.x] = s + xs;
+}
+
+template <int NV, int KIND>
+void run(int wps, float* d) {
+    int iters = 2000;
+    dim3 grid(256 * wps), block(256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<NV, KIND>), grid, block, 0, 0, d, 50, 1.f, 1u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<NV, KIND>), grid, block, 0, 0, d, iters, 1.f, 1u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)grid.x * 4 * iters * 16 * 4096.0;
+    printf("kind=%d NV=%2d waves/SIMD=%d: %.3f ms  %.1f TFLOP/s\n", KIND, NV, wps, ms, flops / ms / 1e9);
+}
+
+int main() {
+    float* d; hipMalloc(&d, 4096);
+    for (int wps : {1, 2, 6}) {
+        run<0, 0>(wps, d); run<2, 0>(wps, d); run<4, 0>(wps, d); run<8, 0>(wps, d); run<12, 0>(wps, d); run<16, 0>(wps, d);
+        run<1, 1>(wps, d); run<2, 1>(wps, d); run<4, 1>(wps, d);
+    }
+    return 0;
+}
