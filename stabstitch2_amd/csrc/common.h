@@ -30,6 +30,24 @@ static inline SsFastDiv ss_fastdiv_make(uint32_t d) {
 }
 __device__ __forceinline__ uint32_t ss_fastdiv(uint32_t n, SsFastDiv f) { return __umulhi(n, f.mul) + (n & f.mask); }
 
+// exact n / d for every 32-bit n (Granlund-Montgomery round-up method): t = umulhi(n, mul); q = (t + ((n - t) >> sh1)) >> sh2
+struct SsDiv32 {
+    uint32_t mul, sh1, sh2;
+};
+static inline SsDiv32 ss_div32_make(uint32_t d) {
+    SsDiv32 f;
+    if (d <= 1) { f.mul = 0u; f.sh1 = 0u; f.sh2 = 0u; return f; }
+    const uint32_t l = 32u - (uint32_t)__builtin_clz(d - 1u);          // ceil(log2 d)
+    f.mul = (uint32_t)(((((1ull << l) - d) << 32) / d) + 1ull);
+    f.sh1 = 1u;
+    f.sh2 = l - 1u;
+    return f;
+}
+__device__ __forceinline__ uint32_t ss_div32(uint32_t n, SsDiv32 f) {
+    const uint32_t t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 __device__ __forceinline__ float ss_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -44,6 +44,8 @@ struct ConvP {
     int pt, ph, pw;
     int K, M;
     SsFastDiv divC, divKw, divKh;
+    SsDiv32 divWo, divHo, divTo;     // output-row decomposition m -> (n, to, ho, wo)
+    SsDiv32 divNt, divSplits;        // workgroup index decomposition (wave-uniform: scalar multiplies)
     int relu, out_cs;
     int splits, tiles_per_split;
     unsigned ntiles;                 // Cout tiles (grid.x = M tiles * ntiles)
@@ -92,18 +94,18 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
             const unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
             lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-        mt = (int)(lin / p.ntiles);
+        mt = (int)ss_div32(lin, p.divNt);
         nt = (int)(lin - (unsigned)mt * p.ntiles);
     }
     // Waves outside the K loop (row setup, epilogue) issue only VALU / memory instructions; beside 6 waves that keep the
     // MFMA pipe busy they would get one issue slot per 64-cycle MFMA and take longer than the K loop itself (measured:
     // 31k + 44k cycles around a 75k-cycle loop).  Raised priority lets them through.
     if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(3);
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsa = 0, tsb = 0, tsc = 0;
     if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
     const int m0 = mt * BM;
     const int n0 = nt * BN;
-    const int grp = blockIdx.z / p.splits;
+    const int grp = (int)ss_div32(blockIdx.z, p.divSplits);
     const int split = blockIdx.z - grp * p.splits;
 
     // descriptor inputs through readfirstlane so that the compiler can prove the SRD wave-uniform (otherwise
@@ -114,44 +116,55 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     const int lrow = tid / TPR;
     const int kq = tid % TPR;    // which float4 of the BK-wide K tile
 
-    // per-thread row bookkeeping (fixed over the K loop): byte offset of tap (0,0,0) and validity masks
-    int a_off[RA];
-    unsigned a_inv_lo[RA], a_inv_hi[RA];
-    unsigned a_msk[RA];          // bits 0..7: valid dw, 8..15: valid dh, 16..23: valid dt (0 for rows >= M)
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        int m = m0 + lrow + i * RPP;
-        bool ok = m < p.M;
-        int mm = ok ? m : 0;
-        int wo = mm % p.Wo;
-        int t1 = mm / p.Wo;
-        int ho = t1 % p.Ho;
-        int t2 = t1 / p.Ho;
-        int to = t2 % p.To;
-        int n = t2 / p.To;
-        int ti0 = to - p.pt, hi0 = ho * p.s - p.ph, wi0 = wo * p.s - p.pw;
-        a_off[i] = (((n * p.T + ti0) * p.H + hi0) * p.W + wi0) * p.C * 4;     // bytes
+    // Row bookkeeping (fixed over the K loop): byte offset of tap (0,0,0) and tap-validity masks of each tile row.
+    // Instructions issued outside the K loop are expensive (they queue behind the other workgroups' MFMAs, ~60 cycles
+    // each), so every row is decomposed ONCE, by thread `row` with multiply-shift divisions, and shared through LDS
+    // instead of being recomputed by the 8 threads that stage it; the remaining waves build the tap table meanwhile.
+    __shared__ uint4 rowinfo[BM];      // {a_off, a_msk, a_inv_lo, a_inv_hi}
+    if (tid < BM) {
+        const int m = m0 + tid;
+        const bool ok = m < p.M;
+        const uint32_t mm = ok ? (uint32_t)m : 0u;
+        const uint32_t t1 = ss_div32(mm, p.divWo);
+        const int wo = (int)(mm - t1 * (uint32_t)p.Wo);
+        const uint32_t t2 = ss_div32(t1, p.divHo);
+        const int ho = (int)(t1 - t2 * (uint32_t)p.Ho);
+        const uint32_t n = ss_div32(t2, p.divTo);
+        const int to = (int)(t2 - n * (uint32_t)p.To);
+        const int ti0 = to - p.pt, hi0 = ho * p.s - p.ph, wi0 = wo * p.s - p.pw;
+        const int aoff = ((((int)n * p.T + ti0) * p.H + hi0) * p.W + wi0) * p.C * 4;     // bytes
         // valid taps along each axis form one interval [lo, hi): bit mask = (1 << hi) - (1 << lo)
         auto span = [](int x0, int k, int size) -> unsigned {
             int lo = max(0, -x0), hi = min(k, size - x0);
             return hi > lo ? (1u << hi) - (1u << lo) : 0u;
         };
         unsigned msk = span(wi0, p.kw, p.W) | (span(hi0, p.kh, p.H) << 8) | (span(ti0, p.kt, p.T) << 16);
-        a_msk[i] = ok ? msk : 0u;
-        if (AMODE > 0) {
-            // table mode: one bit per filter tap (index (dt*kh + dh)*kw + dw < 64), SET where the tap falls outside the
-            // input (or the row is past M)
+        msk = ok ? msk : 0u;           // bits 0..7: valid dw, 8..15: valid dh, 16..23: valid dt
+        unsigned inv_lo = 0xFFFFFFFFu, inv_hi = 0xFFFFFFFFu;
+        if (AMODE == 1) {
+            // table mode, <= 32 taps: bit (dt*kh + dh)*kw + dw SET where the tap falls outside the input
+            unsigned valid = 0u;
+            const unsigned mw = msk & 0xFFu;
+            for (int dt = 0; dt < p.kt; ++dt)
+                for (int dh = 0; dh < p.kh; ++dh) {
+                    const unsigned sel = 0u - ((msk >> (8 + dh)) & (msk >> (16 + dt)) & 1u);
+                    valid |= (mw << ((dt * p.kh + dh) * p.kw)) & sel;
+                }
+            inv_lo = ~valid;
+        } else if (AMODE == 2) {
             unsigned long long valid = 0ull;
-            if (ok) {
-                const unsigned long long mw = msk & 0xFFu;
-                for (int dt = 0; dt < p.kt; ++dt)
-                    for (int dh = 0; dh < p.kh; ++dh)
-                        if ((msk >> (8 + dh)) & (msk >> (16 + dt)) & 1u) valid |= mw << ((dt * p.kh + dh) * p.kw);
-            }
-            a_inv_lo[i] = ~(unsigned)valid;
-            a_inv_hi[i] = ~(unsigned)(valid >> 32);
+            const unsigned long long mw = msk & 0xFFu;
+            for (int dt = 0; dt < p.kt; ++dt)
+                for (int dh = 0; dh < p.kh; ++dh) {
+                    const unsigned long long sel = 0ull - (unsigned long long)((msk >> (8 + dh)) & (msk >> (16 + dt)) & 1u);
+                    valid |= (mw << ((dt * p.kh + dh) * p.kw)) & sel;
+                }
+            inv_lo = ~(unsigned)valid;
+            inv_hi = ~(unsigned)(valid >> 32);
         }
+        rowinfo[tid] = make_uint4((unsigned)aoff, msk, inv_lo, inv_hi);
     }
+    if (p.dbg) tsa = __builtin_amdgcn_s_memtime();
     unsigned w_off[RB], w_bad[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -166,21 +179,36 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 
     if (AMODE > 0) {
         // per-block tap table: entry e describes k = kt0*BK + 4e: {byte offset of the tap relative to tap (0,0,0),
-        // tap bit index | 64 for k >= K}.  Replaces three divisions per K tile per thread by one ds_read_b64.
+        // tap bit index, or 64 for k >= K}.  Replaces three divisions per K tile per thread by one ds_read_b64.
+        constexpr int T0 = BM < 256 ? BM : 0;         // built by the threads that own no row
         const int tab_n = (kt1 - kt0) * TPR;
-        for (int e = tid; e < tab_n; e += 256) {
-            int k = kt0 * BK + e * 4;
-            uint32_t tap = ss_fastdiv((uint32_t)k, p.divC);
-            int ci = k - (int)tap * p.C;
-            uint32_t t2 = ss_fastdiv(tap, p.divKw);
-            int dw = (int)tap - (int)t2 * p.kw;
-            uint32_t dt = ss_fastdiv(t2, p.divKh);
-            int dh = (int)t2 - (int)dt * p.kh;
-            int tapoff = ((((int)dt * p.H + dh) * p.W + dw) * p.C + ci) * 4;
-            tap_tab[e] = k < p.K ? make_uint2((unsigned)tapoff, tap) : make_uint2(0u, 64u);
+        if (tid >= T0) {
+            for (int e = tid - T0; e < tab_n; e += 256 - T0) {
+                int k = kt0 * BK + e * 4;
+                uint32_t tap = ss_fastdiv((uint32_t)k, p.divC);
+                int ci = k - (int)tap * p.C;
+                uint32_t t2 = ss_fastdiv(tap, p.divKw);
+                int dw = (int)tap - (int)t2 * p.kw;
+                uint32_t dt = ss_fastdiv(t2, p.divKh);
+                int dh = (int)t2 - (int)dt * p.kh;
+                int tapoff = ((((int)dt * p.H + dh) * p.W + dw) * p.C + ci) * 4;
+                tap_tab[e] = k < p.K ? make_uint2((unsigned)tapoff, tap) : make_uint2(0u, 64u);
+            }
         }
-        __syncthreads();
     }
+    __syncthreads();
+    int a_off[RA];
+    unsigned a_inv_lo[RA], a_inv_hi[RA];
+    unsigned a_msk[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const uint4 ri = rowinfo[lrow + i * RPP];
+        a_off[i] = (int)ri.x;
+        a_msk[i] = ri.y;
+        a_inv_lo[i] = ri.z;
+        a_inv_hi[i] = ri.w;
+    }
+    if (p.dbg) tsb = __builtin_amdgcn_s_memtime();
     unsigned wk[RB];             // table mode: running byte offset of each filter row's next K tile
 #pragma unroll
     for (int i = 0; i < RB; ++i) wk[i] = w_off[i] + (unsigned)(kt0 * BK + kq * 4) * 4u;
@@ -274,6 +302,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 
     if (kt0 < kt1) {
         gload(kt0);
+        if (p.dbg) tsc = __builtin_amdgcn_s_memtime();
         lstore(0);
     }
     __syncthreads();
@@ -349,7 +378,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         }
     }
     if (p.dbg && tid == 0) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 5;
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        d[5] = tsa; d[6] = tsb; d[7] = tsc;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
         d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
@@ -379,6 +409,8 @@ static void launch_conv(const ConvP& p, int groups, hipStream_t st, unsigned dyn
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     ConvP q = p;
     q.ntiles = (unsigned)ss_cdiv(p.Co, BN);
+    q.divNt = ss_div32_make(q.ntiles);
+    q.divSplits = ss_div32_make((uint32_t)p.splits);
     dim3 g((unsigned)ss_cdiv(p.M, BM) * q.ntiles, 1, groups * p.splits);
     hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK, TAIL, SCHED, AMODE>), g, dim3(256), dyn_lds,
                        st, q);
@@ -449,6 +481,9 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     p.divC = ss_fastdiv_make((uint32_t)cin);
     p.divKw = ss_fastdiv_make((uint32_t)kw);
     p.divKh = ss_fastdiv_make((uint32_t)kh);
+    p.divWo = ss_div32_make((uint32_t)p.Wo);
+    p.divHo = ss_div32_make((uint32_t)p.Ho);
+    p.divTo = ss_div32_make((uint32_t)p.To);
     p.relu = relu; p.out_cs = out_cs;
     p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
     p.in_bytes = (unsigned)(in_elems * 4);

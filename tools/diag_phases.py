@@ -13,7 +13,7 @@ for name in sys.argv[1].split(','):
     res = torch.randn_like(out)
     m = out.numel() // cout
     nblk = ((m + 63) // 64) * ((cout + 63) // 64)
-    dbg = torch.zeros((nblk, 5), dtype=torch.int64, device=dev)
+    dbg = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
     for _ in range(3): ops.conv(x, wt, b, res=res, stride=s, pad=(0, p, p), relu=True, out=out)
     torch.cuda.synchronize()
     lib.ss_debug_ptr(ctypes.c_void_p(dbg.data_ptr()))
@@ -30,6 +30,8 @@ for name in sys.argv[1].split(','):
         name, nblk, total, np.median(pro), np.median(loop), np.median(epi), np.median(d[:, 3] - d[:, 0])))
     print('   p10/p90: prologue %d/%d  loop %d/%d  epilogue %d/%d' % (np.percentile(pro, 10), np.percentile(pro, 90),
           np.percentile(loop, 10), np.percentile(loop, 90), np.percentile(epi, 10), np.percentile(epi, 90)))
+    print('   prologue split (median ticks): row setup %d  table build+barrier %d  first loads issued %d  wait+store+barrier %d' % (
+        np.median(d[:, 5] - d[:, 0]), np.median(d[:, 6] - d[:, 5]), np.median(d[:, 7] - d[:, 6]), np.median(d[:, 1] - d[:, 7])))
     ucu = np.unique(cu)
     print('   distinct CU ids seen: %d; blocks per CU min/median/max: %s' % (len(ucu), np.percentile(np.bincount(np.searchsorted(ucu, cu)), [0, 50, 100])))
     # concurrency on one CU: how many blocks are in each phase at sampled times
