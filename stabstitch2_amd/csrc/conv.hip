@@ -658,6 +658,21 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
     out[idx] = ch < c ? in[((long long)b * c + ch) * hw + rem] : 0.f;
 }
 
+// c <= 4 -> 4 channels (the network inputs): one thread per pixel, plane reads coalesced across lanes, one 16-byte store
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in, float4* __restrict__ out, int c,
+                                                            int hw, long long pixels) {
+    long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= pixels) return;
+    long long b = pix / hw;
+    int rem = (int)(pix - b * hw);
+    const float* s = in + b * c * hw + rem;
+    float4 v = make_float4(s[0], 0.f, 0.f, 0.f);
+    if (c > 1) v.y = s[hw];
+    if (c > 2) v.z = s[2ll * hw];
+    if (c > 3) v.w = s[3ll * hw];
+    out[pix] = v;
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int c, int h, int w,
                                     int cs) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -674,6 +689,12 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
 extern "C" int ss_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream) {
     if (!in || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || c_pad < c) return SS_ERR_ARG;
     long long total = (long long)n * h * w * c_pad;
+    if (c_pad == 4 && (((uintptr_t)out) & 15) == 0) {
+        long long pixels = (long long)n * h * w;
+        hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(ss_cdiv(pixels, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                           reinterpret_cast<float4*>(out), c, h * w, pixels);
+        return ss_launch_status();
+    }
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, c,
                        h, w, c_pad);
     return ss_launch_status();

@@ -3,6 +3,7 @@
     python tools/pmc_summary.py <dir with FETCH csv> <dir with WRITE csv> > profiles/rNN_pmc_hbm.json"""
 import collections
 import csv
+import glob
 import json
 import sys
 
@@ -12,10 +13,11 @@ KEYS = (('conv_igemm', 'conv_igemm_kernel'), ('render_average', 'render_average_
 
 def load(path):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(path + '/p_counter_collection.csv')):
-        for pat, key in KEYS:
-            if pat in r['Kernel_Name']:
-                agg[key].append(float(r['Counter_Value']))
+    for fn in glob.glob(path + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(fn)):
+            for pat, key in KEYS:
+                if pat in r['Kernel_Name']:
+                    agg[key].append(float(r['Counter_Value']))
     return agg
 
 
