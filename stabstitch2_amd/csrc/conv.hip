@@ -403,6 +403,8 @@ __global__ void splitk_reduce_kernel(ConvP p) {
     p.out[o] = v;
 }
 
+static int g_lds_pad = 0;           // ss_debug_set key 4: extra dynamic LDS bytes per workgroup (occupancy experiments)
+
 template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false, int SCHED = 0,
           int AMODE = 0>
 static void launch_conv(const ConvP& p, int groups, hipStream_t st, unsigned dyn_lds = 0) {
@@ -412,8 +414,8 @@ static void launch_conv(const ConvP& p, int groups, hipStream_t st, unsigned dyn
     q.divNt = ss_div32_make(q.ntiles);
     q.divSplits = ss_div32_make((uint32_t)p.splits);
     dim3 g((unsigned)ss_cdiv(p.M, BM) * q.ntiles, 1, groups * p.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK, TAIL, SCHED, AMODE>), g, dim3(256), dyn_lds,
-                       st, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK, TAIL, SCHED, AMODE>), g, dim3(256),
+                       dyn_lds + (unsigned)g_lds_pad, st, q);
 }
 
 static int g_amode_off = 0;         // ss_debug_set key 3: 1 = arithmetic addressing instead of the LDS tap table
@@ -448,6 +450,7 @@ extern "C" void ss_debug_set(int key, int value) {
     if (key == 1) g_ablate = value;
     if (key == 2) g_split_target = value;
     if (key == 3) g_amode_off = value;
+    if (key == 4) g_lds_pad = value;
 }
 
 extern "C" long long ss_conv_workspace_floats(void) { return 16ll << 20; }   // 64 MiB of split-K partials
