@@ -6,21 +6,28 @@
 //     k  = (dt, dh, dw, ci) filter tap x in-channel  (ci fastest, cin % 4 == 0)
 //   Block = 256 threads = WGM x WGN waves (=4), each wave owns WM x WN tiles of 32x32 (16 accumulator
 //   registers each); block tile BM x BN = (WGM*WM*32) x (WGN*WN*32).
-//   The MFMA pipe only stays busy if the non-MFMA instruction count per MFMA is small (one 64-cycle
-//   v_mfma_f32_32x32x2 hides ~10 other issues; the first version of this kernel issued 10.6 and ran the
-//   pipe at 60 %), so everything around the MFMAs is built to be cheap:
-//     * K is walked 32 at a time; one 16-byte buffer_load per thread per 32 tile rows.  Halo taps, the M
-//       tail and the K tail are handled by the buffer descriptor's bounds check: an invalid lane gets byte
-//       offset 0xFFFFFFFF and the hardware returns zeros -- no branches, no selects on the data;
-//     * per row the thread keeps one base offset and one packed validity word (bit masks of the valid
-//       dt / dh / dw), per K tile one tap offset: address = base + tap, valid = 3 shifts and 2 ands;
+//   On a saturated fp32 MFMA pipe every non-MFMA instruction is paid for (a VALU instruction between a wave's own
+//   MFMAs costs ~2.3 pipe cycles, one issued by a wave outside its K loop waits ~60 cycles behind the other
+//   workgroups' MFMAs; LDS / buffer / barrier instructions are free -- tools/micro/), so everything around the MFMAs
+//   is built to be cheap:
+//     * K is walked 32 at a time; one 16-byte buffer_load per thread per 32 tile rows, issued ahead of the tile's
+//       MFMAs.  Halo taps, the M tail and the K tail are handled by the buffer descriptor's bounds check: an invalid
+//       lane gets byte offset 0xFFFFFFFF and the hardware returns zeros -- no branches, no selects on the data;
+//     * addresses come from tables, not arithmetic: per workgroup an LDS table {tap byte offset, tap bit index} per
+//       4 k, per tile row (decomposed once, by one thread, with multiply-shift divisions, shared through LDS) a base
+//       offset and a <= 64-bit mask of the taps that fall outside the input.  Per K tile: one ds_read_b64, then per
+//       row v_bfe_i32 + add + or -> 12 VALU instructions per 16 MFMAs (filters with > 64 taps fall back to the
+//       arithmetic path: three multiply-high divisions per K tile);
 //     * LDS holds rows k-contiguous ([rows][32+4]); the K index inside a tile is permuted so that lane half
 //       h of the MFMA takes k = 16h + j: every lane reads its 16 operands as four ds_read_b128 (row stride
 //       36 dwords = 4*9 keeps each 16-lane group on 16 distinct 16-byte slots: conflict free), and the
 //       staging store is one ds_write_b128;
-//     * LDS double-buffered, one barrier per K tile, next tile's loads in flight under the MFMAs.
+//     * ONE LDS buffer (18 KB) and two barriers per K tile: 6-7 workgroups resident per CU (measured: throughput is
+//       flat from 3 to 7 resident workgroups, tools/ab_occupancy.py);
+//     * s_setprio 3 outside the K loop so that prologue / epilogue instructions win the issue slot.
 //   Epilogue: bias (folded BatchNorm), residual, ReLU; for a fixed accumulator register the 32 lanes of a
-//   half-wave hold 32 consecutive output channels -> 128-byte coalesced NHWC stores.
+//   half-wave hold 32 consecutive output channels -> 128-byte coalesced NHWC accesses, branch free through buffer
+//   instructions (out-of-range offsets for rows >= M), all residual loads in flight before the first use.
 //   Small problems (few tiles, long K) are split along K into `splits` partial sums written to a caller
 //   workspace and combined (deterministically) by splitk_reduce_kernel.
 #include <stdlib.h>
