@@ -567,3 +567,45 @@ def test_host_clip_runner_overlapped_copies(dev, hip_nets):
     for (v, hc, wc), (w, hc2, wc2, _, _) in zip(got, want):
         assert (hc, wc) == (hc2, wc2) and np.array_equal(v, w)
     assert list(runner.run(iter(()))) == []
+
+
+def test_conv_random_shapes_and_address_modes(dev):
+    """Seeded sweep over ragged conv geometries (every padding / stride / kernel size class the tap table and the
+    tap-validity masks distinguish: 1..49 taps -> 32-bit masks, 64-bit masks, > 64 taps -> arithmetic path) against
+    F.conv2d / F.conv3d on the CPU; the LDS-table and the arithmetic address paths must agree bit for bit."""
+    import ctypes
+    from stabstitch2_amd import ops, _hip
+    lib = _hip.lib()
+    lib.ss_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    rs = np.random.RandomState(2024)
+    cases = []
+    for _ in range(36):
+        k = int(rs.choice([1, 2, 3, 5, 7, 8]))
+        cases.append((int(rs.randint(1, 4)), int(rs.choice([1, 3, 4, 8, 20, 64, 68])), int(rs.randint(1, 140)),
+                      int(rs.randint(1, 24)), int(rs.randint(1, 24)), k, int(rs.choice([1, 2, 3])), int(rs.randint(0, k // 2 + 2))))
+    cases += [(1, 4, 64, 12, 12, 8, 1, 4), (2, 8, 3, 9, 31, 8, 2, 0)]          # 64 taps: last bit of the 64-bit mask
+    for (n, cin, cout, h, w, k, s, p) in cases:
+        if (h + 2 * p - k) // s + 1 <= 0 or (w + 2 * p - k) // s + 1 <= 0:
+            continue
+        x = torch.from_numpy(rs.normal(0, 1, (n, cin, h, w)).astype(np.float32))
+        wt = torch.from_numpy((rs.normal(0, 1, (cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+        b = torch.from_numpy(rs.normal(0, 1, cout).astype(np.float32))
+        ref = F.conv2d(x, wt, b, stride=s, padding=p)
+        cp = (cin + 3) // 4 * 4
+        xd, wd, bd = ops.nchw_to_nhwc(x.to(dev), cp), _pack(wt, cp).to(dev), b.to(dev)
+        outs = []
+        for mode in (0, 1):
+            lib.ss_debug_set(3, mode)
+            outs.append(ops.conv(xd, wd, bd, None, stride=s, pad=(0, p, p), relu=False))
+        lib.ss_debug_set(3, 0)
+        assert torch.equal(outs[0], outs[1]), ('table vs arithmetic addressing differ', (n, cin, cout, h, w, k, s, p))
+        close(ops.nhwc_to_nchw(outs[0]), ref, 3e-5 * max(1.0, float(ref.abs().max())), 'conv %s' % ((n, cin, cout, h, w, k, s, p),))
+    # 3-D: 5x3x3 = 45 taps (64-bit masks) and 5x5x5 = 125 taps (arithmetic fallback), temporal padding included
+    for (kt, kk, pt, pp) in ((5, 3, 2, 1), (3, 3, 0, 1), (5, 5, 2, 2)):
+        x = torch.from_numpy(rs.normal(0, 1, (2, 8, 6, 7, 9)).astype(np.float32))
+        wt = torch.from_numpy((rs.normal(0, 1, (10, 8, kt, kk, kk)) / np.sqrt(8 * kt * kk * kk)).astype(np.float32))
+        b = torch.from_numpy(rs.normal(0, 1, 10).astype(np.float32))
+        ref = F.conv3d(x, wt, b, padding=(pt, pp, pp))
+        out = ops.conv(x.permute(0, 2, 3, 4, 1).contiguous().to(dev), _pack(wt, 8).to(dev), b.to(dev), None, stride=1,
+                       pad=(pt, pp, pp), relu=False)
+        close(out.permute(0, 4, 1, 2, 3), ref, 3e-5 * max(1.0, float(ref.abs().max())), 'conv3d %s' % ((kt, kk, pt, pp),))
