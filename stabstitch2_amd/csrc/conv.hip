@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         unsigned msk = span(wi0, p.kw, p.W) | (span(hi0, p.kh, p.H) << 8) | (span(ti0, p.kt, p.T) << 16);
         msk = ok ? msk : 0u;           // bits 0..7: valid dw, 8..15: valid dh, 16..23: valid dt
         unsigned inv_lo = 0xFFFFFFFFu, inv_hi = 0xFFFFFFFFu;
-        if (AMODE == 1) {
+        if (AMODE == 1 || AMODE == 3) {
             // table mode, <= 32 taps: bit (dt*kh + dh)*kw + dw SET where the tap falls outside the input
             unsigned valid = 0u;
             const unsigned mw = msk & 0xFFu;
@@ -222,7 +222,20 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 
     u32x4 ra[RA], rb[RB];
     unsigned oa[RA], ob[RB];     // byte offsets of the next tile's loads (0xFFFFFFFF = out of range -> zeros)
+    unsigned bsoff = 0u;         // AMODE 3: wave-uniform byte offset of the K tile inside a filter row
     auto gaddr = [&](int kt) {
+        if (AMODE == 3) {
+            // aligned problems (Cout % BN == 0, K % BK == 0, <= 32 taps): no K / Cout masks, and the filter rows advance
+            // through the scalar offset of the buffer instruction -> 7 VALU instructions per K tile
+            const uint2 e = tap_tab[(kt - kt0) * TPR + kq];
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const unsigned inv = (unsigned)__builtin_amdgcn_sbfe((int)a_inv_lo[i], e.y, 1u);
+                oa[i] = ((unsigned)a_off[i] + e.x) | inv;
+            }
+            bsoff = (unsigned)kt * (BK * 4u);
+            return;
+        }
         if (AMODE > 0) {
             const uint2 e = tap_tab[(kt - kt0) * TPR + kq];
             const unsigned kinv = (unsigned)__builtin_amdgcn_sbfe((int)e.y, 6u, 1u);      // all ones for k >= K
@@ -265,7 +278,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, oa[i], 0, 0);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, ob[i], 0, 0);
+        for (int i = 0; i < RB; ++i)
+            rb[i] = AMODE == 3 ? __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[i] + (unsigned)kq * 16u, (int)bsoff, 0)
+                               : __builtin_amdgcn_raw_buffer_load_b128(rw, ob[i], 0, 0);
     };
     auto gload = [&](int kt) {
         gaddr(kt);
@@ -433,14 +448,17 @@ static int g_amode_off = 0;         // ss_debug_set key 3: 1 = arithmetic addres
 template <int WGM, int WGN, int WM, int WN, int NBUF, int BK = 32, int SCHED = 0>
 static void launch_auto(const ConvP& p, int groups, hipStream_t st, int taps, bool tail) {
     const unsigned tab_bytes = (unsigned)p.tiles_per_split * (unsigned)(BK / 4) * 8u;
-    const int amode = (g_amode_off || taps > 64 || tab_bytes > 24576u) ? 0 : (taps <= 32 ? 1 : 2);
+    constexpr int BN_ = WGN * WN * 32;
+    int amode = ((g_amode_off & 1) || taps > 64 || tab_bytes > 24576u) ? 0 : (taps <= 32 ? 1 : 2);
+    if (amode == 1 && !(g_amode_off & 2) && p.Co % BN_ == 0 && p.K % BK == 0) amode = 3;
     constexpr bool DEF = WGM == 2 && WGN == 2 && WM == 1 && WN == 1 && NBUF == 1 && BK == 32 && SCHED == 1;
     if (DEF && tail) {
         if (amode == 1) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 1>(p, groups, st, tab_bytes);
         else if (amode == 2) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 2>(p, groups, st, tab_bytes);
         else launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 0>(p, groups, st);
     } else {
-        if (amode == 1) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 1>(p, groups, st, tab_bytes);
+        if (amode == 3) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 3>(p, groups, st, tab_bytes);
+        else if (amode == 1) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 1>(p, groups, st, tab_bytes);
         else if (amode == 2) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 2>(p, groups, st, tab_bytes);
         else launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, false, SCHED, 0>(p, groups, st);
     }
@@ -456,7 +474,7 @@ extern "C" void ss_debug_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     if (key == 1) g_ablate = value;
     if (key == 2) g_split_target = value;
-    if (key == 3) g_amode_off = value;
+    if (key == 3) g_amode_off = value;      // 1: arithmetic addressing, 2: table without the aligned fast path
     if (key == 4) g_lds_pad = value;
 }
 

@@ -1,4 +1,5 @@
-"""Interleaved in-process A/B of the conv address modes (ss_debug_set key 3: 0 = LDS tap table, 1 = arithmetic)."""
+"""Interleaved in-process A/B of the conv address modes (ss_debug_set key 3: 0 = auto (aligned fast path where it
+applies), 2 = LDS tap table without the fast path, 1 = arithmetic)."""
 import sys, os, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabstitch2_amd import ops, _hip
@@ -17,9 +18,9 @@ for name in names:
     wt = torch.randn(cout, kt, k, k, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     pad = (kt // 2, p, p)
     outs = {}
-    res = {0: [], 1: []}
+    res = {0: [], 2: [], 1: []}
     for r in range(rounds):
-        for v in (0, 1):
+        for v in (0, 2, 1):
             lib.ss_debug_set(3, v)
             for _ in range(3): out = ops.conv(x, wt, b, stride=s, pad=pad, relu=True)
             outs[v] = out
@@ -29,6 +30,6 @@ for name in names:
     lib.ss_debug_set(3, 0)
     m = outs[0].numel() // cout; fl = 2.0 * m * cout * kt * k * k * cin
     med = {v: sorted(res[v])[len(res[v]) // 2] for v in res}
-    print('%-8s M=%7d N=%3d K=%4d  table: %.3f ms %5.1f TF   arith: %.3f ms %5.1f TF   equal=%s' % (
-        name, m, cout, kt * k * k * cin, med[0], fl / med[0] / 1e9, med[1], fl / med[1] / 1e9,
-        bool(torch.equal(outs[0], outs[1]))), flush=True)
+    print('%-8s M=%7d N=%3d K=%4d  auto: %.3f ms %5.1f TF   table: %.3f ms %5.1f TF   arith: %.3f ms %5.1f TF   equal=%s' % (
+        name, m, cout, kt * k * k * cin, med[0], fl / med[0] / 1e9, med[2], fl / med[2] / 1e9, med[1], fl / med[1] / 1e9,
+        bool(torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]))), flush=True)
