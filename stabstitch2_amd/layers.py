@@ -146,6 +146,9 @@ def run_block(x, p):
 
 
 STAGE1_CHUNK = int(os.environ.get('SS_STAGE1_CHUNK', '64'))      # images per trunk pass
+# conv1 + max-pool run in sub-chunks so that conv1's output (11 MB per image) is still in the 256 MB MALL when the
+# pool reads it; the rest of the trunk runs on the whole chunk (large launches)
+CONV1_CHUNK = int(os.environ.get('SS_CONV1_CHUNK', '16'))
 
 
 def run_stage1(x_nchw, p, chunk=None):
@@ -162,8 +165,20 @@ def run_stage1(x_nchw, p, chunk=None):
         o += x.shape[0]
     outs = []
     for s in range(0, total, chunk):
-        x = ops.conv(buf[s:s + chunk], p['conv1'][0], p['conv1'][1], stride=2, pad=(0, 3, 3), relu=True)
-        x = ops.maxpool(x, 3, 2, 1)
+        m = min(chunk, total - s)
+        if CONV1_CHUNK > 0 and m > CONV1_CHUNK:
+            x = torch.empty((m, (h // 2 + 1) // 2, (w // 2 + 1) // 2, 64), device=buf.device, dtype=torch.float32) \
+                if (h % 2 == 0 and w % 2 == 0) else None
+        else:
+            x = None
+        if x is not None:
+            for c0 in range(0, m, CONV1_CHUNK):
+                y = ops.conv(buf[s + c0:s + min(c0 + CONV1_CHUNK, m)], p['conv1'][0], p['conv1'][1], stride=2,
+                             pad=(0, 3, 3), relu=True)
+                ops.maxpool(y, 3, 2, 1, out=x[c0:c0 + y.shape[0]])
+        else:
+            x = ops.conv(buf[s:s + chunk], p['conv1'][0], p['conv1'][1], stride=2, pad=(0, 3, 3), relu=True)
+            x = ops.maxpool(x, 3, 2, 1)
         for b in p['layer1']:
             x = run_block(x, b)
         for b in p['layer2']:

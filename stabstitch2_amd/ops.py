@@ -69,11 +69,12 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     return out
 
 
-def maxpool(x, k, stride, pad=0):
+def maxpool(x, k, stride, pad=0, out=None):
     n, h, w, c = x.shape
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1
-    out = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
     H.call('ss_maxpool_nhwc', H.dptr(x), H.dptr(out), n, h, w, c, k, stride, pad, H.stream())
     return out
 
