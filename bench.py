@@ -169,9 +169,10 @@ def main():
     probe = ConvProbe()
     probe.install()
 
-    def step_online():
+    def step_online(use_graph=True):
         from stabstitch2_amd.online import OnlineStitcher
-        st = OnlineStitcher(nets, args.height, args.width, warp_mode=args.warp_mode, fusion_mode=args.fusion_mode)
+        st = OnlineStitcher(nets, args.height, args.width, warp_mode=args.warp_mode, fusion_mode=args.fusion_mode,
+                            use_graph=use_graph)
         last = None
         for t in range(args.frames):
             got = st.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
@@ -227,11 +228,18 @@ def main():
         out = steps_host(args.steps)
     else:
         for i in range(args.steps):
-            probe.active = (i == args.steps - 1)     # HIP events around every conv launch of the last timed step
+            # HIP events around every conv launch of the last timed step (not inside a HIP-graph capture: the streaming
+            # mode is probed on an extra eager pass after the timed region)
+            probe.active = (i == args.steps - 1) and not args.online
             out = step()
     probe.active = False
     sync()
     dt = time.perf_counter() - t0
+    if args.online:
+        probe.active = True
+        step_online(use_graph=False)
+        probe.active = False
+        torch.cuda.synchronize()
     frames_out, hc, wc = out[0], out[1], out[2]
 
     from stabstitch2_amd import dist as ssdist

@@ -44,7 +44,7 @@ int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, int
  * temporal_network.py:65-93) and nn.Conv3d of SmoothNet (smooth_network.py:123-131).
  *   in   [n][t][h][w][cin]            cin % 4 == 0
  *   wgt  [cout][kt][kh][kw][cin]      (BN folded by the caller)
- *   bias [cout] or NULL, res (same shape as out) or NULL
+ *   bias [cout] ([groups][cout] for grouped launches) or NULL, res (same shape as out) or NULL
  *   out  [n][to][ho][wo][out_cs]      first cout channels written (out_cs >= cout)
  * stride applies to h and w (temporal stride is 1); kernel extents <= 8 per axis.  `groups` > 1 runs
  * `groups` independent problems with element strides in_gs / w_gs / out_gs between them (used by the

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     for (int y = 0; y < WN; ++y) {
         const int co = n0 + (wc * WN + y) * 32 + li;
         const bool cok = co < p.Co;
-        const float bias = (direct && p.bias && cok) ? p.bias[co] : 0.f;
+        const float bias = (direct && p.bias && cok) ? p.bias[(long long)grp * p.Co + co] : 0.f;
 #pragma unroll
         for (int x = 0; x < WM; ++x) {
             unsigned off[16];
@@ -418,7 +418,7 @@ __global__ void splitk_reduce_kernel(ConvP p) {
     const float* part = p.partial + (long long)grp * p.splits * per + idx;
     float v = 0.f;
     for (int s = 0; s < p.splits; ++s) v += part[(long long)s * per];
-    if (p.bias) v += p.bias[co];
+    if (p.bias) v += p.bias[(long long)grp * p.Co + co];
     long long o = (long long)grp * p.out_gs + m * p.out_cs + co;
     if (p.res) v += p.res[o];
     if (p.relu) v = fmaxf(v, 0.f);

@@ -212,3 +212,31 @@ def run_regressor(x, p):
     y = ops.linear(flat, p['fc'][0][0], p['fc'][0][1], relu=True)
     y = ops.linear(y, p['fc'][1][0], p['fc'][1][1], relu=True)
     return ops.linear(y, p['fc'][2][0], p['fc'][2][1], relu=False)
+
+
+def pair_regressors(pa, pb):
+    """Stack the conv weights of two regressors of identical architecture (regressNet2 ref / tgt) for grouped launches."""
+    return {'convs': [torch.stack((a, b), 0).contiguous() for a, b in zip(pa['convs'], pb['convs'])],
+            'fc': (pa['fc'], pb['fc'])}
+
+
+def run_regressor_pair(x, pp):
+    """x [2,n,h,w,c] nhwc (one input per regressor) -> (out_a, out_b): the eight convs of both regressors run as
+    eight grouped launches instead of sixteen, the pools on the joint batch; the FC stacks stay per regressor."""
+    g, n = x.shape[0], x.shape[1]
+    for i, w in enumerate(pp['convs']):
+        x = ops.conv_grouped(x, w, None, None, stride=1, pad=(0, 1, 1), relu=True)
+        if i & 1:
+            x = ops.maxpool(x.view(g * n, *x.shape[2:]), 2, 2, 0)
+            x = x.view(g, n, *x.shape[1:])
+    outs = []
+    for k in range(g):
+        fc = pp['fc'][k]
+        flat = x[k].reshape(n, -1)
+        if flat.shape[1] != fc[0][0].shape[1]:
+            raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
+                             % (fc[0][0].shape[1], flat.shape[1]))
+        y = ops.linear(flat, fc[0][0], fc[0][1], relu=True)
+        y = ops.linear(y, fc[1][0], fc[1][1], relu=True)
+        outs.append(ops.linear(y, fc[2][0], fc[2][1], relu=False))
+    return outs

@@ -37,6 +37,9 @@ _conv_ws = {}
 def conv_workspace(device):
     """Split-K scratch (64 MiB) per (device, stream), allocated once; launches on one stream are ordered and each
     conv's reduce runs right behind its partial pass, so one buffer per stream is race free."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture the buffer must come from the graph's own memory pool (and die with it)
+        return torch.empty(int(H.lib().ss_conv_workspace_floats()), device=device, dtype=torch.float32)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _conv_ws.get(key)
     if ws is None:
@@ -66,6 +69,24 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), out.shape[-1],
            1, 0, 0, 0, H.dptr(ws), ws.numel(), H.stream())
+    return out
+
+
+def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False):
+    """G independent convolutions of identical geometry in ONE launch: x [G,n,h,w,c], wgt [G,cout,kt,kh,kw,cin],
+    bias [G,cout] | None, res [G,n,ho,wo,cout] | None -> [G,n,ho,wo,cout].  Used where the reference runs twin
+    sub-networks (regressNet2 ref/tgt, the SpatialNet and TemporalNet trunks in streaming mode)."""
+    g, n, h, w, c = x.shape
+    g2, cout, kt, kh, kw, cin = wgt.shape
+    assert g2 == g and cin == c and kt == 1, (wgt.shape, x.shape)
+    pt, ph, pw = pad
+    ho = (h + 2 * ph - kh) // stride + 1
+    wo = (w + 2 * pw - kw) // stride + 1
+    out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    ws = conv_workspace(x.device)
+    H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
+           n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), cout,
+           g, x[0].numel(), wgt[0].numel(), out[0].numel(), H.dptr(ws), ws.numel(), H.stream())
     return out
 
 

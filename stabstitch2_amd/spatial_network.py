@@ -63,6 +63,12 @@ class SpatialNet(L.PreparedMixin, nn.Module):
             'r2_tgt': L.prep_regressor(self.regressNet2_part1_tgt, self.regressNet2_part2_tgt, 256, 6),
         }
 
+    def _prepared(self):
+        p = super()._prepared()
+        if 'r2_pair' not in p:           # twin stage-2 regressors share every launch (grouped convs)
+            p['r2_pair'] = L.pair_regressors(p['r2_ref'], p['r2_tgt'])
+        return p
+
     @torch.no_grad()
     def forward(self, input1_tensor, input2_tensor):
         """[B,3,360,480] x2 in [-1,1] -> (offset_1 [B,8], offset_2_ref [B,126], offset_2_tgt [B,126])."""
@@ -79,8 +85,10 @@ class SpatialNet(L.PreparedMixin, nn.Module):
         w1 = ops.homo_warp_nhwc(f64[:b], th_ref, fh, fw)
         w2 = ops.homo_warp_nhwc(f64[b:], th_tgt, fh, fw)
         # stage 2: local cost volumes in both directions -> residual mesh motions
-        offset_2_ref = L.run_regressor(ops.cost_volume(w1, w2, 5), p['r2_ref'])
-        offset_2_tgt = L.run_regressor(ops.cost_volume(w2, w1, 5), p['r2_tgt'])
+        cv = torch.empty((2, b, fh, fw, 124), device=w1.device, dtype=torch.float32)
+        ops.cost_volume(w1, w2, 5, out=cv[0])
+        ops.cost_volume(w2, w1, 5, out=cv[1])
+        offset_2_ref, offset_2_tgt = L.run_regressor_pair(cv, p['r2_pair'])
         return offset_1, offset_2_ref, offset_2_tgt
 
     @staticmethod

@@ -609,3 +609,21 @@ def test_conv_random_shapes_and_address_modes(dev):
         out = ops.conv(x.permute(0, 2, 3, 4, 1).contiguous().to(dev), _pack(wt, 8).to(dev), b.to(dev), None, stride=1,
                        pad=(pt, pp, pp), relu=False)
         close(out.permute(0, 4, 1, 2, 3), ref, 3e-5 * max(1.0, float(ref.abs().max())), 'conv3d %s' % ((kt, kk, pt, pp),))
+
+
+def test_online_graph_replay_equals_eager(dev, hip_nets, clip16):
+    """The captured steady state (HIP graph over static ring buffers) produces exactly the frames of the eager
+    steady state, push after push, and both continue the warm-up (list-based) state without a seam."""
+    from stabstitch2_amd.online import OnlineStitcher
+    hr, lr = clip16
+    hrd = [[f.to(dev) for f in v] for v in hr]
+    lrd = [[f.to(dev) for f in v] for v in lr]
+    outs = {}
+    for use_graph in (False, True):
+        st = OnlineStitcher(hip_nets, 360, 480, use_graph=use_graph)
+        frames = []
+        for t in range(14):
+            frames += st.push(hrd[0][t], hrd[1][t], lrd[0][t], lrd[1][t])
+        assert len(frames) == 14 and (st.graph is not None) == use_graph
+        outs[use_graph] = torch.stack(frames, 0)
+    assert torch.equal(outs[False], outs[True])
