@@ -240,3 +240,42 @@ def run_regressor_pair(x, pp):
         y = ops.linear(y, fc[1][0], fc[1][1], relu=True)
         outs.append(ops.linear(y, fc[2][0], fc[2][1], relu=False))
     return outs
+
+
+# --------------------------------------------------------------------------- twin trunks (streaming mode)
+def _stack2(a, b):
+    return None if a is None else torch.stack((a, b), 0).contiguous()
+
+
+def pair_trunks(pa, pb):
+    """Stack two stage-1 trunks of identical architecture (SpatialNet / TemporalNet) for grouped launches."""
+    def blk(x, y):
+        d = {'c1': (_stack2(x['c1'][0], y['c1'][0]), _stack2(x['c1'][1], y['c1'][1])),
+             'c2': (_stack2(x['c2'][0], y['c2'][0]), _stack2(x['c2'][1], y['c2'][1])), 'stride': x['stride'], 'ds': None}
+        if x['ds'] is not None:
+            d['ds'] = (_stack2(x['ds'][0], y['ds'][0]), _stack2(x['ds'][1], y['ds'][1]))
+        return d
+    return {'conv1': (_stack2(pa['conv1'][0], pb['conv1'][0]), _stack2(pa['conv1'][1], pb['conv1'][1])),
+            'layer1': [blk(x, y) for x, y in zip(pa['layer1'], pb['layer1'])],
+            'layer2': [blk(x, y) for x, y in zip(pa['layer2'], pb['layer2'])]}
+
+
+def run_stage1_pair(xs, pp):
+    """The same NCHW inputs through TWO trunks (weights stacked by pair_trunks) -> nhwc [2,n,H/8,W/8,128]:
+    every layer is one grouped launch; conv1 reads the shared input once per group (group stride 0)."""
+    xs = xs if isinstance(xs, (list, tuple)) else [xs]
+    total = sum(x.shape[0] for x in xs)
+    h, w = xs[0].shape[2], xs[0].shape[3]
+    buf = torch.empty((total, h, w, 4), device=xs[0].device, dtype=torch.float32)
+    o = 0
+    for x in xs:
+        ops.nchw_to_nhwc(x, 4, out=buf[o:o + x.shape[0]])
+        o += x.shape[0]
+    y = ops.conv_grouped(buf, pp['conv1'][0], pp['conv1'][1], None, stride=2, pad=(0, 3, 3), relu=True)
+    y = ops.maxpool(y.view(2 * total, *y.shape[2:]), 3, 2, 1)
+    y = y.view(2, total, *y.shape[1:])
+    for b in pp['layer1'] + pp['layer2']:
+        t = ops.conv_grouped(y, b['c1'][0], b['c1'][1], None, stride=b['stride'], pad=(0, 1, 1), relu=True)
+        idt = y if b['ds'] is None else ops.conv_grouped(y, b['ds'][0], b['ds'][1], None, stride=b['stride'], pad=(0, 0, 0))
+        y = ops.conv_grouped(t, b['c2'][0], b['c2'][1], idt, stride=1, pad=(0, 1, 1), relu=True)
+    return y

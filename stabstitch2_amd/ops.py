@@ -74,10 +74,15 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
 
 def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False):
     """G independent convolutions of identical geometry in ONE launch: x [G,n,h,w,c], wgt [G,cout,kt,kh,kw,cin],
-    bias [G,cout] | None, res [G,n,ho,wo,cout] | None -> [G,n,ho,wo,cout].  Used where the reference runs twin
+    bias [G,cout] | None, res [G,n,ho,wo,cout] | None -> [G,n,ho,wo,cout]; a 4-D x [n,h,w,c] is shared by all groups.  Used where the reference runs twin
     sub-networks (regressNet2 ref/tgt, the SpatialNet and TemporalNet trunks in streaming mode)."""
-    g, n, h, w, c = x.shape
     g2, cout, kt, kh, kw, cin = wgt.shape
+    shared = x.dim() == 4                # one input read by every group (group stride 0)
+    if shared:
+        n, h, w, c = x.shape
+        g = g2
+    else:
+        g, n, h, w, c = x.shape
     assert g2 == g and cin == c and kt == 1, (wgt.shape, x.shape)
     pt, ph, pw = pad
     ho = (h + 2 * ph - kh) // stride + 1
@@ -86,7 +91,7 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
     ws = conv_workspace(x.device)
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), cout,
-           g, x[0].numel(), wgt[0].numel(), out[0].numel(), H.dptr(ws), ws.numel(), H.stream())
+           g, 0 if shared else x[0].numel(), wgt[0].numel(), out[0].numel(), H.dptr(ws), ws.numel(), H.stream())
     return out
 
 

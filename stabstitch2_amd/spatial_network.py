@@ -75,6 +75,12 @@ class SpatialNet(L.PreparedMixin, nn.Module):
         p = self._prepared()
         b, _, img_h, img_w = input1_tensor.shape
         f64 = L.run_stage1([input1_tensor, input2_tensor], p['s1'])      # [2B,45,60,128] nhwc
+        return self.forward_features(f64, b, img_h, img_w)
+
+    @torch.no_grad()
+    def forward_features(self, f64, b, img_h, img_w):
+        """Everything after the stage-1 trunk: f64 nhwc [2B,45,60,128] (view 1 first) -> the three offsets."""
+        p = self._prepared()
         f32 = L.run_stage2(f64, p['s2'])                   # [2B,23,30,256]
         # stage 1: contextual correlation -> global homography offsets
         _, flow = ops.ccl(f32[:b], f32[b:], 10.0, want_nchw=False, want_nhwc4=True)
