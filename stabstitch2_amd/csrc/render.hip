@@ -279,13 +279,13 @@ __global__ __launch_bounds__(256) void lb_centroid_kernel(const float* __restric
             if (m2[i] != 0.f) { k2 += 1; r2 += r; c2 += c; }
         }
     }
-    unsigned v[6] = {k1, r1, c1, k2, r2, c2};
+    unsigned v[6] = {k1, r1, c1, k2, r2, c2};       // a wave's sums still fit 32 bits (<= 64 lanes x ~24 rows x 1882)
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        unsigned long long t = v[k];
+        unsigned t = v[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], t);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], (unsigned long long)t);
     }
     __syncthreads();
     if (threadIdx.x < 6) atomicAdd(&s[threadIdx.x], red[threadIdx.x]);
@@ -311,7 +311,12 @@ __device__ __forceinline__ bool lb_overlap(float a, float b) { return rintf(__fm
 
 __global__ __launch_bounds__(256) void lb_range_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
                                                        unsigned long long* s, int hc, int wc) {
-    LbCenters L = lb_centers(s);
+    // the centres cost four fp64 divisions: once per workgroup, not per thread (that was 55 us per frame)
+    __shared__ LbCenters Ls;
+    __shared__ float smn[4], smx[4];
+    if (threadIdx.x == 0) Ls = lb_centers(s);
+    __syncthreads();
+    const LbCenters L = Ls;
     float mn = INFINITY, mx = -INFINITY;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     if (c < wc) {
@@ -326,8 +331,12 @@ __global__ __launch_bounds__(256) void lb_range_kernel(const float* __restrict__
     }
     mn = ss_wave_min(mn);
     mx = ss_wave_max(mx);
-    unsigned* u = reinterpret_cast<unsigned*>(s);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        unsigned* u = reinterpret_cast<unsigned*>(s);
         if (mn != INFINITY) atomicMin(&u[12], f2key(mn));
         if (mx != -INFINITY) atomicMax(&u[13], f2key(mx));
     }
@@ -336,6 +345,9 @@ __global__ __launch_bounds__(256) void lb_range_kernel(const float* __restrict__
 // X = ref_only + (1 - ovl_mask) * m1
 __global__ void lb_premask_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
                                   const unsigned long long* s, float* __restrict__ X, int hc, int wc) {
+    __shared__ LbCenters Ls;
+    if (threadIdx.x == 0) Ls = lb_centers(s);
+    __syncthreads();
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (c >= wc || r >= hc) return;
     const long long i = (long long)r * wc + c;
@@ -345,7 +357,7 @@ __global__ void lb_premask_kernel(const float* __restrict__ m1, const float* __r
     float ref_only = __fsub_rn(a, ovl);
     float om = 0.f;
     if (ovl != 0.f) {
-        LbCenters L = lb_centers(s);
+        const LbCenters L = Ls;
         float pmin = key2f(u[12]), pmax = key2f(u[13]);
         om = __fsub_rn(lb_proj(L, r, c), pmin) / __fadd_rn(__fsub_rn(pmax, pmin), 1e-3f);
     }
@@ -421,7 +433,8 @@ extern "C" int ss_linear_blend(const float* ref, const float* tgt, const float* 
     float* X = ws + 32;
     float* tmp = X + (long long)hc * wc;
     hipLaunchKernelGGL(lb_init_kernel, dim3(1), dim3(64), 0, st, sc);
-    dim3 rg(ss_cdiv(wc, 64), ss_cdiv(hc, 16) < 64 ? ss_cdiv(hc, 16) : 64);
+    // few, long-running workgroups for the two reductions: every workgroup ends in atomics on the same scalars
+    dim3 rg(ss_cdiv(wc, 64), ss_cdiv(hc, 16) < 8 ? ss_cdiv(hc, 16) : 8);
     hipLaunchKernelGGL(lb_centroid_kernel, rg, dim3(256), 0, st, ref_m, tgt_m, sc, hc, wc);
     hipLaunchKernelGGL(lb_range_kernel, rg, dim3(256), 0, st, ref_m, tgt_m, sc, hc, wc);
     const dim3 pg(ss_cdiv(wc, 64), ss_cdiv(hc, 4));
