@@ -627,3 +627,23 @@ def test_online_graph_replay_equals_eager(dev, hip_nets, clip16):
         assert len(frames) == 14 and (st.graph is not None) == use_graph
         outs[use_graph] = torch.stack(frames, 0)
     assert torch.equal(outs[False], outs[True])
+
+
+def test_degenerate_inputs_stay_finite_and_match_oracle(dev, hip_nets):
+    """Constant frames (all black / all white: zero-variance features, degenerate correlation) go through the whole
+    path without NaN/Inf and agree with the CPU oracle like ordinary frames do."""
+    from stabstitch2_amd import pipeline
+    onets = (N.SpatialNet().eval(), N.TemporalNet().eval(), N.SmoothNet().eval())
+    for m in onets:
+        m.load_state_dict(synth.synthetic_state_dict(m), strict=True)
+    n = 8
+    for val in (0.0, 255.0):
+        hr = torch.full((n, 3, 360, 480), val)
+        lr = hr / 127.5 - 1.0
+        frames, hc, wc, m1, m2 = pipeline.run_two_view(hr.to(dev), hr.to(dev), lr.to(dev), lr.to(dev), hip_nets)
+        assert bool(torch.isfinite(frames).all()) and bool(torch.isfinite(m1).all()) and bool(torch.isfinite(m2).all())
+        ref = P.run_two_view([hr[i:i + 1] for i in range(n)], [hr[i:i + 1] for i in range(n)],
+                             [lr[i:i + 1] for i in range(n)], [lr[i:i + 1] for i in range(n)], onets)
+        assert (hc, wc) == (ref[1], ref[2])
+        close(m1.cpu(), ref[3], 5e-3, 'degenerate smooth_mesh1 (val %g)' % val)
+        close(m2.cpu(), ref[4], 5e-3, 'degenerate smooth_mesh2 (val %g)' % val)
