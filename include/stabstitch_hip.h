@@ -60,6 +60,10 @@ int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const flo
 /* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */
 int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
                     void* stream);
+/* same pooling, channels [0,c/2) -> out0 and [c/2,c) -> out1 (both [n][ho][wo][c/2]; c % 8 == 0): lets the SpatialNet and
+ * TemporalNet stems (identical 7x7 s2 conv + pool on the same frames) share one conv1 launch with 2x64 filters */
+int ss_maxpool_nhwc_split(const float* in, float* out0, float* out1, int n, int h, int w, int c, int k, int stride,
+                          int pad, void* stream);
 
 /* K5: nn.Linear (+ReLU): y[m][nout] = x[m][k] . w[nout][k] + b  (spatial_network.py:170-178, 211-219) */
 int ss_linear(const float* x, const float* w, const float* b, float* y, int m, int k, int nout, int relu,

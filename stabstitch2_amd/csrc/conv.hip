@@ -570,8 +570,10 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
 
 // ------------------------------------------------------------------------------------------------
 // max pooling, nhwc, floor mode, -inf padding
-__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w, int c4,
-                               int ho, int wo, int k, int s, int pad) {
+// out2 != nullptr: the upper half of the channels goes to out2 (both outputs c4/2 float4 wide): the shared conv1 of the
+// SpatialNet / TemporalNet stems writes 64 + 64 channels, each trunk continues from its own pooled tensor
+__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, int n,
+                               int h, int w, int c4, int ho, int wo, int k, int s, int pad) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)n * ho * wo * c4;
     if (idx >= total) return;
@@ -592,7 +594,14 @@ __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__
             m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
     }
-    reinterpret_cast<float4*>(out)[idx] = m;
+    if (out2) {
+        const int half = c4 >> 1;
+        const long long pixel = idx / c4;
+        if (cq < half) reinterpret_cast<float4*>(out)[pixel * half + cq] = m;
+        else reinterpret_cast<float4*>(out2)[pixel * half + cq - half] = m;
+    } else {
+        reinterpret_cast<float4*>(out)[idx] = m;
+    }
 }
 
 extern "C" int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
@@ -601,8 +610,20 @@ extern "C" int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w,
     int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
     if (ho <= 0 || wo <= 0) return SS_ERR_ARG;
     long long total = (long long)n * ho * wo * (c / 4);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, h, w,
-                       c / 4, ho, wo, k, stride, pad);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       (float*)nullptr, n, h, w, c / 4, ho, wo, k, stride, pad);
+    return ss_launch_status();
+}
+
+extern "C" int ss_maxpool_nhwc_split(const float* in, float* out0, float* out1, int n, int h, int w, int c, int k,
+                                     int stride, int pad, void* stream) {
+    if (!in || !out0 || !out1 || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || k <= 0 || stride <= 0)
+        return SS_ERR_ARG;
+    int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    if (ho <= 0 || wo <= 0) return SS_ERR_ARG;
+    long long total = (long long)n * ho * wo * (c / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out0, out1, n, h,
+                       w, c / 4, ho, wo, k, stride, pad);
     return ss_launch_status();
 }
 

@@ -279,3 +279,42 @@ def run_stage1_pair(xs, pp):
         idt = y if b['ds'] is None else ops.conv_grouped(y, b['ds'][0], b['ds'][1], None, stride=b['stride'], pad=(0, 0, 0))
         y = ops.conv_grouped(t, b['c2'][0], b['c2'][1], idt, stride=1, pad=(0, 1, 1), relu=True)
     return y
+
+
+# --------------------------------------------------------------------------- shared stem (offline 2-view path)
+def pair_stems(pa, pb):
+    """conv1 of two trunks as ONE convolution with 2 x 64 filters (same input, same geometry)."""
+    return (torch.cat((pa['conv1'][0], pb['conv1'][0]), 0).contiguous(),
+            torch.cat((pa['conv1'][1], pb['conv1'][1]), 0).contiguous())
+
+
+def run_stem_shared(xs, stem):
+    """NCHW inputs (list) -> (pool_a, pool_b) nhwc [n,H/4,W/4,64]: conv1 + ReLU + max-pool of two trunks that read the
+    same frames, computed by one 128-filter conv1 (the input tile, the row bookkeeping and the NHWC conversion are
+    shared) and a pool that splits the channels; 16-image sub-chunks keep conv1's output MALL-resident."""
+    total = sum(x.shape[0] for x in xs)
+    h, w = xs[0].shape[2], xs[0].shape[3]
+    dev = xs[0].device
+    buf = torch.empty((total, h, w, 4), device=dev, dtype=torch.float32)
+    o = 0
+    for x in xs:
+        ops.nchw_to_nhwc(x, 4, out=buf[o:o + x.shape[0]])
+        o += x.shape[0]
+    ho, wo = ((h - 1) // 2 + 2) // 2, ((w - 1) // 2 + 2) // 2
+    pa = torch.empty((total, ho, wo, 64), device=dev, dtype=torch.float32)
+    pb = torch.empty((total, ho, wo, 64), device=dev, dtype=torch.float32)
+    step = CONV1_CHUNK if CONV1_CHUNK > 0 else total
+    for c0 in range(0, total, step):
+        c1 = min(c0 + step, total)
+        y = ops.conv(buf[c0:c1], stem[0], stem[1], stride=2, pad=(0, 3, 3), relu=True)      # [m,H/2,W/2,128]
+        ops.maxpool_split(y, 3, 2, 1, pa[c0:c1], pb[c0:c1])
+    return pa, pb
+
+
+def run_trunk_body(x, p):
+    """layer1 + layer2 of a stage-1 trunk on its pooled stem output."""
+    for b in p['layer1']:
+        x = run_block(x, b)
+    for b in p['layer2']:
+        x = run_block(x, b)
+    return x

@@ -105,6 +105,13 @@ def maxpool(x, k, stride, pad=0, out=None):
     return out
 
 
+def maxpool_split(x, k, stride, pad, out0, out1):
+    """Pool x [n,h,w,c]; channels [0,c/2) -> out0, [c/2,c) -> out1 (each [n,ho,wo,c/2], preallocated)."""
+    n, h, w, c = x.shape
+    H.call('ss_maxpool_nhwc_split', H.dptr(x), H.dptr(out0), H.dptr(out1), n, h, w, c, k, stride, pad, H.stream())
+    return out0, out1
+
+
 def linear(x, w, b=None, relu=False):
     m, k = x.shape
     nout = w.shape[0]

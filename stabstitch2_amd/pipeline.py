@@ -87,6 +87,45 @@ def temporal_stage_views(temporal_net, lrs):
     return [torch.cat((z, m), 0) for m in ms]
 
 
+SHARED_STEM = os.environ.get('SS_SHARED_STEM', '1') == '1'
+
+
+@torch.no_grad()
+def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None):
+    """SpatialNet and TemporalNet of a 2-view clip in one sweep: both nets start with the same 7x7/2 conv + pool on the
+    same LR frames (spatial_network.py:127-130 and temporal_network.py:47-50 build identical stems), so the stem runs
+    ONCE with 2 x 64 filters and each net continues from its half of the channels.
+    -> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""
+    from . import layers as L
+    chunk = chunk or SPATIAL_CHUNK
+    sp, tp = spatial_net._prepared(), temporal_net._prepared()
+    key = ('stem_pair', id(tp))
+    if key not in sp:
+        sp[key] = L.pair_stems(sp['s1'], tp['s1'])
+    n = lr1.shape[0]
+    m1, m2 = [], []
+    ft = None
+    for s in range(0, n, chunk):
+        e = min(s + chunk, n)
+        b = e - s
+        xa, xb = L.run_stem_shared([lr1[s:e], lr2[s:e]], sp[key])
+        off1, off_ref, off_tgt = spatial_net.forward_features(L.run_trunk_body(xa, sp['s1']), b, LR_H, LR_W)
+        a1, a2 = ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W)
+        m1.append(a1)
+        m2.append(a2)
+        f = L.run_trunk_body(xb, tp['s1'])                                 # [2b,45,60,128], view 1 first
+        if n <= chunk:
+            ft = [f[:b], f[b:]]
+        else:
+            if ft is None:
+                ft = [torch.empty((n,) + tuple(f.shape[1:]), device=f.device, dtype=torch.float32) for _ in range(2)]
+            ft[0][s:e].copy_(f[:b])
+            ft[1][s:e].copy_(f[b:])
+    ms = temporal_net.motions_from_view_features(ft)
+    z = torch.zeros_like(ms[0][:1])
+    return torch.cat(m1, 0), torch.cat(m2, 0), torch.cat((z, ms[0]), 0), torch.cat((z, ms[1]), 0)
+
+
 @torch.no_grad()
 def estimate_meshes(nets, lr1, lr2):
     """Stages 1-3 of test() (test_online_tra.py:284-392) for one clip.
@@ -112,6 +151,8 @@ def estimate_meshes(nets, lr1, lr2):
         main.wait_stream(side)
         for t in (t1, t2):
             t.record_stream(main)
+    elif SHARED_STEM:
+        s1, s2, t1, t2 = joint_stage(spatial_net, temporal_net, lr1, lr2)
     else:
         s1, s2 = spatial_stage(spatial_net, lr1, lr2)
         t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])

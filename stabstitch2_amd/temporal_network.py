@@ -54,6 +54,19 @@ class TemporalNet(L.PreparedMixin, nn.Module):
         return [off[i] for i in range(v)]
 
     @torch.no_grad()
+    def motions_from_view_features(self, feats):
+        """feats: list of V nhwc tensors [N,45,60,128] (stage-1 features of every frame of a view)
+        -> list of V tensors [N-1,7,9,2]; one regressor pass for all views."""
+        p = self._prepared()
+        v, n = len(feats), feats[0].shape[0]
+        cv = torch.empty((v * (n - 1), feats[0].shape[1], feats[0].shape[2], 52), device=feats[0].device,
+                         dtype=torch.float32)
+        for i in range(v):
+            ops.cost_volume(feats[i][:n - 1], feats[i][1:], 3, out=cv[i * (n - 1):(i + 1) * (n - 1)])
+        off = L.run_regressor(cv, p['r2']).view(v, n - 1, grid_h + 1, grid_w + 1, 2)
+        return [off[i] for i in range(v)]
+
+    @torch.no_grad()
     def features(self, frames):
         """Stage-1 features of a list of [n_i,3,360,480] device tensors -> nhwc [sum n_i,45,60,128] (for callers that
         keep the previous frame's features, as the reference's loop does at temporal_network.py:144)."""
