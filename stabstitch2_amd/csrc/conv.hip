@@ -544,6 +544,8 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
         launch_auto<2, 2, 2, 1, 1>(p, groups, st, taps, false);
     } else if (best == 3) {
         launch_auto<2, 2, 1, 2, 1>(p, groups, st, taps, false);
+    } else if (best == 16) {
+        launch_auto<2, 2, 1, 2, 1, 32, 1>(p, groups, st, taps, false);
     } else {
         // default: 64x64 tiles, single LDS buffer; small problems are additionally split along K so that ~512
         // workgroups exist
@@ -557,6 +559,13 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
             p.splits = ss_cdiv(nk, p.tiles_per_split);
             p.partial = ws;
         }
+        // Cout a multiple of 128 and at least one full round of 64x128 workgroups: each input tile is staged once for
+        // 128 filters instead of twice for 64 (+2-3 % on the 128-channel layers; with fewer workgroups the smaller tile
+        // fills the chip better: layer3, 1380 workgroups, loses 6 %)
+        const long long b128 = (long long)ss_cdiv(M, 64) * (cout / 128) * groups;
+        if (!force && p.splits == 1 && cout % 128 == 0 && b128 >= 2048 && !tail)
+            launch_auto<2, 2, 1, 2, 1, 32, 1>(p, groups, st, taps, false);
+        else
         if (best == 11) launch_auto<2, 2, 1, 1, 1, 32, 0>(p, groups, st, taps, false);
         else if (best == 4) launch_auto<2, 2, 1, 1, 2>(p, groups, st, taps, false);
         else launch_auto<2, 2, 1, 1, 1, 32, 1>(p, groups, st, taps, tail);   // loads pinned ahead of the MFMAs: +2-3 %
