@@ -66,6 +66,23 @@ class ConvProbe:
             probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes))
             return out
         ops.conv = timed_conv
+        orig_g = ops.conv_grouped
+
+        def timed_conv_grouped(x, wgt, *a, **k):
+            if not probe.active:
+                return orig_g(x, wgt, *a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_g(x, wgt, *a, **k)
+            e1.record()
+            g, cout, kt, kh, kw, cin = wgt.shape
+            m = out.numel() // out.shape[-1]              # rows of all groups together
+            res = k.get('res')
+            nbytes = 4 * (x.numel() + wgt.numel() + out.numel() + (res.numel() if res is not None else 0))
+            probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes))
+            return out
+        ops.conv_grouped = timed_conv_grouped
         from stabstitch2_amd import layers, smooth_network
         layers.ops = ops
         smooth_network.ops = ops
