@@ -523,27 +523,21 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     p.ablate = g_ablate;
     p.dbg = g_dbg;
 
-    // Tile choice.  Measured on MI355X (tools/ab_conv.py, interleaved A/B on the layer shapes of the pipeline): the
-    // 64x64 tile with ONE 18 KB LDS buffer (5-6 resident workgroups per CU, i.e. 5-6 waves per SIMD feeding each
-    // MFMA pipe) beats every larger tile (128x64: -8 %, 128x128 / 256x64 with 2 waves per SIMD: -10..-50 %) on every
-    // shape -- latency hiding by occupancy matters more here than LDS reads per MFMA, and the small tile also
-    // quantises best over 256 CUs.  The larger variants stay selectable for tuning (ss_debug_set / SS_CONV_TILE).
+    // Tile choice.  Measured on MI355X (tools/ab_conv.py, interleaved in-process A/B on the layer shapes of the pipeline):
+    // 64x64 with ONE 18 KB LDS buffer is the best or equal-best tile on every shape except large launches with
+    // Cout % 128 == 0, where 64x128 wins 2-3 % (below).  128x64, 128x128, 256x64, BK = 64 and a double-buffered LDS
+    // variant were all measured equal or slower (throughput is flat between 3 and 7 resident workgroups per CU, so
+    // occupancy does not separate them; the smaller tile fills 256 CUs better and has the shortest prologue).  Three
+    // of them stay selectable for tuning (ss_debug_set key 0 / SS_CONV_TILE): 5 = 128x128, 7 = 128x64, 16 = 64x128.
     int best = 6;
-    const int force = g_force_tile;   // tuning aid only (ss_debug_set / SS_CONV_TILE)
+    const int force = g_force_tile;   // tuning aid only
     if (force) best = force;
     const int taps = kt * kh * kw;
     const bool tail = (K % 32) != 0 && (K % 32) < 16;
-    if (best == 2) {
-        launch_auto<4, 1, 2, 2, 1>(p, groups, st, taps, false);
-    } else if (best == 5) {
-        launch_auto<2, 2, 2, 2, 1>(p, groups, st, taps, false);
-    } else if (best == 10) {
-        p.tiles_per_split = ss_cdiv(K, 64);
-        launch_auto<2, 2, 1, 1, 1, 64>(p, groups, st, taps, false);
+    if (best == 5) {
+        launch_auto<2, 2, 2, 2, 1, 32, 1>(p, groups, st, taps, false);
     } else if (best == 7) {
-        launch_auto<2, 2, 2, 1, 1>(p, groups, st, taps, false);
-    } else if (best == 3) {
-        launch_auto<2, 2, 1, 2, 1>(p, groups, st, taps, false);
+        launch_auto<2, 2, 2, 1, 1, 32, 1>(p, groups, st, taps, false);
     } else if (best == 16) {
         launch_auto<2, 2, 1, 2, 1, 32, 1>(p, groups, st, taps, false);
     } else {
@@ -566,9 +560,7 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
         if (!force && p.splits == 1 && cout % 128 == 0 && b128 >= 2048 && !tail)
             launch_auto<2, 2, 1, 2, 1, 32, 1>(p, groups, st, taps, false);
         else
-        if (best == 11) launch_auto<2, 2, 1, 1, 1, 32, 0>(p, groups, st, taps, false);
-        else if (best == 4) launch_auto<2, 2, 1, 1, 2>(p, groups, st, taps, false);
-        else launch_auto<2, 2, 1, 1, 1, 32, 1>(p, groups, st, taps, tail);   // loads pinned ahead of the MFMAs: +2-3 %
+            launch_auto<2, 2, 1, 1, 1, 32, 1>(p, groups, st, taps, tail);   // loads pinned ahead of the MFMAs: +2-3 %
         if (p.splits > 1) {
             long long per = M * cout;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, st, p);
