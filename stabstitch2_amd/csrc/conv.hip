@@ -444,14 +444,14 @@ static int g_amode_off = 0;         // ss_debug_set key 3: 1 = arithmetic addres
 
 // Address mode: per-block tap table in LDS (8 bytes per 4 k of the block's K range) when the filter has <= 64 taps
 // and the table stays small; otherwise the arithmetic path (three divisions per K tile per thread).  `tail` selects
-// the variant whose peeled last K tile may be shorter than BK/2 (only instantiated for the default tile).
+// the variant whose peeled last K tile may be shorter than BK/2 (only instantiated for the 64x64 and 128x64 tiles).
 template <int WGM, int WGN, int WM, int WN, int NBUF, int BK = 32, int SCHED = 0>
 static void launch_auto(const ConvP& p, int groups, hipStream_t st, int taps, bool tail) {
     const unsigned tab_bytes = (unsigned)p.tiles_per_split * (unsigned)(BK / 4) * 8u;
     constexpr int BN_ = WGN * WN * 32;
     int amode = ((g_amode_off & 1) || taps > 64 || tab_bytes > 24576u) ? 0 : (taps <= 32 ? 1 : 2);
     if (amode == 1 && !(g_amode_off & 2) && p.Co % BN_ == 0 && p.K % BK == 0) amode = 3;
-    constexpr bool DEF = WGM == 2 && WGN == 2 && WM == 1 && WN == 1 && NBUF == 1 && BK == 32 && SCHED == 1;
+    constexpr bool DEF = WGM == 2 && WGN == 2 && (WM == 1 || WM == 2) && WN == 1 && NBUF == 1 && BK == 32 && SCHED == 1;
     if (DEF && tail) {
         if (amode == 1) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 1>(p, groups, st, tab_bytes);
         else if (amode == 2) launch_conv<WGM, WGN, WM, WN, NBUF, 1, BK, DEF, SCHED, 2>(p, groups, st, tab_bytes);
@@ -557,8 +557,13 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
         // 128 filters instead of twice for 64 (+2-3 % on the 128-channel layers; with fewer workgroups the smaller tile
         // fills the chip better: layer3, 1380 workgroups, loses 6 %)
         const long long b128 = (long long)ss_cdiv(M, 64) * (cout / 128) * groups;
+        // otherwise 128x64 (each filter tile staged once for 128 rows, half the prologues) when at least one full round of
+        // those exists: +2-4 % on conv1 / layer1 / the 124-channel regressor conv
+        const long long b128m = (long long)ss_cdiv(M, 128) * ss_cdiv(cout, 64) * groups;
         if (!force && p.splits == 1 && cout % 128 == 0 && b128 >= 2048 && !tail)
             launch_auto<2, 2, 1, 2, 1, 32, 1>(p, groups, st, taps, false);
+        else if (!force && p.splits == 1 && b128m >= 2048)
+            launch_auto<2, 2, 2, 1, 1, 32, 1>(p, groups, st, taps, tail);
         else
             launch_auto<2, 2, 1, 1, 1, 32, 1>(p, groups, st, taps, tail);   // loads pinned ahead of the MFMAs: +2-3 %
         if (p.splits > 1) {
