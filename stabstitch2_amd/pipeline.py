@@ -91,11 +91,13 @@ SHARED_STEM = os.environ.get('SS_SHARED_STEM', '1') == '1'
 
 
 @torch.no_grad()
-def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None):
+def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None):
     """SpatialNet and TemporalNet of a 2-view clip in one sweep: both nets start with the same 7x7/2 conv + pool on the
     same LR frames (spatial_network.py:127-130 and temporal_network.py:47-50 build identical stems), so the stem runs
     ONCE with 2 x 64 filters and each net continues from its half of the channels.
-    -> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""
+    -> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0).
+    tmotion1: view 1's temporal motions when a previous pass already produced them (three-view: the middle view is
+    view 2 of pair (1,2) and view 1 of pair (2,3)); its TemporalNet trunk is then skipped."""
     from . import layers as L
     chunk = chunk or SPATIAL_CHUNK
     sp, tp = spatial_net._prepared(), temporal_net._prepared()
@@ -113,21 +115,25 @@ def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None):
         a1, a2 = ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W)
         m1.append(a1)
         m2.append(a2)
-        f = L.run_trunk_body(xb, tp['s1'])                                 # [2b,45,60,128], view 1 first
+        views = (1,) if tmotion1 is not None else (0, 1)
+        f = L.run_trunk_body(xb if tmotion1 is None else xb[b:], tp['s1'])  # [len(views)*b,45,60,128], view-major
         if n <= chunk:
-            ft = [f[:b], f[b:]]
+            ft = [f[i * b:(i + 1) * b] for i in range(len(views))]
         else:
             if ft is None:
-                ft = [torch.empty((n,) + tuple(f.shape[1:]), device=f.device, dtype=torch.float32) for _ in range(2)]
-            ft[0][s:e].copy_(f[:b])
-            ft[1][s:e].copy_(f[b:])
+                ft = [torch.empty((n,) + tuple(f.shape[1:]), device=f.device, dtype=torch.float32) for _ in views]
+            for i in range(len(views)):
+                ft[i][s:e].copy_(f[i * b:(i + 1) * b])
     ms = temporal_net.motions_from_view_features(ft)
     z = torch.zeros_like(ms[0][:1])
-    return torch.cat(m1, 0), torch.cat(m2, 0), torch.cat((z, ms[0]), 0), torch.cat((z, ms[1]), 0)
+    tm = [torch.cat((z, m), 0) for m in ms]
+    if tmotion1 is not None:
+        tm = [tmotion1, tm[0]]
+    return torch.cat(m1, 0), torch.cat(m2, 0), tm[0], tm[1]
 
 
 @torch.no_grad()
-def estimate_meshes(nets, lr1, lr2):
+def estimate_meshes(nets, lr1, lr2, tmotion1=None):
     """Stages 1-3 of test() (test_online_tra.py:284-392) for one clip.
     lr1, lr2: [N,3,360,480] device tensors (or lists of [1,3,360,480]).
     -> dict(smooth_mesh1/2, ori_mesh1/2 [1,N,7,9,2], ori_path2, smooth_path2 stitched as test_metric_ssd.py:433-436)."""
@@ -151,11 +157,14 @@ def estimate_meshes(nets, lr1, lr2):
         main.wait_stream(side)
         for t in (t1, t2):
             t.record_stream(main)
-    elif SHARED_STEM:
+    elif SHARED_STEM and tmotion1 is None:      # (with view 1's motions known, half of a shared stem would be wasted)
         s1, s2, t1, t2 = joint_stage(spatial_net, temporal_net, lr1, lr2)
     else:
         s1, s2 = spatial_stage(spatial_net, lr1, lr2)
-        t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
+        if tmotion1 is None:
+            t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
+        else:
+            t1, t2 = tmotion1, temporal_stage_views(temporal_net, [lr2])[0]
     smesh1, tsm1 = ops.tsmotion(s1, t1, LR_H, LR_W)
     smesh2, tsm2 = ops.tsmotion(s2, t2, LR_H, LR_W)
     nw = n - (WINDOW - 1)
@@ -288,7 +297,7 @@ def three_view_render(img1, img2, img3, mesh1, middle, mesh3, warp_mode='NORMAL'
 @torch.no_grad()
 def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE'):
     a12 = estimate_meshes(nets, lr1, lr2)
-    a23 = estimate_meshes(nets, lr2, lr3)
+    a23 = estimate_meshes(nets, lr2, lr3, tmotion1=a12['tmotion2'])     # the middle view's TemporalNet pass is shared
     img_h, img_w = hr1[0].shape[-2:]
     m1, mid, m3 = three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'],
                                      a23['smooth_mesh2'], img_h, img_w)
