@@ -60,14 +60,22 @@ SPATIAL_CHUNK = int(os.environ.get('SS_SPATIAL_CHUNK', '32'))     # frame pairs 
 
 
 @torch.no_grad()
-def spatial_stage(spatial_net, lr1, lr2, chunk=None):
-    """lr1, lr2 [N,3,360,480] device -> smotion1, smotion2 [N,7,9,2]."""
+def spatial_stage(spatial_net, lr1, lr2, chunk=None, cache1=None):
+    """lr1, lr2 [N,3,360,480] device -> smotion1, smotion2 [N,7,9,2].
+    cache1: per chunk the (f64, f32) trunk features of view 1 kept by an earlier pass (then only view 2 goes through
+    the trunk)."""
     chunk = chunk or SPATIAL_CHUNK
     m1, m2 = [], []
-    for s in range(0, lr1.shape[0], chunk):
-        o = build_SpatialNet(spatial_net, lr1[s:s + chunk], lr2[s:s + chunk])
-        m1.append(o['motion1'])
-        m2.append(o['motion2'])
+    for i, s in enumerate(range(0, lr1.shape[0], chunk)):
+        if cache1 is None:
+            o = build_SpatialNet(spatial_net, lr1[s:s + chunk], lr2[s:s + chunk])
+            a1, a2 = o['motion1'], o['motion2']
+        else:
+            f64_2, f32_2 = spatial_net.trunk_features([lr2[s:s + chunk]])
+            off = spatial_net.forward_pair(cache1[i][0], f64_2, cache1[i][1], f32_2, LR_H, LR_W)
+            a1, a2 = ops.spatial_meshes(off[0], off[1], off[2], LR_H, LR_W)
+        m1.append(a1)
+        m2.append(a2)
     return torch.cat(m1, 0), torch.cat(m2, 0)
 
 
@@ -91,7 +99,7 @@ SHARED_STEM = os.environ.get('SS_SHARED_STEM', '1') == '1'
 
 
 @torch.no_grad()
-def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None):
+def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None, cache2=None):
     """SpatialNet and TemporalNet of a 2-view clip in one sweep: both nets start with the same 7x7/2 conv + pool on the
     same LR frames (spatial_network.py:127-130 and temporal_network.py:47-50 build identical stems), so the stem runs
     ONCE with 2 x 64 filters and each net continues from its half of the channels.
@@ -111,7 +119,11 @@ def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None):
         e = min(s + chunk, n)
         b = e - s
         xa, xb = L.run_stem_shared([lr1[s:e], lr2[s:e]], sp[key])
-        off1, off_ref, off_tgt = spatial_net.forward_features(L.run_trunk_body(xa, sp['s1']), b, LR_H, LR_W)
+        f64 = L.run_trunk_body(xa, sp['s1'])
+        f32 = L.run_stage2(f64, sp['s2'])
+        off1, off_ref, off_tgt = spatial_net.forward_pair(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
+        if cache2 is not None:                    # view 2's trunk features, for a later pair that starts with this view
+            cache2.append((f64[b:], f32[b:]))
         a1, a2 = ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W)
         m1.append(a1)
         m2.append(a2)
@@ -133,7 +145,7 @@ def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None):
 
 
 @torch.no_grad()
-def estimate_meshes(nets, lr1, lr2, tmotion1=None):
+def estimate_meshes(nets, lr1, lr2, tmotion1=None, spatial_cache1=None, keep_spatial_cache2=False):
     """Stages 1-3 of test() (test_online_tra.py:284-392) for one clip.
     lr1, lr2: [N,3,360,480] device tensors (or lists of [1,3,360,480]).
     -> dict(smooth_mesh1/2, ori_mesh1/2 [1,N,7,9,2], ori_path2, smooth_path2 stitched as test_metric_ssd.py:433-436)."""
@@ -145,6 +157,7 @@ def estimate_meshes(nets, lr1, lr2, tmotion1=None):
     n = lr1.shape[0]
     if n < WINDOW:
         raise ValueError('need at least %d frames for the sliding smooth window, got %d' % (WINDOW, n))
+    cache2 = [] if keep_spatial_cache2 else None
     if OVERLAP_STREAMS:
         # SpatialNet and TemporalNet are independent until tsmotion: run them on two HIP streams so that the
         # partially filled last round of one net's kernels is topped up with the other's workgroups
@@ -157,10 +170,11 @@ def estimate_meshes(nets, lr1, lr2, tmotion1=None):
         main.wait_stream(side)
         for t in (t1, t2):
             t.record_stream(main)
-    elif SHARED_STEM and tmotion1 is None:      # (with view 1's motions known, half of a shared stem would be wasted)
-        s1, s2, t1, t2 = joint_stage(spatial_net, temporal_net, lr1, lr2)
+    elif SHARED_STEM and tmotion1 is None and spatial_cache1 is None:
+        # (with view 1's motions / features known, half of a shared stem would be wasted)
+        s1, s2, t1, t2 = joint_stage(spatial_net, temporal_net, lr1, lr2, cache2=cache2)
     else:
-        s1, s2 = spatial_stage(spatial_net, lr1, lr2)
+        s1, s2 = spatial_stage(spatial_net, lr1, lr2, cache1=spatial_cache1)
         if tmotion1 is None:
             t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
         else:
@@ -182,6 +196,8 @@ def estimate_meshes(nets, lr1, lr2, tmotion1=None):
     out['smooth_path2'] = smooth_path.unsqueeze(0)
     out['smotion1'], out['smotion2'], out['tmotion1'], out['tmotion2'] = s1, s2, t1, t2
     out['tsmotion1'], out['tsmotion2'] = tsm1, tsm2
+    if cache2:
+        out['spatial_cache2'] = cache2
     return out
 
 
@@ -296,8 +312,9 @@ def three_view_render(img1, img2, img3, mesh1, middle, mesh3, warp_mode='NORMAL'
 
 @torch.no_grad()
 def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE'):
-    a12 = estimate_meshes(nets, lr1, lr2)
-    a23 = estimate_meshes(nets, lr2, lr3, tmotion1=a12['tmotion2'])     # the middle view's TemporalNet pass is shared
+    # the middle view's TemporalNet motions and SpatialNet trunk features are computed once and reused by pair (2,3)
+    a12 = estimate_meshes(nets, lr1, lr2, keep_spatial_cache2=True)
+    a23 = estimate_meshes(nets, lr2, lr3, tmotion1=a12['tmotion2'], spatial_cache1=a12.get('spatial_cache2'))
     img_h, img_w = hr1[0].shape[-2:]
     m1, mid, m3 = three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'],
                                      a23['smooth_mesh2'], img_h, img_w)

@@ -80,16 +80,30 @@ class SpatialNet(L.PreparedMixin, nn.Module):
     @torch.no_grad()
     def forward_features(self, f64, b, img_h, img_w):
         """Everything after the stage-1 trunk: f64 nhwc [2B,45,60,128] (view 1 first) -> the three offsets."""
+        f32 = L.run_stage2(f64, self._prepared()['s2'])    # [2B,23,30,256]
+        return self.forward_pair(f64[:b], f64[b:], f32[:b], f32[b:], img_h, img_w)
+
+    @torch.no_grad()
+    def trunk_features(self, x_list):
+        """Stage-1 and stage-2 features of NCHW inputs (they depend on the image alone, so a view that takes part in two
+        pairs -- the middle view of a three-view rig -- needs them once) -> (f64 [n,45,60,128], f32 [n,23,30,256])."""
         p = self._prepared()
-        f32 = L.run_stage2(f64, p['s2'])                   # [2B,23,30,256]
+        f64 = L.run_stage1(list(x_list), p['s1'])
+        return f64, L.run_stage2(f64, p['s2'])
+
+    @torch.no_grad()
+    def forward_pair(self, f64_1, f64_2, f32_1, f32_2, img_h, img_w):
+        """Both views' trunk features (each [B,...]) -> the three offsets (spatial_network.py:291-331)."""
+        p = self._prepared()
+        b = f64_1.shape[0]
         # stage 1: contextual correlation -> global homography offsets
-        _, flow = ops.ccl(f32[:b], f32[b:], 10.0, want_nchw=False, want_nhwc4=True)
+        _, flow = ops.ccl(f32_1, f32_2, 10.0, want_nchw=False, want_nhwc4=True)
         offset_1 = L.run_regressor(flow, p['r1'])
         # bidirectional decomposition at 1/8 scale, warp both feature maps onto the middle plane
         th_ref, th_tgt = ops.spatial_decompose(offset_1, img_h, img_w)
         fh, fw = int(img_h / 8), int(img_w / 8)
-        w1 = ops.homo_warp_nhwc(f64[:b], th_ref, fh, fw)
-        w2 = ops.homo_warp_nhwc(f64[b:], th_tgt, fh, fw)
+        w1 = ops.homo_warp_nhwc(f64_1, th_ref, fh, fw)
+        w2 = ops.homo_warp_nhwc(f64_2, th_tgt, fh, fw)
         # stage 2: local cost volumes in both directions -> residual mesh motions
         cv = torch.empty((2, b, fh, fw, 124), device=w1.device, dtype=torch.float32)
         ops.cost_volume(w1, w2, 5, out=cv[0])
