@@ -304,7 +304,9 @@ def main():
                      'algorithmic_bytes_per_launch': round(conv_bytes / max(conv_n, 1)),
                      'avg_launch_us': round(conv_ms * 1e3 / max(conv_n, 1), 2),
                      'kernel_ms_per_step': round(conv_ms, 3),
-                     'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5)},
+                     'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5),
+                     # whole path against the MFMA roof: 41.31 GFLOP of dense contraction per 2-view frame
+                     'path_mfma_frac': round(fps / world * 41.31e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if args.views == 2 else None},
     }
     if world == 1 and not args.no_cpu_baseline and args.views == 2 and not args.online:
         threads = max(1, min(args.cpu_threads, os.cpu_count()))
@@ -324,6 +326,17 @@ def main():
             d = np.abs(g[0][0].permute(1, 2, 0).cpu().numpy() - cout[0][0])
             par['frame0_median_abs'] = round(float(np.median(d)), 6)
             par['frame0_p999_abs'] = round(float(np.quantile(d, 0.999)), 6)
+        # alignment PSNR / SSIM (test_metric_ssd.py:513-527) of the first frames from both sides, each with its own meshes
+        from oracle import metrics as OM
+        from stabstitch2_amd import metrics as GM
+        k = min(4, n)
+        lr_cpu = lr0.cpu()              # same frames as the meshes were estimated from
+        c1 = OM.warp_lr_with_mask([lr_cpu[0, i:i + 1] for i in range(k)], cout[3][:, :k])
+        c2 = OM.warp_lr_with_mask([lr_cpu[1, i:i + 1] for i in range(k)], cout[4][:, :k])
+        cps = [OM.alignment_psnr_ssim(a, b) for a, b in zip(c1, c2)]
+        gp, gs = GM.alignment_psnr_ssim(GM.warp_lr_planes(lr0[0][:k], g[3][:, :k]), GM.warp_lr_planes(lr0[1][:k], g[4][:, :k]))
+        par['alignment_psnr_delta_db'] = round(max(abs(float(gp[i]) - cps[i][0]) for i in range(k)), 5)
+        par['alignment_ssim_delta'] = round(max(abs(float(gs[i]) - cps[i][1]) for i in range(k)), 6)
         result['parity_vs_cpu'] = par
     print(json.dumps(result))
     if dist is not None:
