@@ -137,9 +137,12 @@ def cpu_baseline(sds, frames, height, width, threads):
     lr2 = [lr[1, i:i + 1] for i in range(frames)]
     t0 = time.perf_counter()
     with torch.no_grad():
-        out = OP.run_two_view(hr1, hr2, lr1, lr2, nets, 'NORMAL', 'AVERAGE')
-    dt = time.perf_counter() - t0
-    return frames / dt, out
+        acc = OP.estimate_meshes(nets, lr1, lr2)                        # SpatialNet, TemporalNet, tsmotion, SmoothNet
+        t1 = time.perf_counter()
+        fr, wc, hc = OP.get_stable_sqe(hr1, hr2, acc['smooth_mesh1'], acc['smooth_mesh2'], 'NORMAL', 'AVERAGE')
+    t2 = time.perf_counter()
+    out = (fr, int(hc), int(wc), acc['smooth_mesh1'], acc['smooth_mesh2'])
+    return frames / (t2 - t0), out, {'estimate_meshes_s': round(t1 - t0, 2), 'warp_and_fuse_s': round(t2 - t1, 2)}
 
 
 def main():
@@ -310,13 +313,14 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline and args.views == 2 and not args.online:
         threads = max(1, min(args.cpu_threads, os.cpu_count()))
-        cfps, cout = cpu_baseline(sds, args.cpu_frames, args.height, args.width, threads)
+        cfps, cout, csplit = cpu_baseline(sds, args.cpu_frames, args.height, args.width, threads)
         result['cpu_baseline'] = {'value': round(cfps, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
                                   'sample': '%d-frame %dx%d 2-view clip (seed 0), NORMAL/AVERAGE, oracle/ on PyTorch-CPU'
                                             % (args.cpu_frames, args.height, args.width)}
         # parity at benchmark time: same clip through the HIP path
         n = args.cpu_frames
         result['cpu_baseline']['host_logical_cpus'] = os.cpu_count()
+        result['cpu_baseline']['stage_seconds'] = csplit
         hr0, lr0 = synth.make_clip_device(n, args.height, args.width, seed=0, device=dev)
         g = pipeline.run_two_view(hr0[0], hr0[1], lr0[0], lr0[1], nets, args.warp_mode, args.fusion_mode)
         dm = max(float((g[3].cpu() - cout[3]).abs().max()), float((g[4].cpu() - cout[4]).abs().max()))
