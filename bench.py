@@ -2,17 +2,22 @@
 """Benchmark of the StabStitch++ inference hot path on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          # self-launches 8 ranks (one per GPU) over RCCL
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" = one 2-view clip of `--frames` synthetic 720x1280 frames through the whole path (SpatialNet, TemporalNet x2,
 tsmotion, sliding SmoothNet windows, canvas, TPS warp + AVERAGE fusion; warp NORMAL -- the defaults of the reference's
 StabStitch-D script, test_online_ssd.py:440-444), inputs resident in HBM, outputs left in HBM.  One clip per rank
-(independent video pairs: no data-path collective); a single all_gather of per-rank records at the end.
-Prints ONE JSON line (see DESIGN.md "Measurement").
+(independent video pairs, seed = rank: no data-path collective); a single all_gather of per-rank records at the end.
+Prints ONE JSON line (see DESIGN.md "Measurement").  At N=1 the line also carries the other BASELINE.json
+configurations (`other_configs`), the CPU oracle baseline with its per-stage split, and benchmark-time parity.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
+import sys
 import time
 
 import torch
@@ -21,13 +26,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+PMC_PROFILE = os.path.join('profiles', 'r02_pmc_hbm.json')
 
 
 def build_nets(dev):
-    from stabstitch2_amd import synth
+    """The three networks on `dev`: real checkpoints when the reference's `Full_model_inference/full_model_{tra,ssd}/`
+    (or $SS_MODEL_DIR) holds the three *.pth files (test_online_tra.py:173-194), else the deterministic synthetic
+    checkpoints of stabstitch2_amd/synth.py.  -> (nets, state_dicts)."""
+    from stabstitch2_amd import synth, pipeline
     from stabstitch2_amd.spatial_network import SpatialNet
     from stabstitch2_amd.temporal_network import TemporalNet
     from stabstitch2_amd.smooth_network import SmoothNet
+    model_dir = os.environ.get('SS_MODEL_DIR') or pipeline.find_model_dir(ROOT)
+    if model_dir:
+        nets = pipeline.load_nets(model_dir, dev)
+        build_nets.weights = 'pretrained (%s)' % model_dir
+        return list(nets), [{k: v.detach().cpu() for k, v in m.state_dict().items()} for m in nets]
+    build_nets.weights = 'synthetic checkpoints'
     nets, sds = [], []
     for cls in (SpatialNet, TemporalNet, SmoothNet):
         m = cls()
@@ -38,8 +53,11 @@ def build_nets(dev):
     return nets, sds
 
 
+build_nets.weights = 'synthetic checkpoints'
+
+
 class ConvProbe:
-    """HIP-event timing of every ss_conv_nhwc launch (the dominant kernel family) on the launch stream."""
+    """HIP-event timing of every conv-engine launch (the dominant kernel family) on the launch stream."""
 
     def __init__(self):
         self.records = []
@@ -47,81 +65,68 @@ class ConvProbe:
 
     def install(self):
         from stabstitch2_amd import ops
-        orig = ops.conv
         probe = self
 
-        def timed_conv(x, wgt, *a, **k):
-            if not probe.active:
-                return orig(x, wgt, *a, **k)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(x, wgt, *a, **k)
-            e1.record()
-            m = out.numel() // out.shape[-1]
-            cout, kt, kh, kw, cin = wgt.shape
-            # algorithmic MACs use the channels that carry data (zero-padded taps excluded)
-            res = k.get('res')
-            nbytes = 4 * (x.numel() + wgt.numel() + out.numel() + (res.numel() if res is not None else 0))
-            probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes))
-            return out
-        ops.conv = timed_conv
-        orig_g = ops.conv_grouped
-
-        def timed_conv_grouped(x, wgt, *a, **k):
-            if not probe.active:
-                return orig_g(x, wgt, *a, **k)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_g(x, wgt, *a, **k)
-            e1.record()
-            g, cout, kt, kh, kw, cin = wgt.shape
-            m = out.numel() // out.shape[-1]              # rows of all groups together
-            res = k.get('res')
-            nbytes = 4 * (x.numel() + wgt.numel() + out.numel() + (res.numel() if res is not None else 0))
-            probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes))
-            return out
-        ops.conv_grouped = timed_conv_grouped
+        def wrap(orig, grouped):
+            def timed(x, wgt, *a, **k):
+                if not probe.active:
+                    return orig(x, wgt, *a, **k)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(x, wgt, *a, **k)
+                e1.record()
+                cout, kt, kh, kw, cin = wgt.shape[-5:]
+                m = out.numel() // out.shape[-1]              # rows (of all groups together)
+                res = k.get('res')
+                nbytes = 4 * (x.numel() + wgt.numel() + out.numel() + (res.numel() if res is not None else 0))
+                stride = k.get('stride', 1)
+                probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes, ops.conv_executed_flop_ratio(
+                    kt, kh, kw, stride, cin, cout, out.shape)))
+                return out
+            return timed
+        ops.conv = wrap(ops.conv, False)
+        ops.conv_grouped = wrap(ops.conv_grouped, True)
         from stabstitch2_amd import layers, smooth_network
         layers.ops = ops
         smooth_network.ops = ops
 
+    @staticmethod
+    def _real_cin(cin, taps):
+        # algorithmic MACs use the channels that carry data (zero-padded taps excluded)
+        if cin == 4 and taps == 9:
+            return 2          # CCL flow (dx, dy) regressor input
+        return {4: 3, 124: 121, 52: 49}.get(cin, cin)
+
     def report(self):
-        real_cin = {4: 3, 124: 121, 52: 49}
         agg = {}
-        for e0, e1, m, cout, taps, cin, nbytes in self.records:
-            c = real_cin.get(cin, cin)
-            if cin == 4 and taps == 9:
-                c = 2
+        for e0, e1, m, cout, taps, cin, nbytes, xr in self.records:
             key = (m, cout, taps, cin)
             a = agg.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1)
-            a[2] += 2.0 * m * cout * taps * c
-        import sys
+            a[2] += 2.0 * m * cout * taps * self._real_cin(cin, taps)
         print('%10s %5s %5s %5s %4s %9s %9s %7s' % ('M', 'cout', 'taps', 'cin', 'n', 'ms', 'GFLOP', 'TF/s'), file=sys.stderr)
         for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print('%10d %5d %5d %5d %4d %9.3f %9.2f %7.1f' % (key + (a[0], a[1], a[2] / 1e9, a[2] / a[1] / 1e9)),
                   file=sys.stderr)
 
     def summary(self):
-        real_cin = {4: 3, 124: 121, 52: 49}
-        tot_ms, tot_flop, n, tot_bytes = 0.0, 0.0, 0, 0.0
-        for e0, e1, m, cout, taps, cin, nbytes in self.records:
-            ms = e0.elapsed_time(e1)
-            c = real_cin.get(cin, cin)
-            if cin == 4 and taps == 9:
-                c = 2      # CCL flow (dx, dy) regressor input
-            tot_ms += ms
-            tot_flop += 2.0 * m * cout * taps * c
+        """-> (ms, direct-conv-equivalent flop, launches, algorithmic bytes, executed MFMA flop)."""
+        tot_ms, tot_flop, n, tot_bytes, tot_exec = 0.0, 0.0, 0, 0.0, 0.0
+        for e0, e1, m, cout, taps, cin, nbytes, xr in self.records:
+            tot_ms += e0.elapsed_time(e1)
+            f = 2.0 * m * cout * taps * self._real_cin(cin, taps)
+            tot_flop += f
+            tot_exec += f * xr
             tot_bytes += nbytes
             n += 1
-        return tot_ms, tot_flop, n, tot_bytes
+        return tot_ms, tot_flop, n, tot_bytes, tot_exec
 
 
 def cpu_baseline(sds, frames, height, width, threads):
-    """The CPU oracle (a from-scratch PyTorch-CPU port of the reference path) on a bounded sample of the workload."""
+    """The CPU oracle (a from-scratch PyTorch-CPU port of the reference path) on a bounded sample of the workload,
+    with the per-stage split BASELINE.md 3 names (spatial / temporal / tsmotion / smooth / warp+blend)."""
     from oracle import nets as ON, pipeline as OP
     from stabstitch2_amd import synth
     torch.set_num_threads(threads)
@@ -131,21 +136,53 @@ def cpu_baseline(sds, frames, height, width, threads):
         m.load_state_dict(sd, strict=True)
         nets.append(m)
     hr, lr = synth.make_clip_device(frames, height, width, seed=0, device='cpu')
-    hr1 = [hr[0, i:i + 1] for i in range(frames)]
-    hr2 = [hr[1, i:i + 1] for i in range(frames)]
-    lr1 = [lr[0, i:i + 1] for i in range(frames)]
-    lr2 = [lr[1, i:i + 1] for i in range(frames)]
-    t0 = time.perf_counter()
+    sl = lambda t: [t[i:i + 1] for i in range(frames)]
+    hr1, hr2, lr1, lr2 = sl(hr[0]), sl(hr[1]), sl(lr[0]), sl(lr[1])
+    st = {}
     with torch.no_grad():
-        acc = OP.estimate_meshes(nets, lr1, lr2)                        # SpatialNet, TemporalNet, tsmotion, SmoothNet
+        t0 = time.perf_counter()
+        s1, s2 = OP.spatial_stage(nets[0], lr1, lr2)
         t1 = time.perf_counter()
+        tm1, tm2 = OP.temporal_stage(nets[1], lr1), OP.temporal_stage(nets[1], lr2)
+        t2 = time.perf_counter()
+        smesh1, tsm1 = OP.tsmotion_prepare(s1, tm1)
+        smesh2, tsm2 = OP.tsmotion_prepare(s2, tm2)
+        t3 = time.perf_counter()
+        acc = OP.smooth_stage(nets[2], tsm1, tsm2, smesh1, smesh2)
+        t4 = time.perf_counter()
         fr, wc, hc = OP.get_stable_sqe(hr1, hr2, acc['smooth_mesh1'], acc['smooth_mesh2'], 'NORMAL', 'AVERAGE')
-    t2 = time.perf_counter()
+        t5 = time.perf_counter()
+    st = {'spatial_s': round(t1 - t0, 2), 'temporal_s': round(t2 - t1, 2), 'tsmotion_s': round(t3 - t2, 2),
+          'smooth_s': round(t4 - t3, 2), 'warp_blend_s': round(t5 - t4, 2)}
     out = (fr, int(hc), int(wc), acc['smooth_mesh1'], acc['smooth_mesh2'])
-    return frames / (t2 - t0), out, {'estimate_meshes_s': round(t1 - t0, 2), 'warp_and_fuse_s': round(t2 - t1, 2)}
+    return frames / (t5 - t0), out, st
 
 
-def main():
+def cpu_thread_sweep(sds, height, width, candidates):
+    """Seconds for one SpatialNet pair + one two-image TPS warp per thread count; -> (best, {threads: seconds}).
+    BASELINE.md 3 names os.cpu_count() threads; on the 2 x 64-core GPU hosts fewer threads are faster for these
+    small-batch CPU convolutions, so the sample runs with the fastest of the candidates and the sweep is reported."""
+    from oracle import nets as ON, samplers as OS, geometry as OG
+    from stabstitch2_amd import synth
+    sp = ON.SpatialNet().eval()
+    sp.load_state_dict(sds[0], strict=True)
+    hr, lr = synth.make_clip_device(1, height, width, seed=0, device='cpu')
+    nr = OG.norm_mesh(OG.rigid_mesh(1, height, width), height, width)
+    src = torch.cat((nr, nr), 0)
+    img = torch.cat((hr[0, 0:1], hr[1, 0:1]), 0)
+    res = {}
+    with torch.no_grad():
+        for th in candidates:
+            torch.set_num_threads(th)
+            ON.build_SpatialNet(sp, lr[0, 0:1], lr[1, 0:1])            # warm
+            t0 = time.perf_counter()
+            ON.build_SpatialNet(sp, lr[0, 0:1], lr[1, 0:1])
+            OS.tps_warp(img, src, src, (height, width), 'NORMAL')
+            res[th] = round(time.perf_counter() - t0, 3)
+    return min(res, key=res.get), res
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -158,33 +195,189 @@ def main():
     ap.add_argument('--warp_mode', default='NORMAL')
     ap.add_argument('--fusion_mode', default='AVERAGE')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=48)
-    ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the other BASELINE.json configurations')
+    ap.add_argument('--cpu-frames', type=int, default=24)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='0 = short sweep over {cpu_count, 64, 32, 16}')
     ap.add_argument('--conv-report', action='store_true')
     ap.add_argument('--io', default='f32', choices=('f32', 'u8', 'u8host'),
                     help="f32: fp32 frames resident in HBM (the headline metric); u8: uint8 frames resident, ingest + "
                          "uint8 sink inside the step; u8host: uint8 frames in pinned host memory, H2D + D2H inside the step")
-    args = ap.parse_args()
+    ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'), help='nccl = RCCL over xGMI; gloo for the CPU launcher test')
+    ap.add_argument('--stub-step-ms', type=float, default=0.0,
+                    help='launcher self-test without GPUs: every step is a sleep of this many ms (backend gloo)')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) under torch.distributed.run on
+    this node and hand them the same command line; rank 0 prints the JSON line."""
+    if not args.stub_step_ms:
+        assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit('--gpus %d but only %d GPU(s) visible on this node' % (args.gpus, have))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def measure(step, sync, warmup, steps):
+    """warm-up, then `steps` timed calls bracketed by sync(); -> (seconds, last result)."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    return time.perf_counter() - t0, out
+
+
+def other_configs(nets, dev, args):
+    """The remaining BASELINE.json configurations and I/O variants on this GPU, a few steps each (same build, same
+    process): fps, ms per step, canvas.  The headline `value` stays configs[2]."""
+    from stabstitch2_amd import synth, pipeline
+    from stabstitch2_amd.online import OnlineStitcher
+    res = {}
+    sync = torch.cuda.synchronize
+
+    def entry(name, frames_per_step, seconds, steps, hc, wc, note=None):
+        res[name] = {'fps': round(frames_per_step * steps / seconds, 1), 'ms_per_step': round(seconds / steps * 1e3, 3),
+                     'frames_per_step': frames_per_step, 'steps': steps, 'canvas': [int(hc), int(wc)]}
+        if note:
+            res[name]['note'] = note
+
+    # configs[1]: 360x480 2-view, 64-frame clip
+    hr, lr = synth.make_clip_device(64, 360, 480, seed=0, device=dev)
+    dt, o = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets), sync, 2, 5)
+    entry('configs[1] 360x480 2-view 64-frame clip', 64, dt, 5, o[1], o[2])
+    # 720p clip shared by the 720p variants
+    n = args.frames
+    hr, lr = synth.make_clip_device(n, 720, 1280, seed=0, views=3, device=dev)
+    # configs[4]: 3-view 720p (two 2-view passes + composition + 3-image render)
+    dt, o = measure(lambda: pipeline.run_three_view(hr[0], hr[1], hr[2], lr[0], lr[1], lr[2], nets), sync, 1, 3)
+    entry('configs[4] 720p 3-view', n, dt, 3, o[1], o[2])
+    # fusion LINEAR (default of test_online_tra.py), warp FAST
+    dt, o = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets, 'NORMAL', 'LINEAR'), sync, 1, 3)
+    entry('720p 2-view fusion LINEAR', n, dt, 3, o[1], o[2])
+    dt, o = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets, 'FAST', 'AVERAGE'), sync, 1, 3)
+    entry('720p 2-view warp FAST', n, dt, 3, o[1], o[2])
+    # host-to-host: uint8 frames in pinned host memory -> stitched uint8 frames in pinned host memory (H2D + ingest +
+    # path + uint8 sink + D2H of every fused frame, as the reference's printed fps includes .cpu())
+    u8 = [hr[v].permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).contiguous().cpu().pin_memory() for v in range(2)]
+    runner = pipeline.HostClipRunner(nets, dev)
+
+    def host_steps(k):
+        last = None
+        for last in runner.run((u8[0], u8[1]) for _ in range(k)):
+            pass
+        return last
+    host_steps(2)
+    sync()
+    t0 = time.perf_counter()
+    last = host_steps(4)
+    sync()
+    entry('720p 2-view uint8 host->host incl. D2H of every fused frame', n, time.perf_counter() - t0, 4, last[1], last[2],
+          'PCIe both ways (5.5 MB in + 3.1 MB out per frame), copies overlapped with compute on three HIP streams')
+    # synchronous variant: fp32 fused frames copied to the host after every clip (the reference's .cpu() per frame)
+    def step_d2h():
+        o = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets)
+        o[0].cpu()
+        return o
+    dt, o = measure(step_d2h, sync, 1, 3)
+    entry('720p 2-view fp32 resident in, fp32 frames D2H (blocking .cpu())', n, dt, 3, o[1], o[2])
+    # streaming, batch 1, HIP graph steady state
+    pushes = 96
+    def stream_once():
+        st = OnlineStitcher(nets, 720, 1280)
+        out = None
+        for t in range(pushes):
+            i = t % n
+            got = st.push(hr[0][i:i + 1], hr[1][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1])
+            if got:
+                out = got[-1]
+        return out, st.hc, st.wc
+    dt, o = measure(stream_once, sync, 1, 2)
+    entry('720p 2-view streaming (batch 1, one pair per push)', pushes, dt, 2, o[1], o[2])
+    return res
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args, argv))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)'
-                         % (args.gpus, world, args.gpus))
-    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    stub = args.stub_step_ms > 0
     dist = None
+    if stub:
+        dev = torch.device('cpu')
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+        if args.backend == 'nccl' and not stub:
+            dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group('gloo')
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            if not stub:
+                torch.cuda.synchronize()
+
+    from stabstitch2_amd import dist as ssdist
+    if stub:
+        # launcher / gather self-test (tests/test_host_logic.py): same control flow, the step is a sleep
+        for _ in range(args.warmup):
+            time.sleep(args.stub_step_ms * 1e-3)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(args.stub_step_ms * 1e-3 * (1 + rank))
+        sync()
+        dt = time.perf_counter() - t0
+        rec = torch.tensor([float(args.frames * args.steps), dt, 0.0, 0.0, float(rank)], dtype=torch.float64)
+        allrec = ssdist.gather_records(rec, dist, None)
+        if rank == 0:
+            print(json.dumps({'metric': 'launcher self-test (stubbed step)', 'value': round(ssdist.aggregate_fps(allrec), 3),
+                              'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': round(float(allrec[:, 1].max()) / args.steps * 1e3, 3), 'scaling': 'weak',
+                              'ranks': dist.get_world_size() if dist is not None else 1, 'backend': 'gloo',
+                              'per_rank_seconds': [round(float(x), 4) for x in allrec[:, 1]],
+                              'clip_seeds': [int(x) for x in allrec[:, 4]]}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from stabstitch2_amd import synth, pipeline, _hip
     _hip.lib()
     torch.set_grad_enabled(False)
     nets, sds = build_nets(dev)
+    # configs[3]: rank r stitches its own clip (seed = rank): N distinct video pairs on N GPUs
     hr, lr = synth.make_clip_device(args.frames, args.height, args.width, seed=rank, views=args.views, device=dev)
     probe = ConvProbe()
     probe.install()
@@ -230,12 +423,6 @@ def main():
                                            args.fusion_mode)[:3]
         return pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets, args.warp_mode, args.fusion_mode)
 
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     if runner is not None:
         if args.warmup:
             steps_host(args.warmup)
@@ -262,8 +449,7 @@ def main():
         torch.cuda.synchronize()
     frames_out, hc, wc = out[0], out[1], out[2]
 
-    from stabstitch2_amd import dist as ssdist
-    rec = torch.tensor([float(args.frames * args.steps), dt, float(hc), float(wc)], dtype=torch.float64)
+    rec = torch.tensor([float(args.frames * args.steps), dt, float(hc), float(wc), float(rank)], dtype=torch.float64)
     allrec = ssdist.gather_records(rec, dist, dev)            # the only collective: result gather
     if rank != 0:
         if dist is not None:
@@ -272,18 +458,19 @@ def main():
     tmax = float(allrec[:, 1].max())
     fps = ssdist.aggregate_fps(allrec)
 
-    conv_ms, conv_flop, conv_n, conv_bytes = probe.summary()
+    conv_ms, conv_flop, conv_n, conv_bytes, conv_exec = probe.summary()
     if args.conv_report:
         probe.report()
-    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    executed = conv_exec / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    equivalent = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # algorithmic HBM bytes per stitched frame: fp32 frames in, fp32 canvas out, weights once
     io_bytes = args.views * (3 * args.height * args.width + 3 * 360 * 480) * 4 + 3 * hc * wc * 4 + 70.6e6
-    # HBM bytes per conv launch from the committed PMC passes of this same command (profiles/r01_pmc_hbm.json;
-    # FETCH_SIZE / WRITE_SIZE cannot be read live from inside the process)
+    # HBM bytes per conv launch: STATIC, from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE
+    # are profiler counters and cannot be read from inside the process)
     traffic = None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')) as f:
-            traffic = json.load(f)['kernels']['conv_igemm_kernel']['hbm_bytes_per_launch']
+        with open(os.path.join(ROOT, PMC_PROFILE)) as f:
+            traffic = json.load(f)['conv_family']['hbm_bytes_per_launch']
     except Exception:
         pass
     result = {
@@ -292,18 +479,25 @@ def main():
         'ms_per_step': round(tmax / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %dx%d %d-view, %d-frame clip per step per GPU, 7-frame SmoothWarp sliding '
-                               'window, warp %s / fusion %s, synthetic checkpoints' % (
+                               'window, warp %s / fusion %s, %s' % (
                                    ('streaming (batch 1) ' if args.online else '') + ('' if args.io == 'f32' else '[io=%s] ' % args.io) +
-                                   ('configs[4]' if args.views == 3 else ('configs[2]' if args.height == 720 else 'configs[1]')),
-                                   args.height, args.width, args.views, args.frames, args.warp_mode, args.fusion_mode),
+                                   ('configs[4]' if args.views == 3 else ('configs[2]' if args.height == 720 else 'configs[1]'))
+                                   + (' x %d GPUs = configs[3]' % world if world > 1 else ''),
+                                   args.height, args.width, args.views, args.frames, args.warp_mode, args.fusion_mode,
+                                   build_nets.weights),
                    'frames_per_step': args.frames, 'canvas': [int(hc), int(wc)], 'parallelism': 'streams%d' % world,
                    'published_reference': '28.3 fps on 1x RTX 4090 at 360x480 (README.md:30); different resolution '
                                           'and hardware, not comparable'},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<WM,WN> (fp32 implicit-GEMM conv, %d launches/clip)'
-                     % conv_n, 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
-                     'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm.json)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv engine: conv_igemm_kernel / conv_wino_kernel (fp32 MFMA, %d launches/clip)'
+                     % conv_n, 'achieved': round(executed, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                     'achieved_is': 'EXECUTED MFMA flop (Winograd F(2x2,3x3) layers count 16/36 of their direct-conv '
+                                    'flop) / summed launch durations (HIP events)',
+                     'direct_conv_equivalent_tflops': round(equivalent, 3),
+                     'traffic': traffic, 'traffic_source': 'static: %s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this '
+                                                           'command), not measured in this run' % PMC_PROFILE,
                      'algorithmic_flop_per_launch': round(conv_flop / max(conv_n, 1)),
+                     'executed_flop_per_launch': round(conv_exec / max(conv_n, 1)),
                      'algorithmic_bytes_per_launch': round(conv_bytes / max(conv_n, 1)),
                      'avg_launch_us': round(conv_ms * 1e3 / max(conv_n, 1), 2),
                      'kernel_ms_per_step': round(conv_ms, 3),
@@ -311,16 +505,31 @@ def main():
                      # whole path against the MFMA roof: 41.31 GFLOP of dense contraction per 2-view frame
                      'path_mfma_frac': round(fps / world * 41.31e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if args.views == 2 else None},
     }
-    if world == 1 and not args.no_cpu_baseline and args.views == 2 and not args.online:
-        threads = max(1, min(args.cpu_threads, os.cpu_count()))
+    if world > 1:
+        result['ranks'] = dist.get_world_size()
+        result['backend'] = 'rccl' if args.backend == 'nccl' else args.backend
+        result['per_rank_seconds'] = [round(float(x), 4) for x in allrec[:, 1]]
+        result['clip_seeds'] = [int(x) for x in allrec[:, 4]]
+    base = world == 1 and args.views == 2 and not args.online and args.io == 'f32'
+    if base and not args.no_other_configs:
+        result['other_configs'] = other_configs(nets, dev, args)
+    if base and not args.no_cpu_baseline:
+        ncpu = os.cpu_count() or 1
+        if args.cpu_threads > 0:
+            threads, sweep = max(1, min(args.cpu_threads, ncpu)), None
+        else:
+            threads, sweep = cpu_thread_sweep(sds, args.height, args.width, sorted({ncpu, min(64, ncpu), min(32, ncpu), min(16, ncpu)}))
         cfps, cout, csplit = cpu_baseline(sds, args.cpu_frames, args.height, args.width, threads)
         result['cpu_baseline'] = {'value': round(cfps, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
                                   'sample': '%d-frame %dx%d 2-view clip (seed 0), NORMAL/AVERAGE, oracle/ on PyTorch-CPU'
-                                            % (args.cpu_frames, args.height, args.width)}
+                                            % (args.cpu_frames, args.height, args.width),
+                                  'host_logical_cpus': ncpu, 'stage_seconds': csplit}
+        if sweep is not None:
+            result['cpu_baseline']['thread_sweep_seconds'] = {str(k): v for k, v in sweep.items()}
+            result['cpu_baseline']['thread_sweep_sample'] = '1 SpatialNet pair + 1 two-image TPS warp per thread count; ' \
+                                                            'the clip sample runs with the fastest'
         # parity at benchmark time: same clip through the HIP path
         n = args.cpu_frames
-        result['cpu_baseline']['host_logical_cpus'] = os.cpu_count()
-        result['cpu_baseline']['stage_seconds'] = csplit
         hr0, lr0 = synth.make_clip_device(n, args.height, args.width, seed=0, device=dev)
         g = pipeline.run_two_view(hr0[0], hr0[1], lr0[0], lr0[1], nets, args.warp_mode, args.fusion_mode)
         dm = max(float((g[3].cpu() - cout[3]).abs().max()), float((g[4].cpu() - cout[4]).abs().max()))

@@ -21,6 +21,13 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the entry points declared here are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#define SS_API __attribute__((visibility("default")))
+#else
+#define SS_API
+#endif
+
 #define SS_OK 0
 #define SS_ERR_ARG (-1)          /* bad dimension / null pointer / unsupported combination */
 #define SS_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch */
@@ -29,14 +36,14 @@ extern "C" {
 #define SS_WARP_NORMAL 0         /* the reference's clamped-index bilinear (utils/torch_tps_transform.py:30-106) */
 #define SS_WARP_FAST 1           /* F.grid_sample(bilinear, zeros, align_corners=True) (:158-162) */
 
-int ss_version(void);
-const char* ss_error_string(int code);
+SS_API int ss_version(void);
+SS_API const char* ss_error_string(int code);
 
 /* ---- layout plumbing (replaces the implicit NCHW tensors of the reference modules) ---------- */
 /* [n][c][h][w] -> [n][h][w][c_pad], channels c..c_pad-1 written as 0 */
-int ss_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream);
+SS_API int ss_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream);
 /* [n][h][w][c_stride] (first c channels) -> [n][c][h][w] */
-int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, int c_stride, void* stream);
+SS_API int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, int c_stride, void* stream);
 
 /* ---- K1/K2/K4/K11: convolution as fp32-MFMA implicit GEMM ------------------------------------
  * Replaces nn.Conv2d(+BatchNorm2d eval)(+residual)(+ReLU) of the ResNet-18 trunk
@@ -48,95 +55,101 @@ int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, int
  *   out  [n][to][ho][wo][out_cs]      first cout channels written (out_cs >= cout)
  * stride applies to h and w (temporal stride is 1); kernel extents <= 8 per axis.  `groups` > 1 runs
  * `groups` independent problems with element strides in_gs / w_gs / out_gs between them (used by the
- * CCL Gram).  ws / ws_floats: optional caller workspace for split-K partial sums of small problems
- * (ss_conv_workspace_floats() is always enough; NULL disables splitting). */
-long long ss_conv_workspace_floats(void);
-int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const float* res, float* out,
+ * CCL Gram).  ws / ws_floats: caller workspace for the split-K partial sums of small problems;
+ * ss_conv_workspace_need(...) returns the floats THIS launch wants (0 for most: no split); a NULL or
+ * smaller workspace disables splitting (same result up to summation order, fewer workgroups). */
+SS_API long long ss_conv_workspace_need(int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
+                                 int stride, int pad_t, int pad_h, int pad_w, int groups);
+SS_API int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const float* res, float* out,
                  int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw, int stride,
                  int pad_t, int pad_h, int pad_w, int relu, int out_cs,
                  int groups, long long in_gs, long long w_gs, long long out_gs,
                  float* ws, long long ws_floats, void* stream);
 
 /* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */
-int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
+SS_API int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
                     void* stream);
 /* same pooling, channels [0,c/2) -> out0 and [c/2,c) -> out1 (both [n][ho][wo][c/2]; c % 8 == 0): lets the SpatialNet and
  * TemporalNet stems (identical 7x7 s2 conv + pool on the same frames) share one conv1 launch with 2x64 filters */
-int ss_maxpool_nhwc_split(const float* in, float* out0, float* out1, int n, int h, int w, int c, int k, int stride,
+SS_API int ss_maxpool_nhwc_split(const float* in, float* out0, float* out1, int n, int h, int w, int c, int k, int stride,
                           int pad, void* stream);
 
 /* K5: nn.Linear (+ReLU): y[m][nout] = x[m][k] . w[nout][k] + b  (spatial_network.py:170-178, 211-219) */
-int ss_linear(const float* x, const float* w, const float* b, float* y, int m, int k, int nout, int relu,
+SS_API int ss_linear(const float* x, const float* w, const float* b, float* y, int m, int k, int nout, int relu,
               void* stream);
 
 /* ---- K3: contextual correlation layer (spatial_network.py:369-425) ---------------------------
  * f1, f2 nhwc [n][h][w][c]; flow out NCHW [n][2][h][w] (ch0 = dx, ch1 = dy).
  * ws: caller workspace of ss_ccl_workspace_floats(n,h,w,c) floats. */
-long long ss_ccl_workspace_floats(int n, int h, int w, int c);
-int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float* flow_nhwc4, int n, int h, int w, int c,
+SS_API long long ss_ccl_workspace_floats(int n, int h, int w, int c);
+SS_API int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float* flow_nhwc4, int n, int h, int w, int c,
            float softmax_scale, float* ws, void* stream);
+
+/* F.normalize(x, p=2, dim=channels) on nhwc: out[p][:] = in[p][:] / max(||in[p][:]||_2, 1e-12)
+ * (first step of CCL, spatial_network.py:372-373, and of cost_volume(norm=True), spatial_network.py:335-337) */
+SS_API int ss_l2norm_nhwc(const float* in, float* out, long long n_pixels, int c, void* stream);
 
 /* ---- K8: cost volume (spatial_network.py:333-358, temporal_network.py:149-174) ---------------
  * x1, x2 nhwc [n][h][w][c]; out nhwc [n][h][w][out_cs], channel j*(2r+1)+i, channels >= (2r+1)^2
  * written as 0.  out[.,y,x,d] = leaky_relu_0.1(mean_c x1[y,x,c] * x2[y+j-r, x+i-r, c]). */
-int ss_cost_volume(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
+SS_API int ss_cost_volume(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
                    int out_cs, void* stream);
 
 /* ---- K6: 4-point DLT, bidirectional decomposition, H -> mesh (fp64 on device) -----------------
  * ss_tensor_dlt: utils/torch_DLT.py:17-45; src, dst [n][4][2] -> H [n][3][3]. */
-int ss_tensor_dlt(const float* src, const float* dst, float* H, int n, void* stream);
+SS_API int ss_tensor_dlt(const float* src, const float* dst, float* H, int n, void* stream);
 /* spatial_network.py:291-312: offset_1 [n][8] at image size (img_h, img_w), feature scale 8 ->
  * normalised homographies theta_ref = M^-1 H_ref M, theta_tgt = M^-1 H_tgt M, each [n][3][3]. */
-int ss_spatial_decompose(const float* offset8, float* theta_ref, float* theta_tgt, int n, float img_h,
+SS_API int ss_spatial_decompose(const float* offset8, float* theta_ref, float* theta_tgt, int n, float img_h,
                          float img_w, void* stream);
 /* spatial_network.py:63-118 (build_SpatialNet tail): offset_1 [n][8], offset_2_ref/tgt [n][126] ->
  * motion1, motion2 [n][7][9][2] (mesh - rigid). */
-int ss_spatial_meshes(const float* offset8, const float* off_ref, const float* off_tgt, float* motion1,
+SS_API int ss_spatial_meshes(const float* offset8, const float* off_ref, const float* off_tgt, float* motion1,
                       float* motion2, int n, float img_h, float img_w, void* stream);
 
 /* ---- K7: homography sampler (utils/torch_homo_transform.py:6-184) ----------------------------
  * theta [n][3][3]; nhwc variant for the 1/8 feature maps, nchw variant = the reference API. */
-int ss_homo_warp_nhwc(const float* in, const float* theta, float* out, int n, int h, int w, int c,
+SS_API int ss_homo_warp_nhwc(const float* in, const float* theta, float* out, int n, int h, int w, int c,
                       int out_h, int out_w, void* stream);
-int ss_homo_warp_nchw(const float* in, const float* theta, float* out, int n, int c, int h, int w,
+SS_API int ss_homo_warp_nchw(const float* in, const float* theta, float* out, int n, int c, int h, int w,
                       int out_h, int out_w, void* stream);
 
 /* ---- K9/K10: thin-plate spline (utils/torch_tps_transform.py:168-226,
  *      utils/torch_tps_transform_point.py:21-125) -------------------------------------------- */
 /* source, target [n][63][2] (normalised) -> T [n][2][66]; fp32 kernel matrix, fp64 solve. */
-int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream);
+SS_API int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream);
 /* point [n][q][2] evaluated through (source, T) -> out [n][q][2] */
-int ss_tps_points(const float* point, const float* source, const float* T, float* out, int n, int q,
+SS_API int ss_tps_points(const float* point, const float* source, const float* T, float* out, int n, int q,
                   void* stream);
 /* test_online_tra.py:309-347 for one view, all frames at once: smotion, tmotion [n][63][2] (LR px)
  * -> smesh [n][63][2] = rigid + smotion, tsmotion [n][63][2] (frame 0 = 0).
  * ws: ss_tsmotion_workspace_floats(n) floats. */
-long long ss_tsmotion_workspace_floats(int n);
-int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
+SS_API long long ss_tsmotion_workspace_floats(int n);
+SS_API int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
                 float img_h, float img_w, float* ws, void* stream);
 
 /* ---- K12/K13: dense TPS warp and fusion (utils/torch_tps_transform.py:108-165,
  *      test_online_tra.py:34-58, 138-150) ----------------------------------------------------- */
 /* generic: U [b][c][h][w] NCHW, source [b][63][2], T [b][2][66] -> out [b][c][hc][wc] */
-int ss_tps_warp_nchw(const float* U, const float* source, const float* T, float* out, int b, int c, int h,
+SS_API int ss_tps_warp_nchw(const float* U, const float* source, const float* T, float* out, int b, int c, int h,
                      int w, int hc, int wc, int mode, void* stream);
 /* same, plus one extra output channel = warp of an all-ones plane (the validity mask of
  * test_online_tra.py:144-147): out [b][c+1][hc][wc] */
-int ss_tps_warp_mask_nchw(const float* U, const float* source, const float* T, float* out, int b, int c,
+SS_API int ss_tps_warp_mask_nchw(const float* U, const float* source, const float* T, float* out, int b, int c,
                           int h, int w, int hc, int wc, int mode, void* stream);
 /* all views of one frame in one launch, per-view image pointers (host array of `views` <= 3 device pointers to
  * [3][h][w]); out [views][4][hc][wc] = 3 colour planes + ones-mask plane (test_online_tra.py:144-147) */
-int ss_tps_warp_views(const float* const* imgs, const float* source, const float* T, float* out, int views,
+SS_API int ss_tps_warp_views(const float* const* imgs, const float* source, const float* T, float* out, int views,
                       int h, int w, int hc, int wc, int mode, void* stream);
 /* fused render of one stitched frame, AVERAGE fusion, 2 or 3 views (chained (1+2)+3):
  * imgs: array of `views` device pointers (host array) to [3][h][w]; source [views][63][2];
  * T [views][2][66]; out [3][hc][wc]. */
-int ss_render_average(const float* const* imgs, const float* source, const float* T, float* out, int views,
+SS_API int ss_render_average(const float* const* imgs, const float* source, const float* T, float* out, int views,
                       int h, int w, int hc, int wc, int mode, void* stream);
 /* LINEAR fusion (linear_blender): ref, tgt [3][hc][wc]; ref_m, tgt_m [hc][wc]; out [3][hc][wc];
  * mask1_out optional [hc][wc]; ws: ss_linear_blend_workspace_floats(hc, wc) floats. */
-long long ss_linear_blend_workspace_floats(int hc, int wc);
-int ss_linear_blend(const float* ref, const float* tgt, const float* ref_m, const float* tgt_m, float* out,
+SS_API long long ss_linear_blend_workspace_floats(int hc, int wc);
+SS_API int ss_linear_blend(const float* ref, const float* tgt, const float* ref_m, const float* tgt_m, float* out,
                     float* mask1_out, int hc, int wc, float* ws, void* stream);
 
 /* ---- K14: canvas bounding box and mesh normalisation (test_online_tra.py:103-136) ------------
@@ -144,10 +157,10 @@ int ss_linear_blend(const float* ref, const float* tgt, const float* ref_m, cons
  * does (x*img_w/480, y*img_h/360) before the min/max; img_w <= 0 / img_h <= 0 means the mesh is
  * already in canvas pixels (three-view second canvas).  bbox (device) [4] = wmin, wmax, hmin, hmax;
  * accumulate != 0 folds the existing bbox contents in (second view, more clips). */
-int ss_mesh_bbox(const float* mesh, int n_points, float img_h, float img_w, float* bbox, int accumulate,
+SS_API int ss_mesh_bbox(const float* mesh, int n_points, float img_h, float img_w, float* bbox, int accumulate,
                  void* stream);
 /* out = norm(scale(mesh) - (wmin,hmin); Hc_f, Wc_f) with the float canvas size read from bbox on device */
-int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_points, float img_h,
+SS_API int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_points, float img_h,
                       float img_w, void* stream);
 
 /* ---- K11: SmoothNet glue (smooth_network.py:64-157) ------------------------------------------
@@ -157,20 +170,20 @@ int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_po
  * zero_first != 0 the first tsmotion of every window counts as 0 (test_online_tra.py:362-366).
  * embed: hidden nhwc [nw][t][7][9][128] =
  *        relu(E1 smesh1) | relu(E3 tsflow1) | relu(E1 smesh2) | relu(E3 tsflow2);  e1w,e3w [32][2]; e1b,e3b [32]. */
-int ss_smooth_embed(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+SS_API int ss_smooth_embed(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
                     const float* e1w, const float* e1b, const float* e3w, const float* e3b, float* hidden,
                     int nw, int t, int wstride, int zero_first, void* stream);
 /* finalize: delta [nw][t][63][4] (decoder output) -> the 8 tensors of build_SmoothNet, each
  * [nw][t][63][2]; any output pointer may be NULL. */
-int ss_smooth_finalize(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+SS_API int ss_smooth_finalize(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
                        const float* delta, float* ori_mesh1, float* ori_mesh2, float* ori_path1,
                        float* ori_path2, float* smooth_mesh1, float* smooth_mesh2, float* smooth_path1,
                        float* smooth_path2, int nw, int t, int wstride, int zero_first, void* stream);
 
 /* canvas-sized elementwise helpers of the harnesses: out = (in + add) * mul  ((img+1)*127.5,
  * test_metric_ssd.py:166);  out = a + b - a*b  (three-view mask union, test_online_tra_threeview.py:501) */
-int ss_add_mul(const float* in, float* out, float add, float mul, long long n, void* stream);
-int ss_mask_union(const float* a, const float* b, float* out, long long n, void* stream);
+SS_API int ss_add_mul(const float* in, float* out, float add, float mul, long long n, void* stream);
+SS_API int ss_mask_union(const float* a, const float* b, float* out, long long n, void* stream);
 
 /* ---- frame I/O either side of the path ----------------------------------
  * ss_ingest_u8 replaces the per-frame host code of test_online_tra.py:252-278: `frames` is DEVICE uint8
@@ -183,22 +196,22 @@ int ss_mask_union(const float* a, const float* b, float* out, long long n, void*
  * oracle/frame_io.py.
  * ss_canvas_to_u8 replaces `stable_list[k].astype(np.uint8)` (:413): [n][3][h][w] fp32 -> uint8 [n][h][w][3]
  * (truncation toward zero, low 8 bits of the int32 value outside 0..255). */
-int ss_ingest_u8(const unsigned char* frames, float* hr, float* lr, int n, int h, int w, int lr_h, int lr_w,
+SS_API int ss_ingest_u8(const unsigned char* frames, float* hr, float* lr, int n, int h, int w, int lr_h, int lr_w,
                  void* stream);
-int ss_canvas_to_u8(const float* canvas, unsigned char* out, int n, int h, int w, void* stream);
+SS_API int ss_canvas_to_u8(const float* canvas, unsigned char* out, int n, int h, int w, void* stream);
 
 /* ---- metric harness (test_metric_ssd.py:444-482, 513-527) -------------------------------------
  * w1, w2: [frames][4][h][w] = 3 colour planes (0..255) + validity-mask plane, as ss_tps_warp_mask_nchw
  * writes them.  out (device, fp64) [frames][2] = alignment PSNR (dB), SSIM of (w1*ov, w2*ov), ov = m1*m2,
  * computed in fp64 with scikit-image 0.15 compare_psnr / compare_ssim semantics (data_range 255, 7x7
  * uniform window, multichannel).  ws: 2*frames doubles. */
-int ss_alignment_psnr_ssim(const float* w1, const float* w2, double* out, double* ws, int frames, int h,
+SS_API int ss_alignment_psnr_ssim(const float* w1, const float* w2, double* out, double* ws, int frames, int h,
                            int w, void* stream);
 /* path [t][63][2] (stitched smooth path of view 2) -> out[0] = stability score (test_metric_ssd.py:459-468) */
-int ss_stability_score(const float* path, float* out, int t, void* stream);
+SS_API int ss_stability_score(const float* path, float* out, int t, void* stream);
 /* mesh [t][7][9][2] (LR px) -> out[0] = max over frames of inter + intra grid loss (:38-87, 473-482);
  * ws: t floats */
-int ss_distortion_score(const float* mesh, float* out, float* ws, int t, void* stream);
+SS_API int ss_distortion_score(const float* mesh, float* out, float* ws, int t, void* stream);
 
 #ifdef __cplusplus
 }

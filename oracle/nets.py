@@ -76,8 +76,13 @@ def _regress_fc(fin, h1, h2, fout):
 
 
 # --------------------------------------------------------------------------- correlation ops
-def cost_volume(x1, x2, search_range):
-    """cv[j*K+i, y, x] = leaky_relu_0.1( mean_c x1[c,y,x] * x2[c, y+j-r, x+i-r] ), zero outside."""
+def cost_volume(x1, x2, search_range, norm=False):
+    """cv[j*K+i, y, x] = leaky_relu_0.1( mean_c x1[c,y,x] * x2[c, y+j-r, x+i-r] ), zero outside
+    (spatial_network.py:333-358; norm=True L2-normalises both maps over channels first, :335-337 -- the signature's
+    default, which the inference path overrides with norm=False at both call sites)."""
+    if norm:
+        x1 = F.normalize(x1, p=2, dim=1)
+        x2 = F.normalize(x2, p=2, dim=1)
     r = search_range
     k = 2 * r + 1
     b, c, h, w = x1.shape

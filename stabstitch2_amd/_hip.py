@@ -23,13 +23,14 @@ SIGNATURES = {
     'ss_error_string': (ctypes.c_char_p, [c_i]),
     'ss_nchw_to_nhwc': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
-    'ss_conv_workspace_floats': (c_ll, []),
+    'ss_conv_workspace_need': (c_ll, [c_i] * 14),
     'ss_conv_nhwc': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 15 + [c_i, c_ll, c_ll, c_ll, c_fp, c_ll, c_st]),
     'ss_maxpool_nhwc': (c_i, [c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_maxpool_nhwc_split': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_linear': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     'ss_ccl_workspace_floats': (c_ll, [c_i, c_i, c_i, c_i]),
     'ss_ccl': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp, c_st]),
+    'ss_l2norm_nhwc': (c_i, [c_fp, c_fp, c_ll, c_i, c_st]),
     'ss_cost_volume': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_tensor_dlt': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
     'ss_spatial_decompose': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
@@ -89,23 +90,66 @@ def check(code, what):
         raise HipError('%s failed: %s (%d)' % (what, lib().ss_error_string(code).decode(), code))
 
 
+class DevPtr(ctypes.c_void_p):
+    """Device pointer that remembers which GPU it lives on (so that `call` can pick that GPU's stream)."""
+    dev = None
+
+
+class _CurrentStream:
+    """Placeholder for "the current HIP stream of the device the pointer arguments live on"; resolved by `call`."""
+
+
+_STREAM = _CurrentStream()
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM
 
 
-def dptr(t, allow_none=False):
-    """Device pointer of a contiguous fp32 device tensor."""
+def dptr(t, allow_none=False, dtype=torch.float32):
+    """Device pointer of a contiguous device tensor of `dtype` (fp32 unless stated)."""
     if t is None:
         if allow_none:
             return None
         raise ValueError('null tensor passed to a HIP kernel')
     if not t.is_cuda:
         raise HipError('stabstitch2_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
-    if t.dtype != torch.float32 or not t.is_contiguous():
-        raise HipError('stabstitch2_amd kernels need contiguous float32 tensors (got %s, contiguous=%s)'
-                       % (t.dtype, t.is_contiguous()))
-    return ctypes.c_void_p(t.data_ptr())
+    if t.dtype != dtype or not t.is_contiguous():
+        raise HipError('stabstitch2_amd kernels need contiguous %s tensors (got %s, contiguous=%s)'
+                       % (str(dtype).replace('torch.', ''), t.dtype, t.is_contiguous()))
+    p = DevPtr(t.data_ptr())
+    p.dev = t.device.index
+    return p
+
+
+def ptr_array(tensors):
+    """`const float* const*` argument: array of device pointers (all tensors checked like `dptr`); carries the device."""
+    ps = [dptr(t) for t in tensors]
+    arr = (ctypes.c_void_p * len(ps))(*[p.value for p in ps])
+    arr.dev = ps[0].dev
+    if any(p.dev != arr.dev for p in ps):
+        raise HipError('tensors of one launch live on different GPUs')
+    return arr
 
 
 def call(name, *args):
-    check(getattr(lib(), name)(*args), name)
+    """Launch on the GPU that owns the pointer arguments, on THAT device's current stream (not the current device's):
+    nets moved to cuda:1 keep working while cuda:0 is current, and launches stay ordered with the torch ops that
+    produced their inputs."""
+    dev = None
+    for a in args:
+        d = getattr(a, 'dev', None)
+        if d is not None:
+            if dev is None:
+                dev = d
+            elif d != dev:
+                raise HipError('%s: tensors of one launch live on different GPUs (cuda:%d and cuda:%d)' % (name, dev, d))
+    fn = getattr(lib(), name)
+    if dev is None:                          # no device pointers (workspace queries, version)
+        return check(fn(*args), name)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    args = tuple(st if a is _STREAM else a for a in args)
+    if dev == torch.cuda.current_device():
+        return check(fn(*args), name)
+    with torch.cuda.device(dev):
+        return check(fn(*args), name)

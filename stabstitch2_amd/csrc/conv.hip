@@ -30,8 +30,6 @@
 //   instructions (out-of-range offsets for rows >= M), all residual loads in flight before the first use.
 //   Small problems (few tiles, long K) are split along K into `splits` partial sums written to a caller
 //   workspace and combined (deterministically) by splitk_reduce_kernel.
-#include <stdlib.h>
-
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,9 +56,19 @@ struct ConvP {
     unsigned ntiles;                 // Cout tiles (grid.x = M tiles * ntiles)
     long long in_gs, w_gs, out_gs;
     unsigned in_bytes, w_bytes;      // per-group extents for the buffer descriptors
-    unsigned long long* dbg;         // tuning aid (ss_debug_ptr): per-workgroup phase timestamps, or nullptr
-    int ablate;                      // tuning aid (SS_CONV_ABLATE): 8 = row-major tile order instead of XCD-aware
+#ifdef SS_TUNING                     // tools/ build only (csrc/build.sh tuning): never in the shipped library
+    unsigned long long* dbg;         // ss_debug_ptr: per-workgroup phase timestamps, or nullptr
+    int ablate;                      // ss_debug_set key 1: 8 = row-major tile order instead of XCD-aware, 32 = no setprio
+#endif
 };
+
+#ifdef SS_TUNING
+#define SS_ABLATE(p, bit) ((p).ablate & (bit))
+#define SS_STAMP(p, var) do { if ((p).dbg) var = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SS_ABLATE(p, bit) 0
+#define SS_STAMP(p, var) do { } while (0)
+#endif
 
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base, unsigned bytes) {
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     {
         const unsigned nwg = gridDim.x, b = blockIdx.x;
         unsigned lin = b;
-        if (!(p.ablate & 8) && nwg >= 16) {
+        if (!SS_ABLATE(p, 8) && nwg >= 16) {
             const unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
             lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
@@ -107,9 +115,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     // Waves outside the K loop (row setup, epilogue) issue only VALU / memory instructions; beside 6 waves that keep the
     // MFMA pipe busy they would get one issue slot per 64-cycle MFMA and take longer than the K loop itself (measured:
     // 31k + 44k cycles around a 75k-cycle loop).  Raised priority lets them through.
-    if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(3);
+    if (!SS_ABLATE(p, 32)) __builtin_amdgcn_s_setprio(3);
+#ifdef SS_TUNING
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsa = 0, tsb = 0, tsc = 0;
-    if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
+#endif
+    SS_STAMP(p, ts0);
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int grp = (int)ss_div32(blockIdx.z, p.divSplits);
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         }
         rowinfo[tid] = make_uint4((unsigned)aoff, msk, inv_lo, inv_hi);
     }
-    if (p.dbg) tsa = __builtin_amdgcn_s_memtime();
+    SS_STAMP(p, tsa);
     unsigned w_off[RB], w_bad[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         a_inv_lo[i] = ri.z;
         a_inv_hi[i] = ri.w;
     }
-    if (p.dbg) tsb = __builtin_amdgcn_s_memtime();
+    SS_STAMP(p, tsb);
     unsigned wk[RB];             // table mode: running byte offset of each filter row's next K tile
 #pragma unroll
     for (int i = 0; i < RB; ++i) wk[i] = w_off[i] + (unsigned)(kt0 * BK + kq * 4) * 4u;
@@ -324,12 +334,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 
     if (kt0 < kt1) {
         gload(kt0);
-        if (p.dbg) tsc = __builtin_amdgcn_s_memtime();
+        SS_STAMP(p, tsc);
         lstore(0);
     }
     __syncthreads();
-    if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
-    if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(0);
+    SS_STAMP(p, ts1);
+    if (!SS_ABLATE(p, 32)) __builtin_amdgcn_s_setprio(0);
     // main loop: straight-line body (no branches) so that hipcc can interleave the next tile's address arithmetic and
     // loads with the MFMAs; the last tile is peeled (nothing to prefetch, and only it can be a partial K tile)
     int kt = kt0;
@@ -357,8 +367,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         }
     }
 
-    if (p.dbg) ts2 = __builtin_amdgcn_s_memtime();
-    if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(3);
+    SS_STAMP(p, ts2);
+    if (!SS_ABLATE(p, 32)) __builtin_amdgcn_s_setprio(3);
     // epilogue: bias (folded BatchNorm), residual, ReLU.  Branch free and without waits between the 16 rows a lane
     // owns: offsets of rows past M / channels past Cout are forced out of range (buffer loads return 0, stores are
     // dropped), all residual loads are issued before the first use and all stores after the last.  (The first
@@ -399,12 +409,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
             }
         }
     }
+#ifdef SS_TUNING
     if (p.dbg && tid == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
         d[5] = tsa; d[6] = tsb; d[7] = tsc;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
         d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
+#endif
 }
 
 // out[m][co] = relu(sum_s partial[s][m][co] + bias[co] + res[m][co]); fixed summation order
@@ -425,7 +437,27 @@ __global__ void splitk_reduce_kernel(ConvP p) {
     p.out[o] = v;
 }
 
-static int g_lds_pad = 0;           // ss_debug_set key 4: extra dynamic LDS bytes per workgroup (occupancy experiments)
+// Tuning knobs: compile-time constants in the shipped library; the tools/ build (-DSS_TUNING) turns them into variables
+// behind ss_debug_set / ss_debug_ptr (not part of the ABI, not declared in include/stabstitch_hip.h).
+#ifdef SS_TUNING
+static int g_lds_pad = 0;           // key 4: extra dynamic LDS bytes per workgroup (occupancy experiments)
+static int g_amode_off = 0;         // key 3: 1 = arithmetic addressing, 2 = table without the aligned fast path
+static int g_force_tile = 0;        // key 0: force a tile variant
+static int g_ablate = 0;            // key 1: ablation mask
+static int g_split_target = 512;    // key 2: workgroups a split-K launch aims for
+static unsigned long long* g_dbg = nullptr;
+extern "C" SS_API void ss_debug_ptr(void* ptr) { g_dbg = (unsigned long long*)ptr; }
+extern "C" SS_API void ss_debug_set(int key, int value) {
+    if (key == 0) g_force_tile = value;
+    if (key == 1) g_ablate = value;
+    if (key == 2) g_split_target = value;
+    if (key == 3) g_amode_off = value;
+    if (key == 4) g_lds_pad = value;
+}
+#else
+constexpr int g_lds_pad = 0, g_amode_off = 0, g_force_tile = 0;
+constexpr int g_split_target = 512;     // measured best (tools/ab_splitk.py)
+#endif
 
 template <int WGM, int WGN, int WM, int WN, int NBUF, int MINW = 1, int BK = 32, bool TAIL = false, int SCHED = 0,
           int AMODE = 0>
@@ -439,8 +471,6 @@ static void launch_conv(const ConvP& p, int groups, hipStream_t st, unsigned dyn
     hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, WM, WN, NBUF, MINW, BK, TAIL, SCHED, AMODE>), g, dim3(256),
                        dyn_lds + (unsigned)g_lds_pad, st, q);
 }
-
-static int g_amode_off = 0;         // ss_debug_set key 3: 1 = arithmetic addressing instead of the LDS tap table
 
 // Address mode: per-block tap table in LDS (8 bytes per 4 k of the block's K range) when the filter has <= 64 taps
 // and the table stays small; otherwise the arithmetic path (three divisions per K tile per thread).  `tail` selects
@@ -464,21 +494,29 @@ static void launch_auto(const ConvP& p, int groups, hipStream_t st, int taps, bo
     }
 }
 
-// tuning aids, not part of the public ABI: key 0 = force tile variant, key 1 = ablation mask
-static int g_force_tile = getenv("SS_CONV_TILE") ? atoi(getenv("SS_CONV_TILE")) : 0;
-static int g_ablate = getenv("SS_CONV_ABLATE") ? atoi(getenv("SS_CONV_ABLATE")) : 0;
-static int g_split_target = 512;    // workgroups a split-K launch aims for (key 2); 512 measured best (tools/ab_splitk.py)
-static unsigned long long* g_dbg = nullptr;
-extern "C" void ss_debug_ptr(void* ptr) { g_dbg = (unsigned long long*)ptr; }
-extern "C" void ss_debug_set(int key, int value) {
-    if (key == 0) g_force_tile = value;
-    if (key == 1) g_ablate = value;
-    if (key == 2) g_split_target = value;
-    if (key == 3) g_amode_off = value;      // 1: arithmetic addressing, 2: table without the aligned fast path
-    if (key == 4) g_lds_pad = value;
+// Split-K plan of a launch (shared by ss_conv_workspace_need and ss_conv_nhwc): small problems (few tiles, long K) are
+// cut along K so that ~g_split_target workgroups exist.  -> number of splits (1 = none).
+static int conv_splits(long long M, int cout, int groups, int nk) {
+    long long b64 = (long long)ss_cdiv(M, 64) * ss_cdiv(cout, 64) * groups;
+    int want = (int)((g_split_target + b64 - 1) / b64);
+    int maxs = nk / 4 > 0 ? nk / 4 : 1;
+    int splits = want < maxs ? want : maxs;
+    if (splits <= 1) return 1;
+    const int tps = ss_cdiv(nk, splits);
+    return ss_cdiv(nk, tps);
 }
 
-extern "C" long long ss_conv_workspace_floats(void) { return 16ll << 20; }   // 64 MiB of split-K partials
+extern "C" long long ss_conv_workspace_need(int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
+                                            int stride, int pad_t, int pad_h, int pad_w, int groups) {
+    if (n <= 0 || t <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
+        groups <= 0)
+        return 0;
+    const int To = t + 2 * pad_t - kt + 1, Ho = (h + 2 * pad_h - kh) / stride + 1, Wo = (w + 2 * pad_w - kw) / stride + 1;
+    if (To <= 0 || Ho <= 0 || Wo <= 0) return 0;
+    const long long M = (long long)n * To * Ho * Wo, K = (long long)kt * kh * kw * cin;
+    const int splits = conv_splits(M, cout, groups, ss_cdiv(K, 32));
+    return splits > 1 ? (long long)groups * splits * M * cout : 0;
+}
 
 extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const float* res, float* out,
                             int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw, int stride,
@@ -520,8 +558,10 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     const int nk = ss_cdiv(K, 32);
     p.splits = 1;
     p.tiles_per_split = nk;
+#ifdef SS_TUNING
     p.ablate = g_ablate;
     p.dbg = g_dbg;
+#endif
 
     // Tile choice.  Measured on MI355X (tools/ab_conv.py, interleaved in-process A/B on the layer shapes of the pipeline):
     // 64x64 with ONE 18 KB LDS buffer is the best or equal-best tile on every shape except large launches with
@@ -543,11 +583,8 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     } else {
         // default: 64x64 tiles, single LDS buffer; small problems are additionally split along K so that ~512
         // workgroups exist
-        long long b64 = (long long)ss_cdiv(M, 64) * ss_cdiv(cout, 64) * groups;
-        int want = (int)((g_split_target + b64 - 1) / b64);
-        int maxs = nk / 4 > 0 ? nk / 4 : 1;
-        int splits = want < maxs ? want : maxs;
-        long long need = (long long)groups * splits * M * cout;
+        const int splits = conv_splits(M, cout, groups, nk);
+        const long long need = (long long)groups * splits * M * cout;
         if (splits > 1 && ws && need <= ws_floats && need < (1ll << 31)) {
             p.tiles_per_split = ss_cdiv(nk, splits);
             p.splits = ss_cdiv(nk, p.tiles_per_split);
@@ -763,7 +800,7 @@ extern "C" int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h,
     return ss_launch_status();
 }
 
-extern "C" int ss_version(void) { return 100; }
+extern "C" int ss_version(void) { return 200; }
 
 extern "C" const char* ss_error_string(int code) {
     switch (code) {

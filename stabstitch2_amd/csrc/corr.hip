@@ -150,6 +150,12 @@ __global__ void l2norm_kernel(const float* __restrict__ in, float* __restrict__ 
     for (int i = lane; i < c; i += 64) out[pix * c + i] = p[i] / d;
 }
 
+extern "C" int ss_l2norm_nhwc(const float* in, float* out, long long n_pixels, int c, void* stream) {
+    if (!in || !out || n_pixels <= 0 || c <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(n_pixels, 4)), dim3(256), 0, (hipStream_t)stream, in, out, n_pixels, c);
+    return ss_launch_status();
+}
+
 // one wave per query position p
 __global__ void ccl_softmax_kernel(const float* __restrict__ Dm, float* __restrict__ flow_nchw,
                                    float* __restrict__ flow_nhwc4, int h, int w, float scale) {

@@ -95,8 +95,13 @@ def pack_fc(lin):
     return lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous()
 
 
+_version_counter = [0]
+
+
 class PreparedMixin:
-    """Lazy, invalidating cache of repacked weights."""
+    """Lazy, invalidating cache of repacked weights.  `weights_version` changes whenever the parameters may have
+    changed (load_state_dict, .to(), .cuda(), ...): caches DERIVED from two nets' prepared weights (shared stems, twin
+    trunks, captured HIP graphs) are keyed on the versions of both and rebuilt on a mismatch."""
 
     def _prepared(self):
         dev = next(self.parameters()).device
@@ -107,8 +112,21 @@ class PreparedMixin:
             object.__setattr__(self, '_prep_cache', cache)
         return cache[1]
 
+    @property
+    def weights_version(self):
+        v = getattr(self, '_weights_version', None)
+        if v is None:
+            v = self._bump()
+        return v
+
+    def _bump(self):
+        _version_counter[0] += 1
+        object.__setattr__(self, '_weights_version', _version_counter[0])
+        return _version_counter[0]
+
     def _invalidate(self):
         object.__setattr__(self, '_prep_cache', None)
+        self._bump()
 
     def load_state_dict(self, *a, **k):
         self._invalidate()
@@ -199,8 +217,17 @@ def prep_regressor(convs, fcs, last_c, last_hw):
     return {'convs': cw, 'fc': [pack_fc_first(lin[0], last_c, last_hw), pack_fc(lin[1]), pack_fc(lin[2])]}
 
 
-def run_regressor(x, p):
+# The regressors and the SmoothNet windows run in batch chunks: one conv launch addresses its input with 32-bit byte
+# offsets (< 2 GiB per group, ss_conv_nhwc returns SS_ERR_UNSUPPORTED beyond), and the reference handles clips of any
+# length frame by frame.  512 cost volumes of 45x60x124 floats are 0.69 GB.
+REG_CHUNK = int(os.environ.get('SS_REG_CHUNK', '512'))
+
+
+def run_regressor(x, p, chunk=None):
     """x nhwc; pairs of 3x3 conv+ReLU then 2x2 max-pool; NHWC flatten; 3 FC."""
+    chunk = chunk or REG_CHUNK
+    if x.shape[0] > chunk:
+        return torch.cat([run_regressor(x[s:s + chunk], p, chunk) for s in range(0, x.shape[0], chunk)], 0)
     for i, w in enumerate(p['convs']):
         x = ops.conv(x, w, None, stride=1, pad=(0, 1, 1), relu=True)
         if i & 1:
@@ -220,10 +247,14 @@ def pair_regressors(pa, pb):
             'fc': (pa['fc'], pb['fc'])}
 
 
-def run_regressor_pair(x, pp):
+def run_regressor_pair(x, pp, chunk=None):
     """x [2,n,h,w,c] nhwc (one input per regressor) -> (out_a, out_b): the eight convs of both regressors run as
     eight grouped launches instead of sixteen, the pools on the joint batch; the FC stacks stay per regressor."""
     g, n = x.shape[0], x.shape[1]
+    chunk = chunk or REG_CHUNK
+    if n > chunk:
+        parts = [run_regressor_pair(x[:, s:s + chunk].contiguous(), pp, chunk) for s in range(0, n, chunk)]
+        return [torch.cat([pt[k] for pt in parts], 0) for k in range(g)]
     for i, w in enumerate(pp['convs']):
         x = ops.conv_grouped(x, w, None, None, stride=1, pad=(0, 1, 1), relu=True)
         if i & 1:

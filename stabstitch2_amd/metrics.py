@@ -40,8 +40,8 @@ def alignment_psnr_ssim(w1, w2):
     assert c == 4 and w2.shape == w1.shape
     out = torch.empty((n, 2), device=w1.device, dtype=torch.float64)
     ws = torch.empty((n, 2), device=w1.device, dtype=torch.float64)
-    H.call('ss_alignment_psnr_ssim', H.dptr(w1), H.dptr(w2), ctypes.c_void_p(out.data_ptr()),
-           ctypes.c_void_p(ws.data_ptr()), n, h, w, H.stream())
+    H.call('ss_alignment_psnr_ssim', H.dptr(w1), H.dptr(w2), H.dptr(out, dtype=out.dtype),
+           H.dptr(ws, dtype=ws.dtype), n, h, w, H.stream())
     return out[:, 0], out[:, 1]
 
 

@@ -20,6 +20,16 @@ from . import ops, pipeline
 from .spatial_network import build_SpatialNet, get_rigid_mesh, get_norm_mesh
 
 WINDOW = pipeline.WINDOW
+_warmup = {}
+
+
+def _warmup_stream(dev):
+    """One capture warm-up stream per device, shared by every stitcher."""
+    s = _warmup.get(dev)
+    if s is None:
+        s = torch.cuda.Stream(dev)
+        _warmup[dev] = s
+    return s
 
 
 class OnlineStitcher:
@@ -44,6 +54,7 @@ class OnlineStitcher:
         self.static = None               # steady-state buffers (inputs, rings, output) once the window is full
         self.graph = None
         self.trunk_pair = None
+        self.trunk_versions = None
 
     def _set_canvas(self):
         bb = self.bbox.cpu()
@@ -80,6 +91,7 @@ class OnlineStitcher:
         # launch per layer for both (12 launches fewer per pushed pair)
         if self.trunk_pair is None:
             self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
+            self.trunk_versions = self._versions()
         f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)            # [2(net),2(view),45,60,128]
         off1, off_ref, off_tgt = self.spatial.forward_features(f2[0], 1, pipeline.LR_H, pipeline.LR_W)
         m1s, m2s = ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W)
@@ -98,8 +110,16 @@ class OnlineStitcher:
         m1, m2 = outs['smooth_mesh1'][0], outs['smooth_mesh2'][0]
         st['out'].copy_(self._render(st['hr1'], st['hr2'], m1[-1:], m2[-1:]))
 
+    def _versions(self):
+        return (self.spatial.weights_version, self.temporal.weights_version, self.smooth.weights_version)
+
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static
+        if self.trunk_pair is not None and self.trunk_versions != self._versions():
+            # a net was reloaded / moved since the twin trunk was stacked and the graph captured: both hold the OLD
+            # weights (the graph by address); rebuild and recapture instead of silently stitching with stale filters
+            self.trunk_pair = None
+            self.graph = None
         st['hr1'].copy_(hr1.reshape(st['hr1'].shape)); st['hr2'].copy_(hr2.reshape(st['hr2'].shape))
         st['lr1'].copy_(lr1.reshape(st['lr1'].shape)); st['lr2'].copy_(lr2.reshape(st['lr2'].shape))
         if not self.use_graph:
@@ -108,7 +128,7 @@ class OnlineStitcher:
             # capture: the eager warm-up runs on a copy of the state so that this push is applied exactly once
             keep = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in st.items()
                     if k in ('prev_feat', 'prev_smotion', 'smesh', 'tsm')}
-            side = torch.cuda.Stream(self.dev)
+            side = _warmup_stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
                 self._step_static()

@@ -1,7 +1,6 @@
-"""Thin tensor-level wrappers over the C ABI: allocate outputs with torch, launch on the current
-stream, return device tensors.  No arithmetic happens in Python."""
-import ctypes
-
+"""Thin tensor-level wrappers over the C ABI: allocate outputs with torch, launch on the current stream of the
+device that owns the tensors, return device tensors.  These wrappers do no arithmetic of their own (the few
+mesh-sized torch expressions of the path live in pipeline.py and are named there)."""
 import torch
 
 from . import _hip as H
@@ -31,21 +30,27 @@ def nhwc_to_nchw(x, c=None):
 
 
 # ------------------------------------------------------------------ conv / pool / fc
-_conv_ws = {}
+def conv_workspace(device, floats):
+    """Split-K scratch for ONE launch, sized by ss_conv_workspace_need and taken from torch's caching allocator on the
+    launch stream (stream-ordered: the block may be reused as soon as the reduce kernel behind it has been enqueued,
+    and inside a HIP-graph capture it comes from the graph's own pool).  Most launches need none."""
+    if floats <= 0:
+        return None
+    return torch.empty(int(floats), device=device, dtype=torch.float32)
 
 
-def conv_workspace(device):
-    """Split-K scratch (64 MiB) per (device, stream), allocated once; launches on one stream are ordered and each
-    conv's reduce runs right behind its partial pass, so one buffer per stream is race free."""
-    if torch.cuda.is_current_stream_capturing():
-        # inside a HIP-graph capture the buffer must come from the graph's own memory pool (and die with it)
-        return torch.empty(int(H.lib().ss_conv_workspace_floats()), device=device, dtype=torch.float32)
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _conv_ws.get(key)
-    if ws is None:
-        ws = torch.empty(int(H.lib().ss_conv_workspace_floats()), device=device, dtype=torch.float32)
-        _conv_ws[key] = ws
-    return ws
+def _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups):
+    return int(H.lib().ss_conv_workspace_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups))
+
+
+def conv_executed_flop_ratio(kt, kh, kw, stride, cin, cout, out_shape):
+    """Executed MFMA flop / direct-convolution flop of the launch the engine picks for this geometry: 16/36 where the
+    Winograd F(2x2,3x3) kernel runs (the library's own dispatch rule, ss_conv_uses_winograd), else 1."""
+    fn = getattr(H.lib(), 'ss_conv_uses_winograd', None)
+    if fn is None:
+        return 1.0
+    ho, wo = out_shape[-3], out_shape[-2]
+    return 16.0 / 36.0 if fn(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho), int(wo)) else 1.0
 
 
 def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=None):
@@ -65,10 +70,10 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     if out is None:
         shape = (n, to, ho, wo, cout) if five else (n, ho, wo, cout)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
-    ws = conv_workspace(x.device)
+    ws = conv_workspace(x.device, _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, 1))
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), out.shape[-1],
-           1, 0, 0, 0, H.dptr(ws), ws.numel(), H.stream())
+           1, 0, 0, 0, H.dptr(ws, True), 0 if ws is None else ws.numel(), H.stream())
     return out
 
 
@@ -88,10 +93,11 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
     ho = (h + 2 * ph - kh) // stride + 1
     wo = (w + 2 * pw - kw) // stride + 1
     out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
-    ws = conv_workspace(x.device)
+    ws = conv_workspace(x.device, _conv_ws_need(n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, g))
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), cout,
-           g, 0 if shared else x[0].numel(), wgt[0].numel(), out[0].numel(), H.dptr(ws), ws.numel(), H.stream())
+           g, 0 if shared else x[0].numel(), wgt[0].numel(), out[0].numel(), H.dptr(ws, True),
+           0 if ws is None else ws.numel(), H.stream())
     return out
 
 
@@ -131,6 +137,13 @@ def ccl(f1, f2, scale=10.0, want_nchw=True, want_nhwc4=True):
     H.call('ss_ccl', H.dptr(f1), H.dptr(f2), H.dptr(a, True), H.dptr(b, True), n, h, w, c, float(scale),
            H.dptr(ws), H.stream())
     return a, b
+
+
+def l2norm(x):
+    """F.normalize(x, p=2, dim=channels) on an nhwc tensor."""
+    out = torch.empty_like(x)
+    H.call('ss_l2norm_nhwc', H.dptr(x), H.dptr(out), x.numel() // x.shape[-1], x.shape[-1], H.stream())
+    return out
 
 
 def cost_volume(x1, x2, r, out=None):
@@ -226,11 +239,9 @@ def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None):
     v = len(imgs)
     imgs = [_f(i) for i in imgs]
     h, w = imgs[0].shape[-2:]
-    arr = (ctypes.c_void_p * v)(*[i.data_ptr() for i in imgs])
+    arr = H.ptr_array(imgs)
     if out is None:
         out = torch.empty((3, hc, wc), device=imgs[0].device, dtype=torch.float32)
-    for i in imgs:
-        H.dptr(i)
     H.call('ss_render_average', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(out), v, h, w, hc, wc, MODES[mode],
            H.stream())
     return out
@@ -241,9 +252,7 @@ def tps_warp_views(imgs, source, T, hc, wc, mode='NORMAL'):
     v = len(imgs)
     imgs = [_f(i) for i in imgs]
     h, w = imgs[0].shape[-2:]
-    for i in imgs:
-        H.dptr(i)
-    arr = (ctypes.c_void_p * v)(*[i.data_ptr() for i in imgs])
+    arr = H.ptr_array(imgs)
     out = torch.empty((v, 4, hc, wc), device=imgs[0].device, dtype=torch.float32)
     H.call('ss_tps_warp_views', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(out), v, h, w, hc, wc, MODES[mode],
            H.stream())
@@ -263,12 +272,7 @@ def mask_union(a, b):
 
 
 def _u8ptr(t):
-    if not t.is_cuda:
-        raise H.HipError('stabstitch2_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
-    if t.dtype != torch.uint8 or not t.is_contiguous():
-        raise H.HipError('expected a contiguous uint8 device tensor (got %s, contiguous=%s)'
-                         % (t.dtype, t.is_contiguous()))
-    return ctypes.c_void_p(t.data_ptr())
+    return H.dptr(t, dtype=torch.uint8)
 
 
 def ingest_u8(frames, lr_h=360, lr_w=480, want_hr=True, hr_out=None, lr_out=None):

@@ -9,7 +9,13 @@ over the whole clip (the clip is resident in HBM): SpatialNet over all frame pai
 over all frames of a view, one batched tsmotion composition per view, all sliding SmoothNet windows
 as one batch, one batched TPS solve for every (frame, view), then one fused warp+blend launch per
 stitched frame.  The only host round trip is the data-dependent canvas size (test_online_tra.py:122-123).
+
+Everything tensor-sized (frames, feature maps, cost volumes, canvases) is computed by the HIP kernels.  What stays as
+torch expressions here is mesh-sized bookkeeping on [N,7,9,2] tensors (a few KB): assembling the clip's meshes from the
+sliding windows and the metric harness's stitched paths (`_stitch_windows`), and the three-view mesh alignment
+(`three_view_compose`: scale, mean offset, middle mesh, bbox, normalise) -- torch device ops, no host sync.
 """
+import glob
 import os
 
 import torch
@@ -109,9 +115,12 @@ def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None, 
     from . import layers as L
     chunk = chunk or SPATIAL_CHUNK
     sp, tp = spatial_net._prepared(), temporal_net._prepared()
-    key = ('stem_pair', id(tp))
-    if key not in sp:
+    # shared-stem filters derive from BOTH nets' weights: keyed on both versions, one live entry (replaced on a miss)
+    key = 'stem_pair'
+    ver = (spatial_net.weights_version, temporal_net.weights_version)
+    if sp.get('stem_pair_version') != ver:
         sp[key] = L.pair_stems(sp['s1'], tp['s1'])
+        sp['stem_pair_version'] = ver
     n = lr1.shape[0]
     m1, m2 = [], []
     ft = None
@@ -183,22 +192,74 @@ def estimate_meshes(nets, lr1, lr2, tmotion1=None, spatial_cache1=None, keep_spa
     smesh2, tsm2 = ops.tsmotion(s2, t2, LR_H, LR_W)
     nw = n - (WINDOW - 1)
     o, _ = smooth_net.run_windows(smesh1, smesh2, tsm1, tsm2, nw, WINDOW, 1, 1)
+    out = _stitch_windows(o)
+    out['smotion1'], out['smotion2'], out['tmotion1'], out['tmotion2'] = s1, s2, t1, t2
+    out['tsmotion1'], out['tsmotion2'] = tsm1, tsm2
+    if cache2:
+        out['spatial_cache2'] = cache2
+    return out
+
+
+def _stitch_windows(o):
+    """Per-window SmoothNet outputs [nw,7,7,9,2] -> the clip's tensors [1,N,7,9,2] (mesh-sized torch glue).
+    Window 0 contributes its 7 frames, every later window its last frame (test_online_tra.py:377-392); the metric
+    harness's paths are chained across windows as test_metric_ssd.py:427-436 does."""
     out = {}
     for k in ('ori_mesh1', 'ori_mesh2', 'smooth_mesh1', 'smooth_mesh2'):
-        # window 0 contributes its 7 frames, every later window its last frame (test_online_tra.py:377-392)
         out[k] = torch.cat((o[k][0], o[k][1:, -1]), 0).unsqueeze(0)
-    # stitched paths of the metric harness (test_metric_ssd.py:427-436)
     op, sp = o['ori_path2'], o['smooth_path2']
     inc = op[1:, -1] - op[1:, -2]
     ori_path = torch.cat((op[0], op[0, -1:] + torch.cumsum(inc, 0)), 0)
     smooth_path = torch.cat((sp[0], ori_path[WINDOW:] + (sp[1:, -1] - op[1:, -1])), 0)
     out['ori_path2'] = ori_path.unsqueeze(0)
     out['smooth_path2'] = smooth_path.unsqueeze(0)
-    out['smotion1'], out['smotion2'], out['tmotion1'], out['tmotion2'] = s1, s2, t1, t2
-    out['tsmotion1'], out['tsmotion2'] = tsm1, tsm2
-    if cache2:
-        out['spatial_cache2'] = cache2
     return out
+
+
+# ------------------------------------------------------------------ checkpoints
+def load_nets(model_dir, device='cuda'):
+    """test_online_tra.py:164-201: build the three networks, require EXACTLY three `*.pth` files in `model_dir`
+    (spatial_warp.pth, temporal_warp.pth, smooth_warp.pth), load `torch.load(p)['model']` strictly, eval mode.
+    -> (spatial_net, temporal_net, smooth_net) on `device`.  Raises FileNotFoundError where the reference prints
+    'No checkpoint found!' and exits."""
+    from .spatial_network import SpatialNet
+    from .temporal_network import TemporalNet
+    from .smooth_network import SmoothNet
+    ckpt_list = sorted(glob.glob(os.path.join(model_dir, '*.pth')))
+    if len(ckpt_list) != 3:
+        raise FileNotFoundError('No checkpoint found! %s holds %d *.pth files, expected spatial_warp.pth, '
+                                'temporal_warp.pth and smooth_warp.pth' % (model_dir, len(ckpt_list)))
+    nets = []
+    for cls, name in ((SpatialNet, 'spatial_warp.pth'), (TemporalNet, 'temporal_warp.pth'), (SmoothNet, 'smooth_warp.pth')):
+        net = cls()
+        ck = torch.load(os.path.join(model_dir, name), map_location='cpu')
+        net.load_state_dict(ck['model'])
+        nets.append(net.to(device).eval())
+    return tuple(nets)
+
+
+def find_model_dir(root):
+    """The reference's checkpoint locations relative to its tree (Full_model_inference/README.md:2-6):
+    full_model_tra first (test_online_tra.py), then full_model_ssd; None when neither holds three *.pth files."""
+    for sub in ('full_model_tra', 'full_model_ssd'):
+        d = os.path.join(root, 'Full_model_inference', sub)
+        if len(glob.glob(os.path.join(d, '*.pth'))) == 3:
+            return d
+    return None
+
+
+_nrigid_cache = {}
+
+
+def norm_rigid_mesh(img_h, img_w, device):
+    """get_norm_mesh(get_rigid_mesh(1, h, w)) as a cached device constant ([1,63,2]; built once per (size, device)
+    instead of on the host for every render)."""
+    key = (int(img_h), int(img_w), str(device))
+    t = _nrigid_cache.get(key)
+    if t is None:
+        t = get_norm_mesh(get_rigid_mesh(1, img_h, img_w, device=device), img_h, img_w).contiguous()
+        _nrigid_cache[key] = t
+    return t
 
 
 # ------------------------------------------------------------------ render
@@ -216,8 +277,7 @@ def render_plan(meshes, img_h, img_w, prescaled=False):
     wc_f, hc_f = bb[1] - bb[0], bb[3] - bb[2]
     hc, wc = int(hc_f.int()), int(wc_f.int())
     src = torch.stack([ops.mesh_normalize(m[0], bbox, sh, sw) for m in meshes], 1).contiguous()   # [N,V,63,2]
-    nrigid = get_norm_mesh(get_rigid_mesh(1, img_h, img_w, device=dev), img_h, img_w)
-    tgt = nrigid.expand(n * v, -1, -1).contiguous()
+    tgt = norm_rigid_mesh(img_h, img_w, dev).expand(n * v, -1, -1).contiguous()
     T = ops.tps_solve(src.view(n * v, 63, 2), tgt).view(n, v, 2, 66)
     return hc, wc, src, T
 
@@ -276,8 +336,9 @@ def _scale(m, img_h, img_w):
 @torch.no_grad()
 def three_view_compose(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w):
     """Mesh alignment, middle plane and TPS re-projection of the outer views.  Inputs [1,N,7,9,2] (LR scale)
-    -> (mesh1, middle, mesh3) in first-canvas HR pixels.  Mesh-sized glue stays in torch; the TPS solves and
-    point evaluations run on the HIP kernels."""
+    -> (mesh1, middle, mesh3) in first-canvas HR pixels.  Mesh-sized glue (scale, mean offset, middle mesh, bbox,
+    normalise: [1,N,7,9,2] tensors) stays in torch on the device; the TPS solves and point evaluations run on the HIP
+    kernels."""
     a1, a2 = _scale(w12_m1, img_h, img_w), _scale(w12_m2, img_h, img_w)
     b1, b2 = _scale(w23_m1, img_h, img_w), _scale(w23_m2, img_h, img_w)
     off = (a2 - b1).reshape(a2.shape[0], a2.shape[1], -1, 2).mean(2).unsqueeze(2).unsqueeze(2)

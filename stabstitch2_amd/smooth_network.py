@@ -7,6 +7,7 @@ from . import grid_res, layers as L, ops
 
 grid_h = grid_res.GRID_H
 grid_w = grid_res.GRID_W
+WINDOW_CHUNK = 2048          # sliding windows per SmoothNet pass ([2048,7,7,9,128] fp32 = 0.46 GB per activation)
 
 
 class MotionPrediction(nn.Module):
@@ -42,6 +43,17 @@ class SmoothNet(L.PreparedMixin, nn.Module):
         """smesh*/ts* [frames,7,9,2] device tensors; see ss_smooth_embed for the window addressing.
         -> (dict of the 8 build_SmoothNet tensors, each [nw,t,7,9,2]; decoder output [nw,t,7,9,4])."""
         p = self._prepared()
+        if nw > WINDOW_CHUNK and wstride <= t:
+            # long clips: windows in chunks (one Conv3d launch addresses < 2 GiB of input); window wi starts at frame
+            # wi * wstride, so a chunk is the same call on the frame range it covers
+            outs, deltas = [], []
+            for s in range(0, nw, WINDOW_CHUNK):
+                m = min(WINDOW_CHUNK, nw - s)
+                f0, f1 = s * wstride, (s + m - 1) * wstride + t
+                o, d = self.run_windows(smesh1[f0:f1], smesh2[f0:f1], ts1[f0:f1], ts2[f0:f1], m, t, wstride, zero_first)
+                outs.append(o)
+                deltas.append(d)
+            return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}, torch.cat(deltas, 0)
         hid = ops.smooth_embed(smesh1, smesh2, ts1, ts2, p['e1'][0], p['e1'][1], p['e3'][0], p['e3'][1], nw, t,
                                wstride, zero_first)
         for w, b in p['conv']:

@@ -114,11 +114,11 @@ class SpatialNet(L.PreparedMixin, nn.Module):
     @staticmethod
     def cost_volume(x1, x2, search_range, norm=True, fast=True):
         """Reference signature (NCHW in/out, spatial_network.py:333-358)."""
-        if norm:
-            raise NotImplementedError('norm=True is never used by the reference inference path')
         d = (2 * search_range + 1) ** 2
-        cv = ops.cost_volume(ops.nchw_to_nhwc(x1), ops.nchw_to_nhwc(x2), search_range)
-        return ops.nhwc_to_nchw(cv, d)
+        a, b = ops.nchw_to_nhwc(x1), ops.nchw_to_nhwc(x2)
+        if norm:                 # F.normalize over channels first (the signature's default; inference passes norm=False)
+            a, b = ops.l2norm(a), ops.l2norm(b)
+        return ops.nhwc_to_nchw(ops.cost_volume(a, b, search_range), d)
 
     def CCL(self, feature_1, feature_2):
         """Reference signature (NCHW in/out, spatial_network.py:369-425)."""

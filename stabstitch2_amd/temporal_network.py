@@ -32,6 +32,8 @@ class TemporalNet(L.PreparedMixin, nn.Module):
         """frames [N,B,3,360,480] (device) -> [N-1,B,7,9,2] mesh motions between consecutive frames."""
         p = self._prepared()
         n, b = frames.shape[0], frames.shape[1]
+        if n < 2:              # a single frame has no consecutive pair (the reference's loop body never runs)
+            return torch.zeros((0, b, grid_h + 1, grid_w + 1, 2), device=frames.device, dtype=torch.float32)
         f = L.run_stage1(frames.reshape(n * b, *frames.shape[2:]), p['s1'])
         f = f.view(n, b, *f.shape[1:])
         x1 = f[:-1].reshape((n - 1) * b, *f.shape[2:])
@@ -86,14 +88,18 @@ class TemporalNet(L.PreparedMixin, nn.Module):
 
     @staticmethod
     def cost_volume(x1, x2, search_range, norm=True, fast=True):
-        if norm:
-            raise NotImplementedError('norm=True is never used by the reference inference path')
         d = (2 * search_range + 1) ** 2
-        return ops.nhwc_to_nchw(ops.cost_volume(ops.nchw_to_nhwc(x1), ops.nchw_to_nhwc(x2), search_range), d)
+        a, b = ops.nchw_to_nhwc(x1), ops.nchw_to_nhwc(x2)
+        if norm:
+            a, b = ops.l2norm(a), ops.l2norm(b)
+        return ops.nhwc_to_nchw(ops.cost_volume(a, b, search_range), d)
 
 
 def build_TemporalNet(net, img_tensor_list):
-    """temporal_network.py:23-34 -> dict(motion_list = [zeros] + N-1 motions), each [B,7,9,2]."""
+    """temporal_network.py:23-34 -> dict(motion_list = [zeros] + N-1 motions), each [B,7,9,2]
+    (a one-frame list gives [zeros], as the reference does)."""
     motion_list = net(img_tensor_list)
-    motion_list.insert(0, torch.zeros_like(motion_list[0]))
+    dev = next(net.parameters()).device
+    b = img_tensor_list[0].shape[0]
+    motion_list.insert(0, torch.zeros((b, grid_h + 1, grid_w + 1, 2), device=dev, dtype=torch.float32))
     return dict(motion_list=motion_list)

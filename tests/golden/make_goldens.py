@@ -95,8 +95,11 @@ def g3():
     fa, fb = cases.g3_inputs(True)
     full5 = RS.SpatialNet.cost_volume(fa, fb, search_range=5, norm=False)
     full3 = RT.TemporalNet.cost_volume(fa, fb, search_range=3, norm=False)
+    # norm=True (the signature's default; spatial_network.py:335-337) -- never used by the inference path, pinned anyway
+    cv5n = RS.SpatialNet.cost_volume(a, b, search_range=5, norm=True)
+    cv3n = RT.TemporalNet.cost_volume(a, b, search_range=3, norm=True)
     save('g3_costvol', cv5=cv5, cv3=cv3, full5_chsum=full5.sum(dim=(2, 3)), full3_chsum=full3.sum(dim=(2, 3)),
-         full5_rows=full5[0, :, 22, :], full3_rows=full3[0, :, 0, :])
+         full5_rows=full5[0, :, 22, :], full3_rows=full3[0, :, 0, :], cv5n=cv5n, cv3n=cv3n)
 
 
 # ------------------------------------------------------------------ G4 CCL
@@ -283,6 +286,43 @@ def g10():
     save('g10_threeview', **res)
 
 
+# ------------------------------------------------------------------ G12 three-view, full path (nets -> compose -> render)
+def three_view_body():
+    """Lines 345..505 of test() in test_online_tra_threeview.py, read at generation time (never stored)."""
+    src_lines = open(os.path.join(ref_shim.REF, 'test_online_tra_threeview.py')).read().split('\n')
+    return '\n'.join(l[4:] if l.startswith('    ') else l for l in src_lines[344:505])
+
+
+def g12(nets):
+    """test_online_tra_threeview.py:154-505 end to end: two 2-view passes (v1,v2), (v2,v3) through the reference's
+    networks (the frame loop of :225-343 replayed by run_motion_stages with the reference's own functions), then the
+    composition / render block executed verbatim.  8-frame 3-view clip, HR 180x320 (LR inputs are always 360x480)."""
+    import test_online_tra_threeview as R3
+    n = 8
+    hr, lr = synth.make_clip(n, 180, 320, seed=4, views=3)
+    a12 = run_motion_stages(nets, lr[0], lr[1])['acc']
+    a23 = run_motion_stages(nets, lr[1], lr[2])['acc']
+    res = dict(w12_m1=a12['smooth_mesh1'], w12_m2=a12['smooth_mesh2'], w23_m1=a23['smooth_mesh1'],
+               w23_m2=a23['smooth_mesh2'])
+    body = three_view_body()
+    for wm, fm in (('NORMAL', 'AVERAGE'), ('NORMAL', 'LINEAR')):
+        ns = dict(vars(R3))
+        ns.update(warp12_mesh1=a12['smooth_mesh1'].clone(), warp12_mesh2=a12['smooth_mesh2'].clone(),
+                  warp23_mesh1=a23['smooth_mesh1'].clone(), warp23_mesh2=a23['smooth_mesh2'].clone(),
+                  img1_list=hr[0], img2_list=hr[1], img3_list=hr[2],
+                  args=types.SimpleNamespace(warp_mode=wm, fusion_mode=fm))
+        exec(compile(body, 'threeview_345_505', 'exec'), ns)
+        tag = fm.lower()
+        res['canvas_' + tag] = np.array([int(ns['out_height'].int()), int(ns['out_width'].int())])
+        res['frames_' + tag] = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), 4) for f in ns['stable_list']])
+        res['iqr_' + tag] = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), 4) for f in ns['stable_list']])
+        if fm == 'AVERAGE':
+            res['mesh1'] = ns['warp12_mesh1']
+            res['middle'] = ns['middle_mesh']
+            res['mesh3'] = ns['warp23_mesh2']
+    save('g12_threeview_full', **res)
+
+
 # ------------------------------------------------------------------ G11 PSNR / SSIM
 def g11():
     a, b = cases.g11_images()
@@ -291,13 +331,28 @@ def g11():
 
 
 if __name__ == '__main__':
+    only = set(sys.argv[1:])            # e.g. `make_goldens.py g3 g12` regenerates just those
+
+    def want(tag):
+        return not only or tag in only
     nets = ref_nets()
-    g1()
-    g2()
-    g3()
-    g4(nets[0])
-    g5()
-    g6_g7()
-    g8_g9(nets)
-    g10()
-    g11()
+    if want('g1'):
+        g1()
+    if want('g2'):
+        g2()
+    if want('g3'):
+        g3()
+    if want('g4'):
+        g4(nets[0])
+    if want('g5'):
+        g5()
+    if want('g6') or want('g7'):
+        g6_g7()
+    if want('g8') or want('g9'):
+        g8_g9(nets)
+    if want('g10'):
+        g10()
+    if want('g11'):
+        g11()
+    if want('g12'):
+        g12(nets)

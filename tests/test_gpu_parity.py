@@ -569,14 +569,21 @@ def test_host_clip_runner_overlapped_copies(dev, hip_nets):
     assert list(runner.run(iter(()))) == []
 
 
-def test_conv_random_shapes_and_address_modes(dev):
+def test_conv_random_shapes_and_address_modes(dev, request):
     """Seeded sweep over ragged conv geometries (every padding / stride / kernel size class the tap table and the
     tap-validity masks distinguish: 1..49 taps -> 32-bit masks, 64-bit masks, > 64 taps -> arithmetic path) against
     F.conv2d / F.conv3d on the CPU; the LDS-table and the arithmetic address paths must agree bit for bit."""
-    import ctypes
     from stabstitch2_amd import ops, _hip
-    lib = _hip.lib()
-    lib.ss_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    # the address-mode switch is a tuning knob: it exists only in the tools/ build of the library (-DSS_TUNING), which
+    # this test loads for its own launches; the comparison against the CPU convolution also runs on the product library
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_tuning', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'tools', '_tuning.py'))
+    tuning = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tuning)
+    product = _hip.lib()
+    request.addfinalizer(lambda: setattr(_hip, '_lib', product))
+    lib = tuning.lib()
     rs = np.random.RandomState(2024)
     cases = []
     for _ in range(36):
@@ -599,6 +606,10 @@ def test_conv_random_shapes_and_address_modes(dev):
             outs.append(ops.conv(xd, wd, bd, None, stride=s, pad=(0, p, p), relu=False))
         lib.ss_debug_set(3, 0)
         assert torch.equal(outs[0], outs[1]), ('table vs arithmetic addressing differ', (n, cin, cout, h, w, k, s, p))
+        _hip._lib = product
+        prod = ops.conv(xd, wd, bd, None, stride=s, pad=(0, p, p), relu=False)
+        _hip._lib = lib
+        assert torch.equal(prod, outs[0]), 'product and tuning builds differ'
         close(ops.nhwc_to_nchw(outs[0]), ref, 3e-5 * max(1.0, float(ref.abs().max())), 'conv %s' % ((n, cin, cout, h, w, k, s, p),))
     # 3-D: 5x3x3 = 45 taps (64-bit masks) and 5x5x5 = 125 taps (arithmetic fallback), temporal padding included
     for (kt, kk, pt, pp) in ((5, 3, 2, 1), (3, 3, 0, 1), (5, 5, 2, 2)):
@@ -647,3 +658,248 @@ def test_degenerate_inputs_stay_finite_and_match_oracle(dev, hip_nets):
         assert (hc, wc) == (ref[1], ref[2])
         close(m1.cpu(), ref[3], 5e-3, 'degenerate smooth_mesh1 (val %g)' % val)
         close(m2.cpu(), ref[4], 5e-3, 'degenerate smooth_mesh2 (val %g)' % val)
+
+
+# ------------------------------------------------------------------ round 2: three-view full path, 720p oracle parity, host API
+def _oracle_nets():
+    onets = (N.SpatialNet().eval(), N.TemporalNet().eval(), N.SmoothNet().eval())
+    for m in onets:
+        m.load_state_dict(synth.synthetic_state_dict(m), strict=True)
+    return onets
+
+
+def test_cost_volume_norm_true(dev, golden):
+    """cost_volume(norm=True) -- the reference signature's default (spatial_network.py:335-337), unused by inference."""
+    from stabstitch2_amd.spatial_network import SpatialNet
+    from stabstitch2_amd.temporal_network import TemporalNet
+    g = golden('g3_costvol')
+    a, b = cases.g3_inputs(False)
+    close(SpatialNet.cost_volume(a.to(dev), b.to(dev), 5, norm=True), g['cv5n'], 1e-6, 'cv5 norm=True')
+    close(TemporalNet.cost_volume(a.to(dev), b.to(dev), 3, norm=True), g['cv3n'], 1e-6, 'cv3 norm=True')
+    close(SpatialNet.cost_volume(a.to(dev), b.to(dev), 5, norm=False), g['cv5'], 1e-5, 'cv5 norm=False')
+
+
+def _three_view_unshared(nets, lr):
+    """Two independent 2-view passes with none of run_three_view's sharing (no reused TemporalNet motions, no reused
+    SpatialNet trunk features, no shared stem)."""
+    from stabstitch2_amd import pipeline
+    outs = []
+    for a, b in ((lr[0], lr[1]), (lr[1], lr[2])):
+        s1, s2 = pipeline.spatial_stage(nets[0], a, b)
+        t1, t2 = pipeline.temporal_stage(nets[1], a), pipeline.temporal_stage(nets[1], b)
+        outs.append((s1, s2, t1, t2))
+    return outs
+
+
+def test_run_three_view_sharing_is_exact(dev, hip_nets):
+    """configs[4]: run_three_view computes the middle view's TemporalNet motions and SpatialNet trunk features once and
+    the (1,2) pair's stems jointly; every shared quantity must equal the unshared computation up to split-K /
+    batch-composition summation order (<= 1e-4 px), the canvas exactly."""
+    from stabstitch2_amd import pipeline
+    n = 9
+    hr, lr = synth.make_clip_device(n, 180, 320, seed=6, views=3, device=dev)
+    a12 = pipeline.estimate_meshes(hip_nets, lr[0], lr[1], keep_spatial_cache2=True)
+    a23 = pipeline.estimate_meshes(hip_nets, lr[1], lr[2], tmotion1=a12['tmotion2'],
+                                   spatial_cache1=a12.get('spatial_cache2'))
+    u12, u23 = _three_view_unshared(hip_nets, lr)
+    for name, got, ref in (('s1_12', a12['smotion1'], u12[0]), ('s2_12', a12['smotion2'], u12[1]),
+                           ('t1_12', a12['tmotion1'], u12[2]), ('t2_12', a12['tmotion2'], u12[3]),
+                           ('s1_23', a23['smotion1'], u23[0]), ('s2_23', a23['smotion2'], u23[1]),
+                           ('t1_23', a23['tmotion1'], u23[2]), ('t2_23', a23['tmotion2'], u23[3])):
+        close(got, ref, 1e-4, 'shared vs unshared ' + name)
+    # whole path: shared run_three_view vs the same clip through plain (unshared, separate-stem) 2-view passes
+    import stabstitch2_amd.pipeline as PL
+    fr, hc, wc, m1, mid, m3 = pipeline.run_three_view(hr[0], hr[1], hr[2], lr[0], lr[1], lr[2], hip_nets)
+    old = PL.SHARED_STEM
+    PL.SHARED_STEM = False
+    try:
+        b12 = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+        b23 = pipeline.estimate_meshes(hip_nets, lr[1], lr[2])
+    finally:
+        PL.SHARED_STEM = old
+    r1, rmid, r3 = pipeline.three_view_compose(b12['smooth_mesh1'], b12['smooth_mesh2'], b23['smooth_mesh1'],
+                                               b23['smooth_mesh2'], 180, 320)
+    close(m1, r1, 1e-3, 'three-view mesh1 shared vs unshared')
+    close(mid, rmid, 1e-3, 'three-view middle shared vs unshared')
+    close(m3, r3, 1e-3, 'three-view mesh3 shared vs unshared')
+    fr2, hc2, wc2 = pipeline.three_view_render(hr[0], hr[1], hr[2], r1, rmid, r3)
+    assert (hc, wc) == (hc2, wc2) and fr.shape == (n, 3, hc, wc) and bool(torch.isfinite(fr).all())
+
+
+@pytest.mark.parametrize('h,w,n', [(180, 320, 8), (720, 1280, 7)])
+def test_run_three_view_vs_oracle(dev, hip_nets, h, w, n):
+    """configs[4] against oracle/pipeline.py run_three_view (two full 2-view passes + composition + 3-image render) on
+    the same clip: re-projected meshes, canvas, box-median frames."""
+    from stabstitch2_amd import pipeline
+    hr, lr = synth.make_clip(n, h, w, seed=7, views=3)
+    hrd = [torch.cat(v, 0).to(dev) for v in hr]
+    lrd = [torch.cat(v, 0).to(dev) for v in lr]
+    fr, hc, wc, m1, mid, m3 = pipeline.run_three_view(hrd[0], hrd[1], hrd[2], lrd[0], lrd[1], lrd[2], hip_nets)
+    ofr, ohc, owc, om1, omid, om3 = P.run_three_view(hr[0], hr[1], hr[2], lr[0], lr[1], lr[2], _oracle_nets())
+    scale = h / 360.0                      # meshes are HR canvas pixels: LR-px error times the HR scale
+    close(m1, om1, 5e-3 * scale, 'mesh1 vs oracle')
+    close(mid, omid, 5e-3 * scale, 'middle vs oracle')
+    close(m3, om3, 5e-3 * scale, 'mesh3 vs oracle')
+    assert (hc, wc) == (ohc, owc)
+    k = 4 if h < 360 else 16
+    got = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), k) for f in fr])
+    ref = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), k) for f in ofr])
+    rng = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), k) for f in ofr])
+    # chained AVERAGE is chaotic where only view 3 is valid (DESIGN.md 4): clean boxes only, loose bound there
+    close_boxes(got, ref, rng, 3.0, 'three-view frames vs oracle', k=k, cover=0.3)
+    ok = cases.smooth_boxes(rng, k)
+    d = np.abs(got - ref)[ok]
+    assert np.median(d) < 0.02, float(np.median(d))
+
+
+def test_three_view_full_path_vs_reference(dev, golden, hip_nets):
+    """G12: test_online_tra_threeview.py:154-505 end to end, produced by the reference itself (two 2-view passes through
+    its networks, then its composition / render block verbatim)."""
+    from stabstitch2_amd import pipeline
+    g = golden('g12_threeview_full')
+    n = g['mesh1'].shape[1]
+    hr, lr = synth.make_clip(n, 180, 320, seed=4, views=3)
+    hrd = [torch.cat(v, 0).to(dev) for v in hr]
+    lrd = [torch.cat(v, 0).to(dev) for v in lr]
+    a12 = pipeline.estimate_meshes(hip_nets, lrd[0], lrd[1], keep_spatial_cache2=True)
+    a23 = pipeline.estimate_meshes(hip_nets, lrd[1], lrd[2], tmotion1=a12['tmotion2'],
+                                   spatial_cache1=a12.get('spatial_cache2'))
+    close(a12['smooth_mesh1'], g['w12_m1'], 5e-3, 'pass (1,2) smooth_mesh1 vs reference')
+    close(a12['smooth_mesh2'], g['w12_m2'], 5e-3, 'pass (1,2) smooth_mesh2 vs reference')
+    close(a23['smooth_mesh1'], g['w23_m1'], 5e-3, 'pass (2,3) smooth_mesh1 vs reference')
+    close(a23['smooth_mesh2'], g['w23_m2'], 5e-3, 'pass (2,3) smooth_mesh2 vs reference')
+    for fm in ('AVERAGE', 'LINEAR'):
+        fr, hc, wc, m1, mid, m3 = pipeline.run_three_view(hrd[0], hrd[1], hrd[2], lrd[0], lrd[1], lrd[2], hip_nets,
+                                                          'NORMAL', fm)
+        close(m1, g['mesh1'], 5e-3, 'mesh1 vs reference')
+        close(mid, g['middle'], 5e-3, 'middle vs reference')
+        close(m3, g['mesh3'], 5e-3, 'mesh3 vs reference')
+        assert [hc, wc] == list(g['canvas_' + fm.lower()])
+        got = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), 4) for f in fr])
+        tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
+        close_boxes(got, g['frames_' + fm.lower()], g['iqr_' + fm.lower()], tol, 'G12 frames ' + fm, k=4, cover=cover)
+
+
+def test_two_view_720p_vs_oracle(dev, hip_nets):
+    """configs[2] as a real parity test (what bench.py checks at benchmark time): 8-frame 720x1280 clip, HIP path vs
+    the CPU oracle -- meshes, canvas, frames (median / p99.9), alignment PSNR / SSIM within 0.01 dB / 1e-3."""
+    from stabstitch2_amd import pipeline, metrics
+    n = 8
+    hr, lr = synth.make_clip_device(n, 720, 1280, seed=0, device='cpu')
+    fr, hc, wc, m1, m2 = pipeline.run_two_view(hr[0].to(dev), hr[1].to(dev), lr[0].to(dev), lr[1].to(dev), hip_nets)
+    sl = lambda t: [t[i:i + 1] for i in range(n)]
+    ofr, ohc, owc, om1, om2 = P.run_two_view(sl(hr[0]), sl(hr[1]), sl(lr[0]), sl(lr[1]), _oracle_nets())
+    close(m1, om1, 5e-3, '720p smooth_mesh1 vs oracle')
+    close(m2, om2, 5e-3, '720p smooth_mesh2 vs oracle')
+    assert (hc, wc) == (ohc, owc)
+    for i in (0, n - 1):
+        d = np.abs(fr[i].permute(1, 2, 0).cpu().numpy() - ofr[i])
+        assert np.median(d) < 5e-3 and np.quantile(d, 0.999) < 0.1, (i, float(np.median(d)), float(np.quantile(d, 0.999)))
+    k = 3
+    c1 = M.warp_lr_with_mask(sl(lr[0])[:k], om1[:, :k])
+    c2 = M.warp_lr_with_mask(sl(lr[1])[:k], om2[:, :k])
+    cps = [M.alignment_psnr_ssim(a, b) for a, b in zip(c1, c2)]
+    gp, gs = metrics.alignment_psnr_ssim(metrics.warp_lr_planes(lr[0][:k].to(dev), m1[:, :k]),
+                                         metrics.warp_lr_planes(lr[1][:k].to(dev), m2[:, :k]))
+    for i in range(k):
+        assert abs(float(gp[i]) - cps[i][0]) < 0.01 and abs(float(gs[i]) - cps[i][1]) < 1e-3, (i, float(gp[i]), cps[i])
+
+
+def test_load_nets_and_checkpoint_dir(dev, tmp_path, hip_nets):
+    """pipeline.load_nets mirrors test_online_tra.py:173-194: exactly three *.pth, torch.load(p)['model'], strict."""
+    from stabstitch2_amd import pipeline
+    from stabstitch2_amd.spatial_network import SpatialNet
+    from stabstitch2_amd.temporal_network import TemporalNet
+    from stabstitch2_amd.smooth_network import SmoothNet
+    d = str(tmp_path / 'Full_model_inference' / 'full_model_tra')
+    synth.write_synthetic_checkpoints(d, SpatialNet(), TemporalNet(), SmoothNet())
+    assert pipeline.find_model_dir(str(tmp_path)) == d
+    nets = pipeline.load_nets(d, dev)
+    _, lr = synth.make_clip_device(7, 360, 480, seed=1, device=dev)
+    a = pipeline.estimate_meshes(nets, lr[0], lr[1])
+    b = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+    assert torch.equal(a['smooth_mesh1'], b['smooth_mesh1']) and torch.equal(a['smooth_mesh2'], b['smooth_mesh2'])
+    os.remove(os.path.join(d, 'smooth_warp.pth'))
+    with pytest.raises(FileNotFoundError):
+        pipeline.load_nets(d, dev)
+
+
+def test_chunked_stages_equal_unchunked(dev, hip_nets):
+    """Long clips: regressors / SmoothNet windows run in batch chunks (a conv launch addresses < 2 GiB); chunking must
+    not change a bit of the per-item results, and a one-frame list behaves like the reference."""
+    from stabstitch2_amd import layers as L, smooth_network as SN
+    from stabstitch2_amd.temporal_network import build_TemporalNet
+    sp, tp, sm = hip_nets
+    x = torch.randn(7, 45, 60, 52, device=dev) * 0.1
+    x[..., 49:] = 0
+    full = L.run_regressor(x, tp._prepared()['r2'])
+    part = L.run_regressor(x, tp._prepared()['r2'], chunk=3)
+    close(part, full, 2e-5, 'chunked regressor')              # small batches take the split-K path: summation order
+    cv = torch.randn(2, 5, 45, 60, 124, device=dev) * 0.1
+    cv[..., 121:] = 0
+    fa, fb = L.run_regressor_pair(cv, sp._prepared()['r2_pair'])
+    pa, pb = L.run_regressor_pair(cv, sp._prepared()['r2_pair'], chunk=2)
+    close(pa, fa, 2e-5, 'chunked twin regressor a')
+    close(pb, fb, 2e-5, 'chunked twin regressor b')
+    rs = np.random.RandomState(5)
+    rigid = torch.from_numpy(cases.rigid(360, 480)).to(dev)
+    mesh = [rigid + torch.from_numpy(rs.normal(0, 2, (20, 7, 9, 2)).astype(np.float32)).to(dev) for _ in range(2)]
+    ts = [torch.from_numpy(rs.normal(0, 1, (20, 7, 9, 2)).astype(np.float32)).to(dev) for _ in range(2)]
+    o_full, d_full = sm.run_windows(mesh[0], mesh[1], ts[0], ts[1], 14, 7, 1, 1)
+    old = SN.WINDOW_CHUNK
+    SN.WINDOW_CHUNK = 5
+    try:
+        o_part, d_part = sm.run_windows(mesh[0], mesh[1], ts[0], ts[1], 14, 7, 1, 1)
+    finally:
+        SN.WINDOW_CHUNK = old
+    close(d_part, d_full, 2e-5, 'chunked SmoothNet windows')
+    for k in o_full:
+        close(o_part[k], o_full[k], 2e-4, 'chunked windows ' + k)
+    one = build_TemporalNet(tp, [torch.zeros(1, 3, 360, 480, device=dev)])['motion_list']
+    assert len(one) == 1 and tuple(one[0].shape) == (1, 7, 9, 2) and float(one[0].abs().max()) == 0.0
+
+
+def test_reloaded_weights_invalidate_derived_caches(dev):
+    """Shared-stem filters and the streaming twin trunk derive from two nets' weights; reloading one net must rebuild
+    them (weights_version), not reuse the stale ones."""
+    from stabstitch2_amd import pipeline
+    from stabstitch2_amd.spatial_network import SpatialNet
+    from stabstitch2_amd.temporal_network import TemporalNet
+    from stabstitch2_amd.smooth_network import SmoothNet
+    nets = []
+    for cls in (SpatialNet, TemporalNet, SmoothNet):
+        m = cls()
+        m.load_state_dict(synth.synthetic_state_dict(m), strict=True)
+        nets.append(m.to(dev))
+    _, lr = synth.make_clip_device(7, 360, 480, seed=2, device=dev)
+    a = pipeline.estimate_meshes(nets, lr[0], lr[1])
+    sd = synth.synthetic_state_dict(nets[1])
+    sd['feature_extractor_stage1.0.weight'] = sd['feature_extractor_stage1.0.weight'] * 1.5
+    v0 = nets[1].weights_version
+    nets[1].load_state_dict(sd, strict=True)
+    assert nets[1].weights_version != v0
+    b = pipeline.estimate_meshes(nets, lr[0], lr[1])              # shared stem path with the NEW temporal conv1
+    old = pipeline.SHARED_STEM
+    pipeline.SHARED_STEM = False
+    try:
+        c = pipeline.estimate_meshes(nets, lr[0], lr[1])          # separate stems: cannot be stale
+    finally:
+        pipeline.SHARED_STEM = old
+    assert float((a['tmotion2'] - b['tmotion2']).abs().max()) > 1e-4
+    close(b['tmotion2'], c['tmotion2'], 1e-4, 'shared stem after reload')
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_nets_on_second_gpu_while_first_is_current():
+    """Launches go to the GPU (and that GPU's current stream) that owns the tensors, not to the current device."""
+    from stabstitch2_amd import pipeline
+    from bench import build_nets
+    torch.cuda.set_device(0)
+    d1 = torch.device('cuda:1')
+    nets1, _ = build_nets(d1)
+    nets0, _ = build_nets(torch.device('cuda:0'))
+    hr, lr = synth.make_clip_device(8, 360, 480, seed=3, device='cpu')
+    r1 = pipeline.run_two_view(hr[0].to(d1), hr[1].to(d1), lr[0].to(d1), lr[1].to(d1), nets1)
+    assert torch.cuda.current_device() == 0 and r1[0].device == d1
+    r0 = pipeline.run_two_view(hr[0].cuda(0), hr[1].cuda(0), lr[0].cuda(0), lr[1].cuda(0), nets0)
+    assert (r0[1], r0[2]) == (r1[1], r1[2]) and torch.equal(r0[3].cpu(), r1[3].cpu()) and torch.equal(r0[0].cpu(), r1[0].cpu())

@@ -21,7 +21,9 @@ def built_lib():
     return _hip.lib()
 
 
-def test_cabi_exports_every_declared_symbol(built_lib):
+def test_cabi_exports_exactly_the_declared_symbols(built_lib):
+    """Two-sided: header == ctypes table == what the shared library exports under the ss_ prefix (the library is built
+    with -fvisibility=hidden; tuning knobs such as ss_debug_set exist only in the tools/ build)."""
     from stabstitch2_amd import _hip
     hdr = open(os.path.join(ROOT, 'include', 'stabstitch_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', hdr)))
@@ -29,7 +31,13 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     for name in declared:
         assert hasattr(built_lib, name), name
     assert sorted(_hip.SIGNATURES) == declared, 'ctypes table and header disagree'
-    assert built_lib.ss_version() >= 100
+    nm = subprocess.run(['nm', '-D', '--defined-only', _hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith('ss_')})
+    assert exported == declared, ('library exports != header', sorted(set(exported) ^ set(declared)))
+    assert 'getenv' not in nm                                   # no environment overrides inside the product library
+    und = subprocess.run(['nm', '-D', '--undefined-only', _hip.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'getenv' not in und
+    assert built_lib.ss_version() >= 200
     assert built_lib.ss_error_string(-1) == b'bad argument'
     # argument validation happens before any device work, so it can be exercised without a GPU
     assert built_lib.ss_conv_nhwc(None, None, None, None, None, *([1] * 15), 1, 0, 0, 0, None, 0, None) == -1
@@ -37,6 +45,10 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert built_lib.ss_tps_solve(None, None, None, 1, None) == -1
     assert built_lib.ss_ccl_workspace_floats(2, 23, 30, 256) == 2 * 690 * (512 + 690)
     assert built_lib.ss_tsmotion_workspace_floats(10) == 126 + 10 * 384
+    # split-K plan: large launches need no workspace, the tiny-map regressor tail does
+    assert built_lib.ss_conv_workspace_need(64, 1, 90, 120, 64, 64, 1, 3, 3, 1, 0, 1, 1, 1) == 0
+    need = built_lib.ss_conv_workspace_need(32, 1, 5, 7, 256, 256, 1, 3, 3, 1, 0, 1, 1, 1)
+    assert need > 0 and need % (32 * 5 * 7 * 256) == 0
 
 
 def test_product_never_imports_oracle_and_fails_without_gpu():
@@ -158,3 +170,28 @@ def test_two_rank_gloo_gather():
         assert allrec == [[96.0, 1.0, 740.0, 1882.0], [64.0, 2.0, 740.0, 1883.0]]
     from stabstitch2_amd import dist as D
     assert D.aggregate_fps(torch.tensor(res[0][2])) == 160.0 / 2.0
+
+
+def test_bench_self_launches_ranks_and_gathers():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (torch.distributed.run, 127.0.0.1),
+    each with its own clip seed, gathers one record per rank and prints ONE JSON line from rank 0.  Driven here with the
+    gloo backend and a stubbed step (no GPU in this container); on a GPU node the same code path initialises RCCL."""
+    import json
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--frames', '32', '--backend', 'gloo', '--stub-step-ms', '20'], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks'] == 2 and out['clip_seeds'] == [0, 1] and len(out['per_rank_seconds']) == 2
+    # whole-job value = all ranks' frames / slowest rank (rank 1 sleeps twice as long per step)
+    assert out['per_rank_seconds'][1] >= out['per_rank_seconds'][0] * 0.9
+    assert abs(out['value'] - 2 * 32 * 3 / max(out['per_rank_seconds'])) / out['value'] < 0.05
+    # N = 1 never spawns; a launcher-provided WORLD_SIZE that disagrees with --gpus is refused
+    env2 = dict(env, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub-step-ms', '1'],
+                        capture_output=True, text=True, env=env2, timeout=120)
+    assert r2.returncode != 0 and 'WORLD_SIZE=4' in (r2.stderr + r2.stdout)

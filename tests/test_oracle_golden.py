@@ -91,6 +91,8 @@ def test_g3_cost_volume(golden):
     a, b = cases.g3_inputs(False)
     close(N.cost_volume(a, b, 5), g['cv5'], 1e-5, 'cv5')
     close(N.cost_volume(a, b, 3), g['cv3'], 1e-5, 'cv3')
+    close(N.cost_volume(a, b, 5, norm=True), g['cv5n'], 1e-6, 'cv5 norm=True')
+    close(N.cost_volume(a, b, 3, norm=True), g['cv3n'], 1e-6, 'cv3 norm=True')
     fa, fb = cases.g3_inputs(True)
     f5 = N.cost_volume(fa, fb, 5)
     f3 = N.cost_volume(fa, fb, 3)
@@ -233,6 +235,31 @@ def test_g10_three_view(golden):
         # by ~1e-3 between CPUs already (0.12 grey levels oracle-vs-golden across two x86 hosts)
         tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
         close_boxes(got, g['frames_' + fm.lower()], g['iqr_' + fm.lower()], tol, 'three-view ' + fm, k=4, cover=cover)
+
+
+def test_g12_three_view_full_path(golden, nets):
+    """oracle run_three_view (two full 2-view passes + composition + render) vs the reference's own full three-view path
+    (test_online_tra_threeview.py:154-505), fixture G12."""
+    g = golden('g12_threeview_full')
+    n = g['mesh1'].shape[1]
+    hr, lr = synth.make_clip(n, 180, 320, seed=4, views=3)
+    a12 = P.estimate_meshes(nets, lr[0], lr[1])
+    a23 = P.estimate_meshes(nets, lr[1], lr[2])
+    close(a12['smooth_mesh1'], g['w12_m1'], 1e-3, 'w12_m1')
+    close(a12['smooth_mesh2'], g['w12_m2'], 1e-3, 'w12_m2')
+    close(a23['smooth_mesh1'], g['w23_m1'], 1e-3, 'w23_m1')
+    close(a23['smooth_mesh2'], g['w23_m2'], 1e-3, 'w23_m2')
+    m1, mid, m3 = P.three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'],
+                                       a23['smooth_mesh2'], 180, 320)
+    close(m1, g['mesh1'], 2e-3, 'mesh1')
+    close(mid, g['middle'], 2e-3, 'middle')
+    close(m3, g['mesh3'], 2e-3, 'mesh3')
+    for fm in ('AVERAGE', 'LINEAR'):
+        frames, ow, oh = P.three_view_render(hr[0], hr[1], hr[2], m1, mid, m3, 'NORMAL', fm)
+        assert [int(oh), int(ow)] == list(g['canvas_' + fm.lower()])
+        got = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), 4) for f in frames])
+        tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
+        close_boxes(got, g['frames_' + fm.lower()], g['iqr_' + fm.lower()], tol, 'G12 ' + fm, k=4, cover=cover)
 
 
 def test_g11_psnr_ssim(golden):

@@ -3,7 +3,8 @@ applies), 2 = LDS tap table without the fast path, 1 = arithmetic)."""
 import sys, os, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabstitch2_amd import ops, _hip
-lib = _hip.lib(); lib.ss_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+import _tuning
+lib = _tuning.lib()
 dev = torch.device('cuda:0')
 SHAPES = {'conv1': (64, 1, 360, 480, 4, 64, 1, 7, 2, 3), 'layer1': (64, 1, 90, 120, 64, 64, 1, 3, 1, 1),
           'layer2': (64, 1, 45, 60, 128, 128, 1, 3, 1, 1), 'layer3': (64, 1, 23, 30, 256, 256, 1, 3, 1, 1),

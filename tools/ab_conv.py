@@ -2,7 +2,8 @@
 import sys, os, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabstitch2_amd import ops, _hip
-lib = _hip.lib(); lib.ss_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+import _tuning
+lib = _tuning.lib()
 dev = torch.device('cuda:0')
 SHAPES = {'conv1': (64, 360, 480, 4, 64, 7, 2, 3), 'layer1': (64, 90, 120, 64, 64, 3, 1, 1), 'layer2': (64, 45, 60, 128, 128, 3, 1, 1),
           'layer3': (64, 23, 30, 256, 256, 3, 1, 1), 'l2.0': (64, 90, 120, 64, 128, 3, 2, 1), 'reg124': (32, 45, 60, 124, 64, 3, 1, 1)}

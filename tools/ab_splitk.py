@@ -1,7 +1,8 @@
 import sys, os, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabstitch2_amd import ops, _hip
-lib = _hip.lib(); lib.ss_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+import _tuning
+lib = _tuning.lib()
 dev = torch.device('cuda:0')
 cases = {'smooth3d': ((26, 7, 7, 9, 128), (128, 5, 3, 3, 128), (2, 1, 1)), 'reg128@11x15x32': ((32, 11, 15, 128), (128, 1, 3, 3, 128), (0, 1, 1)),
          'reg256@5x7x32': ((32, 5, 7, 256), (256, 1, 3, 3, 256), (0, 1, 1)), 'reg128@22x30x32': ((32, 22, 30, 128), (128, 1, 3, 3, 128), (0, 1, 1)),

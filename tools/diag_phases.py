@@ -3,7 +3,8 @@ import sys, os, torch, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabstitch2_amd import ops, _hip
-lib = _hip.lib(); lib.ss_debug_ptr.argtypes = [ctypes.c_void_p]
+import _tuning
+lib = _tuning.lib()
 dev = torch.device('cuda:0')
 SHAPES = {'layer1': (64, 90, 120, 64, 64, 3, 1, 1), 'layer2': (64, 45, 60, 128, 128, 3, 1, 1), 'layer3': (64, 23, 30, 256, 256, 3, 1, 1)}
 for name in sys.argv[1].split(','):
