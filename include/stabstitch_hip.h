@@ -66,6 +66,25 @@ SS_API int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, co
                  int groups, long long in_gs, long long w_gs, long long out_gs,
                  float* ws, long long ws_floats, void* stream);
 
+/* ---- the same convolution for 3x3 / stride 1 / pad 1 layers as fused Winograd F(2x2,3x3) on the fp32 matrix cores
+ * (2.25x fewer MFMA flops; input and output transforms inside the GEMM kernel, nothing extra through HBM).  Replaces
+ * the stride-1 3x3 nn.Conv2d(+BN)(+residual)(+ReLU) of the trunk bodies and regressors (spatial_network.py:132-136,
+ * 147-209, temporal_network.py:65-93).  Filters are transformed (G g G^T in fp64, rounded to fp32) and laid out in
+ * the kernel's B-operand register order ONCE per checkpoint load:
+ *   ss_wino_packed_floats(cout, cin)         floats of the packed buffer (per group); cout % 16 == 0
+ *   ss_wino_pack(wgt, packed, ...)           wgt [groups][cout][1][3][3][cin]  ->  packed [groups][...]
+ *   ss_conv3x3_wino_nhwc(...)                in [n][h][w][cin], out [n][h][w][out_cs]; cin % 4 == 0, cout % 64 == 0;
+ *                                            bias / res / relu / out_cs / groups as ss_conv_nhwc (u_gs = packed floats per group)
+ *   ss_conv_uses_winograd(...)               the engine's own dispatch rule for a layer geometry (1 = Winograd pays:
+ *                                            3x3 s1, cin >= 32, cout % 64 == 0, >= 70 % of the tile slots used, >= 512
+ *                                            workgroups); callers may apply any rule, results agree to fp32 rounding */
+SS_API long long ss_wino_packed_floats(int cout, int cin);
+SS_API int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, int groups, void* stream);
+SS_API int ss_conv_uses_winograd(int kt, int kh, int kw, int stride, int cin, int cout, int ho, int wo, int images);
+SS_API int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
+                                int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
+                                long long in_gs, long long u_gs, long long out_gs, void* stream);
+
 /* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */
 SS_API int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
                     void* stream);

@@ -25,6 +25,10 @@ SIGNATURES = {
     'ss_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_conv_workspace_need': (c_ll, [c_i] * 14),
     'ss_conv_nhwc': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 15 + [c_i, c_ll, c_ll, c_ll, c_fp, c_ll, c_st]),
+    'ss_wino_packed_floats': (c_ll, [c_i, c_i]),
+    'ss_wino_pack': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
+    'ss_conv_uses_winograd': (c_i, [c_i] * 9),
+    'ss_conv3x3_wino_nhwc': (c_i, [c_fp] * 5 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
     'ss_maxpool_nhwc': (c_i, [c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_maxpool_nhwc_split': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_linear': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),

@@ -1,6 +1,8 @@
 """Thin tensor-level wrappers over the C ABI: allocate outputs with torch, launch on the current stream of the
 device that owns the tensors, return device tensors.  These wrappers do no arithmetic of their own (the few
 mesh-sized torch expressions of the path live in pipeline.py and are named there)."""
+import os
+
 import torch
 
 from . import _hip as H
@@ -43,14 +45,57 @@ def _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups):
     return int(H.lib().ss_conv_workspace_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups))
 
 
+# Winograd F(2x2,3x3) for the stride-1 3x3 layers (csrc/wino.hip).  Host-level switch for A/B measurements and the
+# parity tests; the dispatch rule itself is the library's (ss_conv_uses_winograd).
+WINOGRAD = os.environ.get('SS_WINOGRAD', '1') == '1'
+
+
+def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
+    return bool(WINOGRAD and kt == 1 and tuple(pad) == (0, 1, 1) and
+                H.lib().ss_conv_uses_winograd(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho),
+                                              int(wo), int(images)))
+
+
 def conv_executed_flop_ratio(kt, kh, kw, stride, cin, cout, out_shape):
     """Executed MFMA flop / direct-convolution flop of the launch the engine picks for this geometry: 16/36 where the
     Winograd F(2x2,3x3) kernel runs (the library's own dispatch rule, ss_conv_uses_winograd), else 1."""
-    fn = getattr(H.lib(), 'ss_conv_uses_winograd', None)
-    if fn is None:
-        return 1.0
+    if len(out_shape) == 5 and kt == 1:          # grouped 2-D launch [g,n,ho,wo,c]
+        images = out_shape[0] * out_shape[1]
+    else:
+        images = out_shape[0]
     ho, wo = out_shape[-3], out_shape[-2]
-    return 16.0 / 36.0 if fn(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho), int(wo)) else 1.0
+    return 16.0 / 36.0 if _uses_winograd(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, images) else 1.0
+
+
+def wino_packed(wgt, groups):
+    """Transformed + packed filters of a 3x3 weight tensor ([cout,1,3,3,cin] or [g,cout,1,3,3,cin]), built on first use
+    by ss_wino_pack and kept on the tensor (prepared weights are rebuilt, hence re-packed, whenever a net is reloaded)."""
+    pk = getattr(wgt, '_wino_packed', None)
+    if pk is None:
+        cout, cin = wgt.shape[-5], wgt.shape[-1]
+        per = int(H.lib().ss_wino_packed_floats(cout, cin))
+        pk = torch.empty((groups, per), device=wgt.device, dtype=torch.float32)
+        H.call('ss_wino_pack', H.dptr(wgt), H.dptr(pk), cout, cin, groups, H.stream())
+        wgt._wino_packed = pk
+    return pk
+
+
+def conv_winograd(x, wgt, bias=None, res=None, relu=False, out=None):
+    """3x3 / stride 1 / pad 1 convolution on the fused Winograd F(2x2,3x3) kernel, unconditionally (ops.conv applies the
+    library's dispatch rule).  x nhwc [n,h,w,c] (or [g,n,h,w,c] with wgt [g,cout,1,3,3,c]: grouped launch)."""
+    grouped = wgt.dim() == 6
+    g = wgt.shape[0] if grouped else 1
+    cout, cin = wgt.shape[-5], wgt.shape[-1]
+    assert tuple(wgt.shape[-4:-1]) == (1, 3, 3) and x.shape[-1] == cin, (wgt.shape, x.shape)
+    shared = grouped and x.dim() == 4
+    n, h, w = x.shape[-4], x.shape[-3], x.shape[-2]
+    if out is None:
+        out = torch.empty(((g, n, h, w, cout) if grouped else (n, h, w, cout)), device=x.device, dtype=torch.float32)
+    pk = wino_packed(wgt, g)
+    H.call('ss_conv3x3_wino_nhwc', H.dptr(x), H.dptr(pk), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
+           n, h, w, cin, cout, int(relu), out.shape[-1], g, 0 if (shared or not grouped) else x[0].numel(),
+           pk.shape[1], out[0].numel() if grouped else 0, H.stream())
+    return out
 
 
 def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=None):
@@ -70,6 +115,8 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     if out is None:
         shape = (n, to, ho, wo, cout) if five else (n, ho, wo, cout)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    if not five and _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n):
+        return conv_winograd(x, wgt, bias, res, relu, out)
     ws = conv_workspace(x.device, _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, 1))
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), out.shape[-1],
@@ -93,6 +140,8 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
     ho = (h + 2 * ph - kh) // stride + 1
     wo = (w + 2 * pw - kw) // stride + 1
     out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    if _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n * g):
+        return conv_winograd(x, wgt, bias, res, relu, out)
     ws = conv_workspace(x.device, _conv_ws_need(n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, g))
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), cout,

@@ -175,7 +175,7 @@ def test_dlt_decomposition_meshes(dev, golden):
     H = torch_DLT.tensor_DLT(c.to(dev), (c + off.reshape(b, 4, 2)).to(dev)).cpu()
     pts = torch.tensor([[0., 0., 1.], [480., 0., 1.], [0., 360., 1.], [480., 360., 1.], [240., 180., 1.]]).T
     pa, pb = H @ pts, torch.from_numpy(g['H_full']) @ pts
-    close(pa[:, :2] / pa[:, 2:3], pb[:, :2] / pb[:, 2:3], 5e-2, 'DLT action on corners (px)')
+    close(pa[:, :2] / pa[:, 2:3], pb[:, :2] / pb[:, 2:3], 5e-3, 'DLT action on corners (px)')
     zero = torch.zeros(b, 126, device=dev)
     m1, m2 = ops.spatial_meshes(off.to(dev), zero, zero, 360, 480)
     rigid = torch.from_numpy(g['rigid'])
@@ -224,7 +224,7 @@ def test_tps_dense_warp_and_fusion(dev, golden):
     Ud, sd, td = U.to(dev), src.to(dev), tgt.to(dev)
     wn = torch_tps_transform.transformer(Ud, sd, td, size, 'NORMAL')
     wf = torch_tps_transform.transformer(Ud, sd, td, size, 'FAST')
-    close(wn[:, 3:5], g['normal'][:, 3:5], 2e-4 * 96 / 2 + 1e-4, 'coords NORMAL (px)')
+    close(wn[:, 3:5], g['normal'][:, 3:5], 2.5e-3, 'coords NORMAL (px)')          # observed 2.4e-4 px
     close(wn[:, 0:3], g['normal'][:, 0:3], 2e-3, 'intensity NORMAL')
     close_grad(wf, g['fast'], 5e-3, 2e-3, 'FAST')
     close(torch_tps_transform.transformer(Ud, ident.to(dev), td, (72, 96), 'NORMAL'), g['ident_normal'], 2e-3, 'id N')
@@ -271,16 +271,16 @@ def test_nets_vs_reference(dev, golden, hip_nets, clip16):
     sp, tp, sm = hip_nets
     _, lr = clip16
     o1, o2r, o2t = sp(lr[0][0].to(dev), lr[1][0].to(dev))
-    close(o1, g['offset_1'], 1e-3, 'offset_1')
-    close(o2r, g['offset_2_ref'], 1e-3, 'offset_2_ref')
-    close(o2t, g['offset_2_tgt'], 1e-3, 'offset_2_tgt')
+    close(o1, g['offset_1'], 1e-4, 'offset_1')                 # gates = ~10x the observed deviations (4e-6 px)
+    close(o2r, g['offset_2_ref'], 1e-4, 'offset_2_ref')
+    close(o2t, g['offset_2_tgt'], 1e-4, 'offset_2_tgt')
     lr1 = torch.cat(lr[0], 0).to(dev)
     lr2 = torch.cat(lr[1], 0).to(dev)
     o = build_SpatialNet(sp, lr1, lr2)                      # whole clip as one batch
-    close(o['motion1'], g['motion1'], 5e-2, 'motion1')
-    close(o['motion2'], g['motion2'], 5e-2, 'motion2')
+    close(o['motion1'], g['motion1'], 5e-3, 'motion1')         # observed 3-5e-4 px (the fp64 DLT vs the reference's fp32 inverse)
+    close(o['motion2'], g['motion2'], 5e-3, 'motion2')
     tm = build_TemporalNet(tp, [f.to(dev) for f in lr[0]])['motion_list']
-    close(torch.cat(tm, 0), g['tmotion1'], 1e-3, 'tmotion1')
+    close(torch.cat(tm, 0), g['tmotion1'], 1e-4, 'tmotion1')
     rigid = torch.from_numpy(cases.rigid(360, 480)).to(dev)
     ts1 = [torch.from_numpy(g['tsmotion1'][i:i + 1]).to(dev) for i in range(7)]
     ts2 = [torch.from_numpy(g['tsmotion2'][i:i + 1]).to(dev) for i in range(7)]
@@ -291,7 +291,7 @@ def test_nets_vs_reference(dev, golden, hip_nets, clip16):
     w0 = build_SmoothNet(sm, ts1, ts2, sm1, sm2)
     assert sorted(w0) == sorted(k[3:] for k in g.files if k.startswith('w0_'))
     for k, v in w0.items():
-        close(v, g['w0_' + k], 2e-3, 'window0 ' + k)
+        close(v, g['w0_' + k], 5e-4, 'window0 ' + k)             # observed 3e-5
 
 
 def test_pipeline_vs_reference(dev, golden, hip_nets, clip16):
@@ -299,10 +299,10 @@ def test_pipeline_vs_reference(dev, golden, hip_nets, clip16):
     g = golden('g9_pipeline')
     hr, lr = clip16
     acc = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
-    close(acc['smooth_mesh1'], g['smooth_mesh1'], 5e-2, 'smooth_mesh1')
-    close(acc['smooth_mesh2'], g['smooth_mesh2'], 5e-2, 'smooth_mesh2')
-    close(acc['ori_path2'], g['ori_path2'], 5e-2, 'ori_path2')
-    close(acc['smooth_path2'], g['smooth_path2'], 5e-2, 'smooth_path2')
+    close(acc['smooth_mesh1'], g['smooth_mesh1'], 5e-3, 'smooth_mesh1')      # observed 4-5e-4 px
+    close(acc['smooth_mesh2'], g['smooth_mesh2'], 5e-3, 'smooth_mesh2')
+    close(acc['ori_path2'], g['ori_path2'], 1e-2, 'ori_path2')            # a 15-step cumulative sum: observed 1.1e-3
+    close(acc['smooth_path2'], g['smooth_path2'], 1e-2, 'smooth_path2')
     m1 = torch.from_numpy(g['smooth_mesh1']).to(dev)
     m2 = torch.from_numpy(g['smooth_mesh2']).to(dev)
     for wm, fm in (('NORMAL', 'AVERAGE'), ('FAST', 'AVERAGE'), ('NORMAL', 'LINEAR')):
@@ -343,9 +343,9 @@ def test_three_view_vs_reference(dev, golden):
     n = meshes[0].shape[1]
     hr, _ = synth.make_clip(n, 180, 320, seed=3, views=3)
     mesh1, mid, mesh3 = pipeline.three_view_compose(*meshes, 180, 320)
-    close(mesh1, g['mesh1'], 5e-2, 'mesh1')
-    close(mid, g['middle'], 5e-2, 'middle')
-    close(mesh3, g['mesh3'], 5e-2, 'mesh3')
+    close(mesh1, g['mesh1'], 5e-3, 'mesh1')                   # observed 3.4e-4 px
+    close(mid, g['middle'], 1e-3, 'middle')
+    close(mesh3, g['mesh3'], 5e-3, 'mesh3')
     gm = [torch.from_numpy(g[k]).to(dev) for k in ('mesh1', 'middle', 'mesh3')]
     for fm in ('AVERAGE', 'LINEAR'):
         frames, hc, wc = pipeline.three_view_render(hr[0], hr[1], hr[2], *gm, 'NORMAL', fm)
@@ -903,3 +903,79 @@ def test_nets_on_second_gpu_while_first_is_current():
     assert torch.cuda.current_device() == 0 and r1[0].device == d1
     r0 = pipeline.run_two_view(hr[0].cuda(0), hr[1].cuda(0), lr[0].cuda(0), lr[1].cuda(0), nets0)
     assert (r0[1], r0[2]) == (r1[1], r1[2]) and torch.equal(r0[3].cpu(), r1[3].cpu()) and torch.equal(r0[0].cpu(), r1[0].cpu())
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,bias,res,relu', [
+    (3, 64, 64, 90, 120, True, True, True),        # layer1 body (8x4 tile blocks, ragged bottom)
+    (2, 128, 128, 45, 60, True, False, True),      # layer2 body: odd height (half tiles), 2 cout blocks
+    (2, 256, 256, 23, 30, True, True, True),       # layer3 body: 4x8 tile blocks, odd height
+    (2, 121, 64, 45, 60, False, False, True),      # cost-volume regressor conv: 121 -> 124 channels (channel tail)
+    (1, 49, 64, 45, 60, False, False, True),       # 49 -> 52 channels
+    (2, 64, 128, 37, 51, True, True, False),       # odd x odd map, no ReLU
+    (5, 128, 64, 11, 15, False, False, True),      # small map (below the dispatch threshold, kernel must still be right)
+    (1, 32, 64, 2, 2, True, False, False),         # a single tile
+])
+def test_conv_winograd(dev, n, cin, cout, h, w, bias, res, relu):
+    """Fused Winograd F(2x2,3x3) kernel vs F.conv2d (fp32 CPU) and vs the implicit-GEMM kernel."""
+    from stabstitch2_amd import ops
+    rs = np.random.RandomState(n * 977 + cin + cout + h)
+    x = torch.from_numpy(rs.normal(0, 1, (n, cin, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    b = torch.from_numpy(rs.normal(0, 1, cout).astype(np.float32)) if bias else None
+    ref = F.conv2d(x, wt, b, stride=1, padding=1)
+    r = torch.from_numpy(rs.normal(0, 1, tuple(ref.shape)).astype(np.float32)) if res else None
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    cp = (cin + 3) // 4 * 4
+    xd = ops.nchw_to_nhwc(x.to(dev), cp)
+    rd = ops.nchw_to_nhwc(r.to(dev)) if res else None
+    wd = _pack(wt, cp).to(dev)
+    out = ops.conv_winograd(xd, wd, b.to(dev) if bias else None, rd, relu=relu)
+    scale = max(1.0, float(ref.abs().max()))
+    close(ops.nhwc_to_nchw(out), ref, 4e-5 * scale, 'winograd conv vs F.conv2d')
+    old = ops.WINOGRAD
+    ops.WINOGRAD = False
+    try:
+        direct = ops.conv(xd, wd, b.to(dev) if bias else None, rd, stride=1, pad=(0, 1, 1), relu=relu)
+    finally:
+        ops.WINOGRAD = old
+    close(out, direct, 4e-5 * scale, 'winograd vs implicit GEMM')
+    # out_cs > cout (channel-padded destination) leaves the padding untouched
+    wide = torch.full((n, h, w, cout + 4), 7.0, device=dev)
+    ops.conv_winograd(xd, wd, b.to(dev) if bias else None, None, relu=False, out=wide)
+    assert float((wide[..., cout:] - 7.0).abs().max()) == 0.0
+
+
+def test_conv_winograd_grouped_and_dispatch(dev):
+    """Grouped launches (twin regressors / twin trunks) and the dispatch rule: ops.conv picks Winograd exactly where
+    ss_conv_uses_winograd says so, and both engines agree on the pipeline's layer shapes."""
+    from stabstitch2_amd import ops, _hip
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.normal(0, 1, (2, 6, 45, 60, 64)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rs.normal(0, 1, (2, 128, 1, 3, 3, 64)) / 24.0).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rs.normal(0, 1, (2, 128)).astype(np.float32)).to(dev)
+    g = ops.conv_winograd(x, w, b, None, relu=True)
+    for k in range(2):
+        one = ops.conv_winograd(x[k], w[k].contiguous(), b[k].contiguous(), None, relu=True)
+        assert torch.equal(g[k], one)
+    shared = ops.conv_winograd(x[0], w, b, None, relu=True)          # one input read by both groups
+    assert torch.equal(shared[0], g[0])
+    lib = _hip.lib()
+    assert lib.ss_conv_uses_winograd(1, 3, 3, 1, 64, 64, 90, 120, 64) == 1
+    assert lib.ss_conv_uses_winograd(1, 3, 3, 2, 64, 128, 45, 60, 64) == 0       # strided
+    assert lib.ss_conv_uses_winograd(1, 7, 7, 2, 4, 64, 180, 240, 64) == 0       # conv1
+    assert lib.ss_conv_uses_winograd(5, 3, 3, 1, 128, 128, 7, 9, 26) == 0        # Conv3d
+    assert lib.ss_conv_uses_winograd(1, 3, 3, 1, 4, 64, 23, 30, 32) == 0         # 2-channel flow input
+    xl = torch.from_numpy(rs.normal(0, 1, (64, 45, 60, 128)).astype(np.float32)).to(dev)
+    wl = torch.from_numpy((rs.normal(0, 1, (128, 1, 3, 3, 128)) / 34.0).astype(np.float32)).to(dev)
+    a = ops.conv(xl, wl, None, None, relu=True)                        # dispatches to Winograd (large launch)
+    assert torch.equal(a, ops.conv_winograd(xl, wl, None, None, relu=True))
+    old = ops.WINOGRAD
+    ops.WINOGRAD = False
+    try:
+        d = ops.conv(xl, wl, None, None, relu=True)
+    finally:
+        ops.WINOGRAD = old
+    close(a, d, 4e-5 * max(1.0, float(d.abs().max())), 'dispatch: winograd vs implicit GEMM')
