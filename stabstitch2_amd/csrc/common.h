@@ -63,3 +63,8 @@ __device__ __forceinline__ float ss_wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+#ifdef SS_TUNING
+// tools/ build only: buffer for per-workgroup s_memtime stamps (set through ss_debug_ptr, conv.hip)
+extern unsigned long long* ss_tuning_dbg;
+#endif

@@ -445,7 +445,8 @@ static int g_amode_off = 0;         // key 3: 1 = arithmetic addressing, 2 = tab
 static int g_force_tile = 0;        // key 0: force a tile variant
 static int g_ablate = 0;            // key 1: ablation mask
 static int g_split_target = 512;    // key 2: workgroups a split-K launch aims for
-static unsigned long long* g_dbg = nullptr;
+unsigned long long* ss_tuning_dbg = nullptr;
+#define g_dbg ss_tuning_dbg
 extern "C" SS_API void ss_debug_ptr(void* ptr) { g_dbg = (unsigned long long*)ptr; }
 extern "C" SS_API void ss_debug_set(int key, int value) {
     if (key == 0) g_force_tile = value;

@@ -23,10 +23,11 @@
 //       against 32 ds_read_b128 (A operand, shared by the 4 waves) and 16 global 16-byte loads (B operand: the
 //       transformed filters are PRE-PACKED in the exact register layout of the B operand, so they go global -> VGPR,
 //       fully coalesced, no LDS, no reuse lost: each element is needed by exactly one wave of the workgroup);
-//   epilogue: the 16 positions of one (tile, cout) sit in ONE lane, so A^T M A is register arithmetic; bias (folded
-//   BatchNorm), residual, ReLU; 64-byte runs of NHWC stores through buffer instructions with out-of-range offsets for
-//   pixels outside the image.
-// Two workgroups per CU (58 KB LDS, <= 256 registers): one transforms while the other feeds the MFMA pipe.
+//   epilogue: the 16 positions of one (tile, cout) sit in ONE lane, so A^T M A is register arithmetic; the 2x2 results
+//   are staged through LDS so that bias (folded BatchNorm), residual, ReLU and the NHWC store run on whole 256-byte pixel
+//   rows with 16-byte accesses (out-of-range offsets for pixels outside the image: no branches).
+// Two workgroups per CU (58 KB LDS, <= 256 registers): one transforms while the other feeds the MFMA pipe; everything
+// outside the MFMA phase runs at raised wave priority so that it is not queued behind the other workgroup's MFMAs.
 #include "common.h"
 
 typedef float w_f32x4 __attribute__((ext_vector_type(4)));
@@ -47,7 +48,16 @@ struct WinoP {
     SsDiv32 divNcb;
     long long in_gs, u_gs, out_gs;      // element strides between groups
     unsigned in_bytes, out_bytes, u_bytes;
+#ifdef SS_TUNING
+    unsigned long long* dbg;            // per-workgroup phase stamps (tools/diag_wino.py)
+#endif
 };
+
+#ifdef SS_TUNING
+#define W_STAMP(i) do { if (p.dbg) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float* base, unsigned bytes) {
     unsigned long long a = (unsigned long long)base;
@@ -66,11 +76,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
     constexpr int NE = (RPIX * 4 + 255) / 256;              // 16-byte raw items per thread
     constexpr int VS = 20;                                  // V row stride in dwords (16 k + pad)
     __shared__ __attribute__((aligned(16))) float raw[RPIX * RS];
-    __shared__ __attribute__((aligned(16))) float V[16 * 32 * VS];
+    __shared__ __attribute__((aligned(16))) float V[16 * 32 * VS];      // the epilogue reuses it as the output stage (32 KB)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SS_TUNING
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // Everything outside the MFMA phase (setup, transforms, epilogue) is VALU / LDS work that shares its SIMD with the
+    // OTHER resident workgroup's MFMAs; at equal priority every VALU instruction waits for an MFMA boundary (measured:
+    // 3.9k cycles per input transform, 18k per epilogue).  Raised priority lets it through (same rule as conv.hip).
+    __builtin_amdgcn_s_setprio(3);
+    W_STAMP(0);
 
     // XCD-aware block order (as conv.hip): consecutive workgroups go round-robin to the 8 XCDs; give every XCD one
     // contiguous run of m-blocks (all cout blocks of an m-block back to back) so halo rows and the cout-block re-reads of
@@ -147,16 +165,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
             dst[k] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * k, so, 0));
     };
     auto transform = [&](int row) {
-        // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  -> (first, second, sign of second)
+        // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3; `row` is wave-uniform (scalar branches, packed adds)
         const int ra = row == 0 ? 0 : (row == 2 ? 2 : 1);
         const int rb = row == 3 ? 3 : (row == 2 ? 1 : 2);
-        const float sg = row == 1 ? 1.f : -1.f;
-        w_f32x4 r[4];
+        w_f32x4 x[4], y[4], r[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const w_f32x4 x = *reinterpret_cast<const w_f32x4*>(&raw[t_src + (ra * RW + b) * RS]);
-            const w_f32x4 y = *reinterpret_cast<const w_f32x4*>(&raw[t_src + (rb * RW + b) * RS]);
-            r[b] = x + sg * y;
+            x[b] = *reinterpret_cast<const w_f32x4*>(&raw[t_src + (ra * RW + b) * RS]);
+            y[b] = *reinterpret_cast<const w_f32x4*>(&raw[t_src + (rb * RW + b) * RS]);
+        }
+        if (row == 1) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r[b] = x[b] + y[b];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r[b] = x[b] - y[b];
         }
         float* dst = &V[(row * 4) * 32 * VS + t_dst];
         *reinterpret_cast<w_f32x4*>(dst) = r[0] - r[2];
@@ -186,16 +209,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 
     raw_issue(0);
     u_issue(ua, 0, 0);
+    W_STAMP(1);
     for (int c = 0; c < p.nchunk; ++c) {
         // registers -> LDS raw patch (everyone is past the previous chunk's transform: it read `raw` before barrier B)
 #pragma unroll
         for (int e = 0; e < NE; ++e)
             if (NE * 256 == RPIX * 4 || tid + 256 * e < RPIX * 4) *reinterpret_cast<w_u32x4*>(&raw[rlds[e]]) = rr[e];
         __syncthreads();                        // A: raw visible; every wave has finished the previous chunk's MFMAs (V free)
+        if (c == 0) W_STAMP(5);
+        if (c == 1) W_STAMP(7);
         transform(t_row0);
         transform(t_row0 + 2);
         __syncthreads();                        // B: V complete
+        if (c == 0) W_STAMP(6);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
         u_issue(ub, c, 1);                      // second half of this chunk's filters: used ~2000 cycles from now
         __builtin_amdgcn_sched_barrier(0);
         mma_half(ua, 0);
@@ -210,64 +238,86 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         mma_half(ub, 1);
+        __builtin_amdgcn_s_setprio(3);
+        if (c == 0) W_STAMP(4);
     }
+    W_STAMP(2);
 
     // ---------------------------------------------------------------- epilogue: Y = A^T M A, bias, residual, ReLU
+    // The 16 positions of one (tile, cout) sit in one lane: A^T M A is register arithmetic.  The 2x2 results go through
+    // LDS (the V buffer, free now) so that global memory sees whole 256-byte pixel rows as 16-byte accesses: stage
+    // S[pixel = tile * 4 + 2a + b][64 couts], the cout index rotated by 16 * ((pixel >> 4) & 3) so that the four 16-lane
+    // groups of a wave (four different tiles) write four different bank groups.
     float* __restrict__ out = p.out + (long long)grp * p.out_gs;
     const float* __restrict__ res = p.res ? p.res + (long long)grp * p.out_gs : nullptr;
     const __amdgpu_buffer_rsrc_t rout = w_rsrc(out, p.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = w_rsrc(res ? res : out, p.out_bytes);
-    const int co = (int)cb16 * 16 + (lane & 15);
-    const float bias = p.bias ? p.bias[(long long)grp * p.Co + co] : 0.f;
+    // this thread's 8 output items: (pixel = e * 16 + tid / 16, channel quad = tid % 16)
+    const int cq = tid & 15;
+    unsigned goff[8];
+    w_u32x4 rv[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int e = 0; e < 8; ++e) {
+        const int px = e * 16 + (tid >> 4);
+        const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
+        const int ty = tile / TBW, tx = tile - ty * TBW;
+        const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + b;
+        const bool ok = oy < p.H && ox < p.W;
+        goff[e] = ok ? ((((unsigned)img * p.H + oy) * p.W + ox) * (unsigned)p.out_cs + cbk * 64u + 4u * cq) * 4u : 0xFFFFFFFFu;
+    }
+    if (res) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tile = half * 16 + 4 * (lane >> 4) + r;
-            const int ty = tile / TBW, tx = tile - ty * TBW;
-            const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-            float T[4][2];
+        for (int e = 0; e < 8; ++e) rv[e] = __builtin_amdgcn_raw_buffer_load_b128(rres, goff[e], 0, 0);
+    }
+    w_f32x4 bias4 = (w_f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const w_f32x4*>(p.bias + (long long)grp * p.Co + cbk * 64 + 4 * cq);
+    __syncthreads();                            // every wave is done reading V
+    {
+        const int cw = wave * 16 + (lane & 15);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float m0 = acc[4 * i + 0][half][r], m1 = acc[4 * i + 1][half][r];
-                const float m2 = acc[4 * i + 2][half][r], m3 = acc[4 * i + 3][half][r];
-                T[i][0] = (m0 + m1) + m2;
-                T[i][1] = (m1 - m2) - m3;
-            }
-            float Y[2][2];
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                Y[0][b] = (T[0][b] + T[1][b]) + T[2][b];
-                Y[1][b] = (T[1][b] - T[2][b]) - T[3][b];
-            }
-            unsigned off[2][2];
+            for (int r = 0; r < 4; ++r) {
+                const int tile = half * 16 + 4 * (lane >> 4) + r;
+                float T[4][2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int i = 0; i < 4; ++i) {
+                    const float m0 = acc[4 * i + 0][half][r], m1 = acc[4 * i + 1][half][r];
+                    const float m2 = acc[4 * i + 2][half][r], m3 = acc[4 * i + 3][half][r];
+                    T[i][0] = (m0 + m1) + m2;
+                    T[i][1] = (m1 - m2) - m3;
+                }
+                // rotation: (pixel >> 4) & 3 = (tile >> 2) & 3 = lane >> 4 for every pixel of this tile
+                float* srow = &V[(tile * 4) * 64 + ((cw + 16 * (lane >> 4)) & 63)];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const bool ok = (oy + a) < p.H && (ox + b) < p.W;
-                    off[a][b] = ok ? (((((unsigned)img * p.H + oy + a) * p.W + ox + b) * (unsigned)p.out_cs) + (unsigned)co) * 4u
-                                   : 0xFFFFFFFFu;
+                    srow[b * 64] = (T[0][b] + T[1][b]) + T[2][b];
+                    srow[(2 + b) * 64] = (T[1][b] - T[2][b]) - T[3][b];
                 }
-            float rv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-            if (res) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        rv[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, off[a][b], 0, 0));
             }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float v = Y[a][b] + bias;
-                    if (res) v += rv[a][b];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off[a][b], 0, 0);
-                }
         }
     }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int px = e * 16 + (tid >> 4);
+        w_f32x4 v = *reinterpret_cast<const w_f32x4*>(&V[px * 64 + ((4 * cq + 16 * ((px >> 4) & 3)) & 63)]);
+        v = v + bias4;
+        if (res) v = v + __builtin_bit_cast(w_f32x4, rv[e]);
+        if (p.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w_u32x4, v), rout, goff[e], 0, 0);
+    }
+#ifdef SS_TUNING
+    if (p.dbg && tid == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 10;
+        for (int i = 0; i < 8; ++i) d[i] = ts[i];
+        d[8] = __builtin_amdgcn_s_memtime();
+        d[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -363,6 +413,9 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
     p.in_bytes = (unsigned)(in_elems * 4);
     p.out_bytes = (unsigned)(out_elems * 4);
     p.u_bytes = (unsigned)(u_floats * 4);
+#ifdef SS_TUNING
+    p.dbg = ss_tuning_dbg;
+#endif
     const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
     if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
     dim3 g((unsigned)wgs, 1, groups);

@@ -745,11 +745,28 @@ def test_run_three_view_vs_oracle(dev, hip_nets, h, w, n):
     got = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), k) for f in fr])
     ref = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), k) for f in ofr])
     rng = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), k) for f in ofr])
-    # chained AVERAGE is chaotic where only view 3 is valid: clean boxes only, loose bound there
-    close_boxes(got, ref, rng, 3.0, 'three-view frames vs oracle', k=k, cover=0.3)
+    # chained AVERAGE is chaotic where only view 3 is valid (avg(residue, residue) hits its 1e-6
+    # denominator, the reference's own output there differs between machines by O(10) grey levels): compare the boxes
+    # left of the middle view's right border sharply, the rest only through the median deviation
+    xlim = int(float(omid[..., 0].max()) // k) - 1
     ok = cases.smooth_boxes(rng, k)
-    d = np.abs(got - ref)[ok]
-    assert np.median(d) < 0.02, float(np.median(d))
+    ok[:, :, xlim:] = False
+    assert ok.mean() > 0.3, ok.mean()
+    dd = np.abs(got - ref)[ok]
+    if os.environ.get('SS_VERBOSE'):
+        print('  three-view AVERAGE (views 1-2 region): p99 %.3e  p99.9 %.3e  max %.3e' % (
+            np.quantile(dd, 0.99), np.quantile(dd, 0.999), dd.max()))
+    # isolated boxes on the outer border (neither of views 1, 2 valid) stay chaotic: quantiles, with the old loose bound as max
+    assert np.quantile(dd, 0.99) < 0.05 and dd.max() < 3.0, (float(np.quantile(dd, 0.99)), float(dd.max()))
+    clean = cases.smooth_boxes(rng, k)
+    assert np.median(np.abs(got - ref)[clean]) < 0.02, float(np.median(np.abs(got - ref)[clean]))
+    # LINEAR fusion has no singular denominator: whole canvas
+    frl = pipeline.run_three_view(hrd[0], hrd[1], hrd[2], lrd[0], lrd[1], lrd[2], hip_nets, 'NORMAL', 'LINEAR')[0]
+    ofl = P.three_view_render(hr[0], hr[1], hr[2], om1, omid, om3, 'NORMAL', 'LINEAR')[0]
+    gl = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), k) for f in frl])
+    rl = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), k) for f in ofl])
+    il = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), k) for f in ofl])
+    close_boxes(gl, rl, il, 0.5, 'three-view LINEAR frames vs oracle', k=k, cover=0.5)
 
 
 def test_three_view_full_path_vs_reference(dev, golden, hip_nets):
