@@ -10,24 +10,26 @@
 // this network (64..256 channels); here both transforms live inside the GEMM kernel:
 //
 //   workgroup = 256 threads = 4 waves; tile = 32 output tiles (TBH x TBW block of 2x2 tiles = 2TBH x 2TBW pixels of ONE
-//   image) x 64 output channels x all 16 positions; K loop over cin in chunks of 16.
+//   image) x 64 output channels x all 16 positions; K loop over cin in chunks of 16.  Wave i owns ROW i of the 4x4
+//   transform domain (positions 4i..4i+3) for all 32 tiles and all 64 output channels: 4 x 2 accumulator tiles of
+//   v_mfma_f32_32x32x2_f32 = 128 registers.
 //   per chunk:
 //     * raw (2TBH+2) x (2TBW+2) x 16ch input patch: coalesced 16-byte buffer loads issued one chunk ahead (halo / M tail
 //       / channel tail through the descriptor's bounds check: invalid lanes get offset 0xFFFFFFFF and read zeros),
-//       registers -> LDS `raw`;
-//     * input transform B^T d B: 512 tasks (tile, channel quad, transform row) -> 2 per thread, 8 ds_read_b128 +
-//       8 float4 adds + 4 ds_write_b128 each (the transform row is wave-uniform: no divergence); result V[pos][tile][k]
-//       k-contiguous in LDS (row stride 20 dwords: conflict-free 16-byte reads);
-//     * GEMMs on v_mfma_f32_16x16x4_f32: wave w owns output channels [16w, 16w+16) of the block for ALL 16 positions and
-//       both 16-tile halves: 16 x 2 accumulator tiles of 4 registers = 128 registers; per chunk 128 MFMAs per wave
-//       against 32 ds_read_b128 (A operand, shared by the 4 waves) and 16 global 16-byte loads (B operand: the
-//       transformed filters are PRE-PACKED in the exact register layout of the B operand, so they go global -> VGPR,
-//       fully coalesced, no LDS, no reuse lost: each element is needed by exactly one wave of the workgroup);
-//   epilogue: the 16 positions of one (tile, cout) sit in ONE lane, so A^T M A is register arithmetic; the 2x2 results
-//   are staged through LDS so that bias (folded BatchNorm), residual, ReLU and the NHWC store run on whole 256-byte pixel
-//   rows with 16-byte accesses (out-of-range offsets for pixels outside the image: no branches).
-// Two workgroups per CU (58 KB LDS, <= 256 registers): one transforms while the other feeds the MFMA pipe; everything
-// outside the MFMA phase runs at raised wave priority so that it is not queued behind the other workgroup's MFMAs.
+//       registers -> LDS transposed to channel planes [channel][row][col] (two buffers, one barrier per chunk);
+//     * input transform B^T d B IN THE MFMA OPERAND LAYOUT: lane (tile = lane & 31, k half = lane >> 5) reads rows
+//       (ra, rb) of its tile's 4x4 patch for its 8 channels (16 conflict-free 8-byte-pair LDS reads), one packed
+//       add/sub for the row stage, four scalar add/subs per channel for the column stage -> the 32 A-operand registers
+//       of the wave's 4 positions.  The transformed input never exists in memory (first version: 128 KB of LDS
+//       reads per chunk for the A operands, LDS-bound);
+//     * 64 MFMAs per wave: B operand = transformed filters PRE-PACKED in the register layout of the instruction, global
+//       -> VGPR, fully coalesced 1 KB loads, prefetched one position (1024 MFMA cycles) ahead; each filter element is
+//       needed by exactly one wave of the workgroup, so nothing is lost by skipping LDS;
+//   epilogue: wave i forms T[i][b] = sum_j M[i][j] A[j][b] in registers, stages it in LDS; then each thread sums the
+//   three T rows of its pixels in a fixed order (A^T), adds bias (folded BatchNorm) / residual, applies ReLU and stores
+//   whole 256-byte pixel rows with 16-byte accesses (out-of-range offsets for pixels outside the image: no branches).
+// Two workgroups per CU (64 KB LDS, <= 256 registers); the waves of a workgroup are decoupled inside the K loop (one
+// barrier per chunk), so one wave's transform runs under the other waves' MFMAs.
 #include "common.h"
 
 typedef float w_f32x4 __attribute__((ext_vector_type(4)));
@@ -67,16 +69,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float* base, unsi
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+typedef float w_f32x16 __attribute__((ext_vector_type(16)));
+typedef float w_f32x2 __attribute__((ext_vector_type(2)));
+
 template <int TBH, int TBW>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
     static_assert(TBH * TBW == 32, "32 tiles per workgroup");
     constexpr int RH = 2 * TBH + 2, RW = 2 * TBW + 2;      // raw input patch (pixels)
     constexpr int RPIX = RH * RW;
-    constexpr int RS = 24;                                  // raw pixel stride in dwords (16 channels + pad)
+    constexpr int RWP = TBW == 4 ? 12 : 24;                 // LDS row pitch of a channel plane (dwords): see `transform`
+    constexpr int PLANE = RH * RWP + 4;                     // channel plane stride; = 4 (mod 8): 2 lanes per bank on the raw store
     constexpr int NE = (RPIX * 4 + 255) / 256;              // 16-byte raw items per thread
-    constexpr int VS = 20;                                  // V row stride in dwords (16 k + pad)
-    __shared__ __attribute__((aligned(16))) float raw[RPIX * RS];
-    __shared__ __attribute__((aligned(16))) float V[16 * 32 * VS];      // the epilogue reuses it as the output stage (32 KB)
+    constexpr int RAWF = 16 * PLANE;                        // dwords of one raw buffer (16 channel planes)
+    static_assert(2 * RAWF <= 16384, "two raw buffers fit the 64 KB block");
+    // 64 KB: two raw buffers ([channel][row][col], channel-major) during the K loop, the T stage in the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[16384];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,9 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 #ifdef SS_TUNING
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    // Everything outside the MFMA phase (setup, transforms, epilogue) is VALU / LDS work that shares its SIMD with the
-    // OTHER resident workgroup's MFMAs; at equal priority every VALU instruction waits for an MFMA boundary (measured:
-    // 3.9k cycles per input transform, 18k per epilogue).  Raised priority lets it through (same rule as conv.hip).
+    // Setup and epilogue are VALU / LDS work that shares its SIMD with the OTHER resident workgroup's MFMAs; at equal
+    // priority every such instruction waits for an MFMA boundary.  Raised priority lets it through (as in conv.hip).
     __builtin_amdgcn_s_setprio(3);
     W_STAMP(0);
 
@@ -125,134 +131,138 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         const bool ok = item < RPIX * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         rbase[e] = ((((unsigned)img * p.H + iy) * p.W + ix) * (unsigned)p.C + 4u * q) * 4u;
         rinv[e] = ok ? 0u : 0xFFFFFFFFu;
-        rlds[e] = pix * RS + 4 * q;
+        rlds[e] = (4 * q) * PLANE + ry * RWP + rx;           // channel 4q of this pixel; the quad's channels are PLANE apart
     }
-    const int myq = tid & 3;                                // channel quad of this thread's raw items AND transform tasks
+    const int myq = tid & 3;                                // channel quad of this thread's raw items
 
-    // transform tasks: id = row * 128 + tile * 4 + quad; thread takes ids tid and tid + 256 -> rows (tid >> 7) and + 2
-    const int t_tile = (tid >> 2) & 31;
-    const int t_ty = t_tile / TBW, t_tx = t_tile - t_ty * TBW;
-    const int t_row0 = __builtin_amdgcn_readfirstlane(tid >> 7);       // 0 or 1, wave-uniform
-    const int t_src = ((2 * t_ty) * RW + 2 * t_tx) * RS + 4 * myq;      // top-left pixel of the 4x4 patch
-    const int t_dst = t_tile * VS + 4 * myq;
+    // This lane in the GEMMs (v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5]): tile `lane & 31`, channels
+    // 8 * (lane >> 5) .. + 7 of the chunk; the wave's transform row = its position row.
+    const int kh = lane >> 5;
+    const int m_tile = lane & 31;
+    const int m_ty = m_tile / TBW, m_tx = m_tile - m_ty * TBW;
+    // top-left dword of the tile's 4x4 patch in channel plane 8 kh.  Bank picture of one 16-lane group of the 8-byte
+    // reads (16 tiles, same channel): (8,4) blocks: 2 tx + 24 ty covers all 32 banks once (row pitch 12);
+    // (4,8) blocks: 2 tx (0..14) + 48 ty = +16 (row pitch 24).
+    const int t_src = (8 * kh) * PLANE + (2 * m_ty) * RWP + 2 * m_tx;
+    const int t_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);  // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int t_rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
 
-    // MFMA operand addressing
-    const int a_off = (lane & 15) * VS + 4 * (lane >> 4);               // + pos * 32 * VS + half * 16 * VS
+    // packed filters: [cout/32][chunk][pos][half][lane][4] floats -> 32 KB per (cout block, chunk), 2 KB per position
     const unsigned u_lane = (unsigned)lane * 16u;
-    const unsigned cb16 = cbk * 4u + (unsigned)wave;                    // 16-channel block of this wave
-    // packed filters: [cout/16][chunk][pos][lane][4] floats -> per (cb16, chunk): 16 KB
-    const unsigned u_wave = cb16 * (unsigned)p.nchunk * 16384u;
+    const unsigned u_wave = (cbk * 2u) * (unsigned)p.nchunk * 32768u + (unsigned)wave * 8192u;     // + blk * nchunk * 32 KB
+    const unsigned u_blk = (unsigned)p.nchunk * 32768u;
 
-    w_f32x4 acc[16][2];
+    w_f32x16 acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 16; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (w_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    w_u32x4 rr[NE];
-    w_f32x4 ua[8], ub[8];
+    w_f32x4 rr[NE];
     auto raw_issue = [&](int c) {
         const unsigned coff = (unsigned)c * 64u;
         const unsigned cinv = ((c * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-            rr[e] = __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0);
+            rr[e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0));
     };
-    auto u_issue = [&](w_f32x4* dst, int c, int half) {
-        const int so = (int)__builtin_amdgcn_readfirstlane(u_wave + (unsigned)c * 16384u + (unsigned)half * 8192u);
+    // filters of (chunk c, position 4 wave + j): u[blk][half] = 4 floats = MFMA steps 4 half .. 4 half + 3
+    auto u_issue = [&](w_f32x4 (&u)[2][2], int c, int j) {
+        const unsigned base = u_wave + (unsigned)c * 32768u + (unsigned)j * 2048u;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            dst[k] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * k, so, 0));
-    };
-    auto transform = [&](int row) {
-        // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3; `row` is wave-uniform (scalar branches, packed adds)
-        const int ra = row == 0 ? 0 : (row == 2 ? 2 : 1);
-        const int rb = row == 3 ? 3 : (row == 2 ? 1 : 2);
-        w_f32x4 x[4], y[4], r[4];
+        for (int blk = 0; blk < 2; ++blk) {
+            const int so = (int)__builtin_amdgcn_readfirstlane(base + (unsigned)blk * u_blk);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            x[b] = *reinterpret_cast<const w_f32x4*>(&raw[t_src + (ra * RW + b) * RS]);
-            y[b] = *reinterpret_cast<const w_f32x4*>(&raw[t_src + (rb * RW + b) * RS]);
+            for (int h = 0; h < 2; ++h)
+                u[blk][h] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * h, so, 0));
         }
-        if (row == 1) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) r[b] = x[b] + y[b];
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) r[b] = x[b] - y[b];
-        }
-        float* dst = &V[(row * 4) * 32 * VS + t_dst];
-        *reinterpret_cast<w_f32x4*>(dst) = r[0] - r[2];
-        *reinterpret_cast<w_f32x4*>(dst + 32 * VS) = r[1] + r[2];
-        *reinterpret_cast<w_f32x4*>(dst + 2 * 32 * VS) = r[2] - r[1];
-        *reinterpret_cast<w_f32x4*>(dst + 3 * 32 * VS) = r[1] - r[3];
     };
-    auto mma_half = [&](const w_f32x4* u, int half) {
-        // A operands one position ahead of the MFMAs that use them (LDS latency behind 8 MFMAs = 256 cycles)
-        w_f32x4 n0 = *reinterpret_cast<const w_f32x4*>(&V[half * 8 * 32 * VS + a_off]);
-        w_f32x4 n1 = *reinterpret_cast<const w_f32x4*>(&V[half * 8 * 32 * VS + 16 * VS + a_off]);
+    float av[4][8];              // A operands of this chunk: av[j][s] = V[position 4 wave + j][tile][channel 8 kh + s]
+    const w_f32x2 t_sg = wave == 1 ? (w_f32x2){1.f, 1.f} : (w_f32x2){-1.f, -1.f};     // row stage: d[ra] + sg * d[rb] (exact)
+    auto transform = [&](const float* buf) {
+        const float* src = buf + t_src;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int pos = half * 8 + k;
-            const w_f32x4 a0 = n0, a1 = n1;
-            if (k < 7) {
-                n0 = *reinterpret_cast<const w_f32x4*>(&V[(pos + 1) * 32 * VS + a_off]);
-                n1 = *reinterpret_cast<const w_f32x4*>(&V[(pos + 1) * 32 * VS + 16 * VS + a_off]);
-            }
+        for (int c = 0; c < 8; ++c) {
+            const float* pa = src + c * PLANE + t_ra * RWP;
+            const float* pb = src + c * PLANE + t_rb * RWP;
+            const w_f32x2 xa0 = *reinterpret_cast<const w_f32x2*>(pa), xa1 = *reinterpret_cast<const w_f32x2*>(pa + 2);
+            const w_f32x2 xb0 = *reinterpret_cast<const w_f32x2*>(pb), xb1 = *reinterpret_cast<const w_f32x2*>(pb + 2);
+            const w_f32x2 r0 = __builtin_elementwise_fma(xb0, t_sg, xa0);      // (r0, r1)
+            const w_f32x2 r1 = __builtin_elementwise_fma(xb1, t_sg, xa1);      // (r2, r3)
+            const w_f32x2 d = r0 - r1;                                         // (r0 - r2, r1 - r3) = positions 0 and 3
+            av[0][c] = d[0];
+            av[1][c] = r0[1] + r1[0];
+            av[2][c] = r1[0] - r0[1];
+            av[3][c] = d[1];
+        }
+    };
+    auto mma = [&](int j, const w_f32x4 (&u)[2][2]) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], u[k][s], acc[pos][0], 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], u[k][s], acc[pos][1], 0, 0, 0);
-            }
+        for (int s = 0; s < 8; ++s) {
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s], u[0][s >> 2][s & 3], acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s], u[1][s >> 2][s & 3], acc[j][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
+    w_f32x4 ua[2][2], ub[2][2];
     raw_issue(0);
     u_issue(ua, 0, 0);
     W_STAMP(1);
     for (int c = 0; c < p.nchunk; ++c) {
-        // registers -> LDS raw patch (everyone is past the previous chunk's transform: it read `raw` before barrier B)
+        float* buf = smem + (c & 1) * RAWF;
+        // registers -> LDS, transposed to channel planes.  Two buffers: the waves still transforming chunk c - 1 read the
+        // other one, and everyone passed the previous barrier after its chunk c - 2 reads: ONE barrier per chunk.
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-            if (NE * 256 == RPIX * 4 || tid + 256 * e < RPIX * 4) *reinterpret_cast<w_u32x4*>(&raw[rlds[e]]) = rr[e];
-        __syncthreads();                        // A: raw visible; every wave has finished the previous chunk's MFMAs (V free)
+            if (NE * 256 == RPIX * 4 || tid + 256 * e < RPIX * 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) buf[rlds[e] + k * PLANE] = rr[e][k];
+            }
+        __syncthreads();
         if (c == 0) W_STAMP(5);
-        if (c == 1) W_STAMP(7);
-        transform(t_row0);
-        transform(t_row0 + 2);
-        __syncthreads();                        // B: V complete
+        // next chunk's raw patch (branch free: the last iteration re-requests its own chunk, results unused -- with a
+        // conditional the compiler drains the prefetch of the path that issued none)
+        const int cn = c + 1 < p.nchunk ? c + 1 : c;
+        raw_issue(cn);
+        transform(buf);
         if (c == 0) W_STAMP(6);
-        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
-        u_issue(ub, c, 1);                      // second half of this chunk's filters: used ~2000 cycles from now
+        // filters one position (16 MFMAs = 1024 cycles) ahead; the sched_barriers pin every group of loads in front of
+        // the MFMAs it overlaps with (left alone, the scheduler sinks them into the MFMA run to shorten live ranges and
+        // the next position then waits for L2)
         __builtin_amdgcn_sched_barrier(0);
-        mma_half(ua, 0);
+        u_issue(ub, c, 1);
         __builtin_amdgcn_sched_barrier(0);
-        {
-            // next chunk: raw patch and first half of the filters.  Branch free (the last iteration re-requests its own
-            // chunk, results unused): with a conditional the compiler has to wait for the loads of the path that issued
-            // none, i.e. it drains the whole prefetch before the second half of the MFMAs.
-            const int cn = c + 1 < p.nchunk ? c + 1 : c;
-            raw_issue(cn);
-            u_issue(ua, cn, 0);
-        }
+        mma(0, ua);
         __builtin_amdgcn_sched_barrier(0);
-        mma_half(ub, 1);
+        u_issue(ua, c, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, ub);
+        __builtin_amdgcn_sched_barrier(0);
+        u_issue(ub, c, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(2, ua);
+        __builtin_amdgcn_sched_barrier(0);
+        u_issue(ua, cn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(3, ub);
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(3);
-        if (c == 0) W_STAMP(4);
     }
     W_STAMP(2);
 
     // ---------------------------------------------------------------- epilogue: Y = A^T M A, bias, residual, ReLU
-    // The 16 positions of one (tile, cout) sit in one lane: A^T M A is register arithmetic.  The 2x2 results go through
-    // LDS (the V buffer, free now) so that global memory sees whole 256-byte pixel rows as 16-byte accesses: stage
-    // S[pixel = tile * 4 + 2a + b][64 couts], the cout index rotated by 16 * ((pixel >> 4) & 3) so that the four 16-lane
-    // groups of a wave (four different tiles) write four different bank groups.
+    // Wave i holds M[i][0..3]: it forms T[i][b] = sum_j M[i][j] A[j][b] in registers and stages it in LDS,
+    // S[i][b][tile][64 couts]; then every thread owns 8 x (pixel, 4 couts), adds the three T rows of its pixel
+    // (Y[0][b] = T0 + T1 + T2, Y[1][b] = T1 - T2 - T3, fixed order), bias (folded BatchNorm), residual, ReLU, and
+    // global memory sees whole 256-byte pixel rows as 16-byte accesses (out-of-range offsets outside the image).
     float* __restrict__ out = p.out + (long long)grp * p.out_gs;
     const float* __restrict__ res = p.res ? p.res + (long long)grp * p.out_gs : nullptr;
     const __amdgpu_buffer_rsrc_t rout = w_rsrc(out, p.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = w_rsrc(res ? res : out, p.out_bytes);
-    // this thread's 8 output items: (pixel = e * 16 + tid / 16, channel quad = tid % 16)
     const int cq = tid & 15;
     unsigned goff[8];
     w_u32x4 rv[8];
@@ -271,37 +281,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
     }
     w_f32x4 bias4 = (w_f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const w_f32x4*>(p.bias + (long long)grp * p.Co + cbk * 64 + 4 * cq);
-    __syncthreads();                            // every wave is done reading V
+    __syncthreads();                            // every wave is done with the raw buffers (the stage aliases them)
+    W_STAMP(4);
     {
-        const int cw = wave * 16 + (lane & 15);
+        float* srow = smem + (wave * 2) * 32 * 64 + (lane & 31);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tile = half * 16 + 4 * (lane >> 4) + r;
-                float T[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float m0 = acc[4 * i + 0][half][r], m1 = acc[4 * i + 1][half][r];
-                    const float m2 = acc[4 * i + 2][half][r], m3 = acc[4 * i + 3][half][r];
-                    T[i][0] = (m0 + m1) + m2;
-                    T[i][1] = (m1 - m2) - m3;
-                }
-                // rotation: (pixel >> 4) & 3 = (tile >> 2) & 3 = lane >> 4 for every pixel of this tile
-                float* srow = &V[(tile * 4) * 64 + ((cw + 16 * (lane >> 4)) & 63)];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    srow[b * 64] = (T[0][b] + T[1][b]) + T[2][b];
-                    srow[(2 + b) * 64] = (T[1][b] - T[2][b]) - T[3][b];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const float m0 = acc[0][blk][r], m1 = acc[1][blk][r], m2 = acc[2][blk][r], m3 = acc[3][blk][r];
+                srow[tile * 64 + blk * 32] = (m0 + m1) + m2;
+                srow[(32 + tile) * 64 + blk * 32] = (m1 - m2) - m3;
             }
-        }
     }
     __syncthreads();
+    W_STAMP(7);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int px = e * 16 + (tid >> 4);
-        w_f32x4 v = *reinterpret_cast<const w_f32x4*>(&V[px * 64 + ((4 * cq + 16 * ((px >> 4) & 3)) & 63)]);
+        const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
+        // a = 0: rows 0, 1, 2 added; a = 1: row 1 minus rows 2, 3
+        const float* s0 = smem + ((a * 2 + b) * 32 + tile) * 64 + 4 * cq;
+        const w_f32x4 x = *reinterpret_cast<const w_f32x4*>(s0);
+        const w_f32x4 y = *reinterpret_cast<const w_f32x4*>(s0 + 2 * 32 * 64);
+        const w_f32x4 z = *reinterpret_cast<const w_f32x4*>(s0 + 4 * 32 * 64);
+        const float sg = a ? -1.f : 1.f;
+        w_f32x4 v = (x + sg * y) + sg * z;
         v = v + bias4;
         if (res) v = v + __builtin_bit_cast(w_f32x4, rv[e]);
         if (p.relu) {
@@ -322,45 +328,47 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 
 // ------------------------------------------------------------------------------------------------
 // Filter transform + packing: U = G g G^T in fp64, rounded once to fp32, stored in the B-operand register layout of the
-// kernel above:  U[cout/16][chunk][pos][lane][s] = (G g G^T)[pos] of (cout = 16 cb + (lane & 15), cin = 16 chunk + 4 (lane >> 4) + s),
+// kernel above (v_mfma_f32_32x32x2_f32: B[k = lane >> 5][j = lane & 31]):
+//   U[cout/32][chunk][pos][half][lane][e] = (G g G^T)[pos] of (cout = 32 cb + (lane & 31), cin = 16 chunk + 8 (lane >> 5) + 4 half + e),
 // zero for cin >= C.   wgt: [cout][1][3][3][cin] (BN folded).
 __global__ void wino_pack_kernel(const float* __restrict__ wgt, float* __restrict__ U, int cout, int cin, int nchunk,
                                  long long w_gs, long long u_gs) {
-    const long long per = (long long)(cout / 16) * nchunk * 16 * 64;       // float4 slots per group
+    const long long per = (long long)(cout / 32) * nchunk * 16 * 2 * 64;   // float4 slots per group
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= per) return;
     const int grp = blockIdx.y;
     const int lane = (int)(idx & 63);
-    const int pos = (int)((idx >> 6) & 15);
-    const long long cc = idx >> 10;
+    const int half = (int)((idx >> 6) & 1);
+    const int pos = (int)((idx >> 7) & 15);
+    const long long cc = idx >> 11;
     const int chunk = (int)(cc % nchunk);
     const int cb = (int)(cc / nchunk);
-    const int co = cb * 16 + (lane & 15);
+    const int co = cb * 32 + (lane & 31);
     const int i = pos >> 2, j = pos & 3;
     const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     float v[4];
-    for (int s = 0; s < 4; ++s) {
-        const int ci = chunk * 16 + 4 * (lane >> 4) + s;
+    for (int e = 0; e < 4; ++e) {
+        const int ci = chunk * 16 + 8 * (lane >> 5) + 4 * half + e;
         double acc = 0.0;
         if (ci < cin) {
             const float* g = wgt + (long long)grp * w_gs + (long long)co * 9 * cin + ci;
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 3; ++b) acc += G[i][a] * (double)g[(a * 3 + b) * cin] * G[j][b];
         }
-        v[s] = (float)acc;
+        v[e] = (float)acc;
     }
     reinterpret_cast<float4*>(U + (long long)grp * u_gs)[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 extern "C" long long ss_wino_packed_floats(int cout, int cin) {
-    if (cout <= 0 || cin <= 0 || (cout & 15)) return 0;
-    return (long long)(cout / 16) * ss_cdiv(cin, 16) * 16 * 64 * 4;
+    if (cout <= 0 || cin <= 0 || (cout & 31)) return 0;
+    return (long long)(cout / 32) * ss_cdiv(cin, 16) * 16 * 2 * 64 * 4;
 }
 
 extern "C" int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, int groups, void* stream) {
-    if (!wgt || !packed || cout <= 0 || cin <= 0 || (cout & 15) || (cin & 3) || groups <= 0) return SS_ERR_ARG;
+    if (!wgt || !packed || cout <= 0 || cin <= 0 || (cout & 31) || (cin & 3) || groups <= 0) return SS_ERR_ARG;
     const int nchunk = ss_cdiv(cin, 16);
-    const long long per = (long long)(cout / 16) * nchunk * 16 * 64;
+    const long long per = (long long)(cout / 32) * nchunk * 16 * 2 * 64;
     hipLaunchKernelGGL(wino_pack_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, (hipStream_t)stream, wgt, packed,
                        cout, cin, nchunk, (long long)cout * 9 * cin, per * 4);
     return ss_launch_status();

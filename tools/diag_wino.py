@@ -32,10 +32,10 @@ for name in sys.argv[1].split(','):
     t0 = d[:, 0].min()
     span = d[:, 8].max() - t0
     med = lambda a: int(np.median(a))
-    print('   %d blocks, kernel span %d ticks (100 MHz); per block median ticks: setup %d | wait raw + barrier A %d | transform + barrier B %d | '
-          'MFMA phase (chunk 0) %d | chunk-1 write+barrier A %d | whole K loop %d | epilogue %d | total %d'
-          % (len(d), span, med(d[:, 1] - d[:, 0]), med(d[:, 5] - d[:, 1]), med(d[:, 6] - d[:, 5]), med(d[:, 4] - d[:, 6]),
-             med(d[:, 7] - d[:, 4]), med(d[:, 2] - d[:, 1]), med(d[:, 8] - d[:, 2]), med(d[:, 8] - d[:, 0])))
+    print('   %d blocks; per block median ticks (~shader clocks): setup %d | first raw wait + barrier %d | transform (chunk 0) %d | '
+          'whole K loop %d | epilogue: residual issue + wait for the slowest wave %d, T stage + barrier %d, combine + store %d | total %d'
+          % (len(d), med(d[:, 1] - d[:, 0]), med(d[:, 5] - d[:, 1]), med(d[:, 6] - d[:, 5]),
+             med(d[:, 2] - d[:, 1]), med(d[:, 4] - d[:, 2]), med(d[:, 7] - d[:, 4]), med(d[:, 8] - d[:, 7]), med(d[:, 8] - d[:, 0])))
     hw = d[:, 9] & 0xFFFFFFFF; xcc = (d[:, 9] >> 32) & 0xF
     cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | (((hw >> 12) & 1) << 7) | (xcc << 8)
     ucu = np.unique(cu)
