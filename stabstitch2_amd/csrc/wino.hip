@@ -52,13 +52,17 @@ struct WinoP {
     unsigned in_bytes, out_bytes, u_bytes;
 #ifdef SS_TUNING
     unsigned long long* dbg;            // per-workgroup phase stamps (tools/diag_wino.py)
+    int ablate;                         // 1: no filter loads, 2: no raw loads / LDS / transform, 4: no epilogue (wrong results)
 #endif
 };
 
 #ifdef SS_TUNING
 #define W_STAMP(i) do { if (p.dbg) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W_ABLATE(bit) (p.ablate & (bit))
+extern int g_wino_ablate;
 #else
 #define W_STAMP(i) do { } while (0)
+#define W_ABLATE(bit) 0
 #endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float* base, unsigned bytes) {
@@ -72,18 +76,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float* base, unsi
 typedef float w_f32x16 __attribute__((ext_vector_type(16)));
 typedef float w_f32x2 __attribute__((ext_vector_type(2)));
 
-template <int TBH, int TBW>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
+// NB = 32-channel output blocks per workgroup: 2 (64 channels, 128 accumulator registers, two workgroups per CU) or
+// 1 (32 channels, 64 accumulator registers, THREE workgroups per CU: the epilogue / prologue of one workgroup hides
+// behind the MFMAs of two others -- the short-K layers (cin = 64: 4 chunks) spend a quarter of a workgroup's life there)
+template <int TBH, int TBW, int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p) {
     static_assert(TBH * TBW == 32, "32 tiles per workgroup");
+    constexpr int BN = 32 * NB;                             // output channels per workgroup
     constexpr int RH = 2 * TBH + 2, RW = 2 * TBW + 2;      // raw input patch (pixels)
     constexpr int RPIX = RH * RW;
     constexpr int RWP = TBW == 4 ? 12 : 24;                 // LDS row pitch of a channel plane (dwords): see `transform`
     constexpr int PLANE = RH * RWP + 4;                     // channel plane stride; = 4 (mod 8): 2 lanes per bank on the raw store
     constexpr int NE = (RPIX * 4 + 255) / 256;              // 16-byte raw items per thread
     constexpr int RAWF = 16 * PLANE;                        // dwords of one raw buffer (16 channel planes)
-    static_assert(2 * RAWF <= 16384, "two raw buffers fit the 64 KB block");
-    // 64 KB: two raw buffers ([channel][row][col], channel-major) during the K loop, the T stage in the epilogue
-    __shared__ __attribute__((aligned(16))) float smem[16384];
+    constexpr int SMEMF = 8192 * NB;                        // T stage: 4 waves x 2 x 32 tiles x BN channels
+    static_assert(2 * RAWF <= SMEMF, "two raw buffers fit the block");
+    // two raw buffers ([channel][row][col], channel-major) during the K loop, the T stage in the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[SMEMF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         }
     }
     const unsigned mb = ss_div32(lin, p.divNcb);
-    const unsigned cbk = lin - mb * p.ncb;                  // 64-channel output block
+    const unsigned cbk = lin - mb * p.ncb;                  // output block (BN channels)
     const unsigned t1 = ss_div32(mb, p.divBx);
     const int bx = (int)(mb - t1 * p.nbx);
     const unsigned img = ss_div32(t1, p.divBy);
@@ -149,19 +158,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 
     // packed filters: [cout/32][chunk][pos][half][lane][4] floats -> 32 KB per (cout block, chunk), 2 KB per position
     const unsigned u_lane = (unsigned)lane * 16u;
-    const unsigned u_wave = (cbk * 2u) * (unsigned)p.nchunk * 32768u + (unsigned)wave * 8192u;     // + blk * nchunk * 32 KB
+    const unsigned u_wave = (cbk * NB) * (unsigned)p.nchunk * 32768u + (unsigned)wave * 8192u;     // + blk * nchunk * 32 KB
     const unsigned u_blk = (unsigned)p.nchunk * 32768u;
 
-    w_f32x16 acc[4][2];
+    w_f32x16 acc[4][NB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     w_f32x4 rr[NE];
     auto raw_issue = [&](int c) {
+        if (W_ABLATE(2)) return;
         const unsigned coff = (unsigned)c * 64u;
         const unsigned cinv = ((c * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
@@ -169,10 +179,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
             rr[e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0));
     };
     // filters of (chunk c, position 4 wave + j): u[blk][half] = 4 floats = MFMA steps 4 half .. 4 half + 3
-    auto u_issue = [&](w_f32x4 (&u)[2][2], int c, int j) {
+    auto u_issue = [&](w_f32x4 (&u)[NB][2], int c, int j) {
+        if (W_ABLATE(1)) return;
         const unsigned base = u_wave + (unsigned)c * 32768u + (unsigned)j * 2048u;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NB; ++blk) {
             const int so = (int)__builtin_amdgcn_readfirstlane(base + (unsigned)blk * u_blk);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -198,16 +209,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
             av[3][c] = d[1];
         }
     };
-    auto mma = [&](int j, const w_f32x4 (&u)[2][2]) {
+    auto mma = [&](int j, const w_f32x4 (&u)[NB][2]) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s], u[0][s >> 2][s & 3], acc[j][0], 0, 0, 0);
-            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s], u[1][s >> 2][s & 3], acc[j][1], 0, 0, 0);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                acc[j][blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s], u[blk][s >> 2][s & 3], acc[j][blk], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    w_f32x4 ua[2][2], ub[2][2];
+    // filters one position (16 NB/2 MFMAs) ahead in two alternating register sets.  (One set per position, reloaded three
+    // positions ahead, was measured slower: 256 registers with spills, 367 vs 313 us on layer1.)
+    w_f32x4 ua[NB][2], ub[NB][2];
     raw_issue(0);
     u_issue(ua, 0, 0);
     W_STAMP(1);
@@ -217,22 +231,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         // other one, and everyone passed the previous barrier after its chunk c - 2 reads: ONE barrier per chunk.
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-            if (NE * 256 == RPIX * 4 || tid + 256 * e < RPIX * 4) {
+            if (!W_ABLATE(2) && (NE * 256 == RPIX * 4 || tid + 256 * e < RPIX * 4)) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) buf[rlds[e] + k * PLANE] = rr[e][k];
             }
         __syncthreads();
         if (c == 0) W_STAMP(5);
-        // next chunk's raw patch (branch free: the last iteration re-requests its own chunk, results unused -- with a
+        // next chunk's raw patch: branch free (the last iteration re-requests its own chunk, results unused -- with a
         // conditional the compiler drains the prefetch of the path that issued none)
         const int cn = c + 1 < p.nchunk ? c + 1 : c;
         raw_issue(cn);
-        transform(buf);
+        if (!W_ABLATE(2)) transform(buf);
         if (c == 0) W_STAMP(6);
         __builtin_amdgcn_s_setprio(0);
-        // filters one position (16 MFMAs = 1024 cycles) ahead; the sched_barriers pin every group of loads in front of
-        // the MFMAs it overlaps with (left alone, the scheduler sinks them into the MFMA run to shorten live ranges and
-        // the next position then waits for L2)
+        // the sched_barriers pin every group of loads in front of the MFMAs it overlaps with (left alone, the scheduler
+        // sinks them into the MFMA run to shorten live ranges and the next position then waits for L2)
         __builtin_amdgcn_sched_barrier(0);
         u_issue(ub, c, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -253,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         __builtin_amdgcn_s_setprio(3);
     }
     W_STAMP(2);
+    if (W_ABLATE(4)) return;
 
     // ---------------------------------------------------------------- epilogue: Y = A^T M A, bias, residual, ReLU
     // Wave i holds M[i][0..3]: it forms T[i][b] = sum_j M[i][j] A[j][b] in registers and stages it in LDS,
@@ -263,49 +277,51 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
     const float* __restrict__ res = p.res ? p.res + (long long)grp * p.out_gs : nullptr;
     const __amdgpu_buffer_rsrc_t rout = w_rsrc(out, p.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = w_rsrc(res ? res : out, p.out_bytes);
-    const int cq = tid & 15;
-    unsigned goff[8];
-    w_u32x4 rv[8];
+    // this thread's output items: (pixel, channel quad); BN / 4 quads per pixel -> 128 * BN / 4 / 256 = 4 NB items
+    constexpr int QP = BN / 4, NI = 4 * NB, PSTEP = 256 / QP;
+    const int cq = tid % QP;
+    unsigned goff[NI];
+    w_u32x4 rv[NI];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int px = e * 16 + (tid >> 4);
+    for (int e = 0; e < NI; ++e) {
+        const int px = e * PSTEP + tid / QP;
         const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
         const int ty = tile / TBW, tx = tile - ty * TBW;
         const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + b;
         const bool ok = oy < p.H && ox < p.W;
-        goff[e] = ok ? ((((unsigned)img * p.H + oy) * p.W + ox) * (unsigned)p.out_cs + cbk * 64u + 4u * cq) * 4u : 0xFFFFFFFFu;
+        goff[e] = ok ? ((((unsigned)img * p.H + oy) * p.W + ox) * (unsigned)p.out_cs + cbk * BN + 4u * cq) * 4u : 0xFFFFFFFFu;
     }
     if (res) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = __builtin_amdgcn_raw_buffer_load_b128(rres, goff[e], 0, 0);
+        for (int e = 0; e < NI; ++e) rv[e] = __builtin_amdgcn_raw_buffer_load_b128(rres, goff[e], 0, 0);
     }
     w_f32x4 bias4 = (w_f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *reinterpret_cast<const w_f32x4*>(p.bias + (long long)grp * p.Co + cbk * 64 + 4 * cq);
+    if (p.bias) bias4 = *reinterpret_cast<const w_f32x4*>(p.bias + (long long)grp * p.Co + cbk * BN + 4 * cq);
     __syncthreads();                            // every wave is done with the raw buffers (the stage aliases them)
     W_STAMP(4);
     {
-        float* srow = smem + (wave * 2) * 32 * 64 + (lane & 31);
+        float* srow = smem + (wave * 2) * 32 * BN + (lane & 31);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const float m0 = acc[0][blk][r], m1 = acc[1][blk][r], m2 = acc[2][blk][r], m3 = acc[3][blk][r];
-                srow[tile * 64 + blk * 32] = (m0 + m1) + m2;
-                srow[(32 + tile) * 64 + blk * 32] = (m1 - m2) - m3;
+                srow[tile * BN + blk * 32] = (m0 + m1) + m2;
+                srow[(32 + tile) * BN + blk * 32] = (m1 - m2) - m3;
             }
     }
     __syncthreads();
     W_STAMP(7);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int px = e * 16 + (tid >> 4);
+    for (int e = 0; e < NI; ++e) {
+        const int px = e * PSTEP + tid / QP;
         const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
         // a = 0: rows 0, 1, 2 added; a = 1: row 1 minus rows 2, 3
-        const float* s0 = smem + ((a * 2 + b) * 32 + tile) * 64 + 4 * cq;
+        const float* s0 = smem + ((a * 2 + b) * 32 + tile) * BN + 4 * cq;
         const w_f32x4 x = *reinterpret_cast<const w_f32x4*>(s0);
-        const w_f32x4 y = *reinterpret_cast<const w_f32x4*>(s0 + 2 * 32 * 64);
-        const w_f32x4 z = *reinterpret_cast<const w_f32x4*>(s0 + 4 * 32 * 64);
+        const w_f32x4 y = *reinterpret_cast<const w_f32x4*>(s0 + 2 * 32 * BN);
+        const w_f32x4 z = *reinterpret_cast<const w_f32x4*>(s0 + 4 * 32 * BN);
         const float sg = a ? -1.f : 1.f;
         w_f32x4 v = (x + sg * y) + sg * z;
         v = v + bias4;
@@ -374,6 +390,13 @@ extern "C" int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, 
     return ss_launch_status();
 }
 
+#ifdef SS_TUNING
+int g_wino_ablate = 0;                   // ss_debug_set key 6
+int g_wino_nb1_max_cin = 0;              // ss_debug_set key 5
+#else
+constexpr int g_wino_nb1_max_cin = 0;
+#endif
+
 // tile-block shape: the one that wastes fewer tile slots on this map (8x4 or 4x8 blocks of 2x2 tiles)
 static void wino_blocks(int h, int w, int& tbh, int& tbw, double& eff) {
     const int th = (h + 1) / 2, tw = (w + 1) / 2;
@@ -415,7 +438,8 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
     p.nby = (unsigned)ss_cdiv((h + 1) / 2, tbh);
     p.divBx = ss_div32_make(p.nbx);
     p.divBy = ss_div32_make(p.nby);
-    p.ncb = (unsigned)(cout / 64);
+    const int nb = cin <= g_wino_nb1_max_cin ? 1 : 2;         // 2 (64-channel blocks) in the product build
+    p.ncb = (unsigned)(cout / (32 * nb));
     p.divNcb = ss_div32_make(p.ncb);
     p.in_gs = in_gs; p.u_gs = u_gs; p.out_gs = out_gs;
     p.in_bytes = (unsigned)(in_elems * 4);
@@ -423,12 +447,20 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
     p.u_bytes = (unsigned)(u_floats * 4);
 #ifdef SS_TUNING
     p.dbg = ss_tuning_dbg;
+    p.ablate = g_wino_ablate;
 #endif
     const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
     if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
-    if (tbh == 8) hipLaunchKernelGGL((conv_wino_kernel<8, 4>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wino_kernel<4, 8>), g, dim3(256), 0, st, p);
+#ifdef SS_TUNING      // 32-channel blocks / three workgroups per CU: measured slower on every layer (tools/diag_wino.py); tools build only
+    if (nb == 1) {
+        if (tbh == 8) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1>), g, dim3(256), 0, st, p);
+        return ss_launch_status();
+    }
+#endif
+    if (tbh == 8) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2>), g, dim3(256), 0, st, p);
     return ss_launch_status();
 }

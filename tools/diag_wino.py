@@ -8,7 +8,12 @@ import _tuning
 lib = _tuning.lib()
 dev = torch.device('cuda:0')
 SHAPES = {'layer1': (64, 90, 120, 64, 64), 'layer2': (64, 45, 60, 128, 128), 'layer3': (64, 23, 30, 256, 256)}
-for name in sys.argv[1].split(','):
+VARIANTS = {'64-channel blocks (2 WG/CU)': 0, '32-channel blocks (3 WG/CU)': 4096}
+if len(sys.argv) > 2:
+    VARIANTS = {'64-channel blocks (2 WG/CU)': 0}
+for name, vname in ((a, b) for a in sys.argv[1].split(',') for b in VARIANTS):
+    lib.ss_debug_set(5, VARIANTS[vname])
+    lib.ss_debug_set(6, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     n, h, w, cin, cout = SHAPES[name]
     x = torch.randn(n, h, w, cin, device=dev); wt = torch.randn(cout, 1, 3, 3, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     out = ops.conv_winograd(x, wt, b, None, relu=True)
@@ -22,7 +27,7 @@ for name in sys.argv[1].split(','):
     for _ in range(5): ops.conv_winograd(x, wt, b, res, relu=True, out=out)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print('%s: %.1f us per launch, %.1f TF/s direct-equivalent' % (name, ms * 1e3, 2.0 * n * h * w * cout * 9 * cin / ms / 1e9))
+    print('%s [%s]: %.1f us per launch, %.1f TF/s direct-equivalent' % (name, vname, ms * 1e3, 2.0 * n * h * w * cout * 9 * cin / ms / 1e9))
     lib.ss_debug_ptr(ctypes.c_void_p(dbg.data_ptr()))
     ops.conv_winograd(x, wt, b, res, relu=True, out=out)
     torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import glob
 import json
 import sys
 
-KEYS = (('conv_igemm', 'conv_igemm_kernel'), ('render_average', 'render_average_kernel'), ('cost_volume', 'cost_volume_kernel'),
+KEYS = (('conv_wino', 'conv_wino_kernel'), ('conv_igemm', 'conv_igemm_kernel'), ('render_average', 'render_average_kernel'), ('cost_volume', 'cost_volume_kernel'),
         ('maxpool', 'maxpool_kernel'), ('linear_kernel', 'linear_kernel'))
 
 
@@ -34,13 +34,13 @@ def durations(path):
 f, w = load(sys.argv[1]), load(sys.argv[2])
 dur = durations(sys.argv[1])
 out = {'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py --steps 2 '
-                  '--warmup 1 --no-cpu-baseline (one pass per counter)',
+                  '--warmup 1 --no-cpu-baseline --no-other-configs (one pass per counter)',
        'units': 'counter value x 1000 = bytes.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-B '
                 'requests of a 16-B/lane stream at 64 B, so the conv engine (buffer_load_dwordx4) and maxpool/linear (float4 '
                 'loads) fetch bytes = 2 x FETCH_SIZE; dword gathers (render, cost volume) and WRITE_SIZE are used as reported.',
        'kernels': {}}
 for key in f:
-    corr = 2.0 if key in ('conv_igemm_kernel', 'maxpool_kernel', 'linear_kernel') else 1.0
+    corr = 2.0 if key in ('conv_wino_kernel', 'conv_igemm_kernel', 'maxpool_kernel', 'linear_kernel') else 1.0
     fa, wa = sum(f[key]) / len(f[key]), sum(w[key]) / len(w[key])
     out['kernels'][key] = {'launches': len(f[key]), 'FETCH_SIZE_avg': round(fa, 1), 'WRITE_SIZE_avg': round(wa, 1),
                            'fetch_correction': corr, 'hbm_bytes_per_launch': round((corr * fa + wa) * 1000.0)}
@@ -48,4 +48,12 @@ for key in f:
         us = sum(dur[key]) / len(dur[key])
         out['kernels'][key]['avg_us_under_pmc'] = round(us, 2)
         out['kernels'][key]['hbm_TB_per_s'] = round((corr * fa + wa) * 1000.0 / us / 1e6, 3)
+# the conv engine as one family (what bench.py's roofline block quotes): all Winograd + implicit-GEMM launches together
+fam = [k for k in ('conv_wino_kernel', 'conv_igemm_kernel') if k in f]
+if fam:
+    nl = sum(len(f[k]) for k in fam)
+    tot = sum(2.0 * sum(f[k]) + sum(w[k]) for k in fam) * 1000.0
+    out['conv_family'] = {'kernels': fam, 'launches': nl, 'hbm_bytes_per_launch': round(tot / nl)}
+    if all(dur.get(k) for k in fam):
+        out['conv_family']['avg_us_under_pmc'] = round(sum(sum(dur[k]) for k in fam) / nl, 2)
 print(json.dumps(out, indent=1))
