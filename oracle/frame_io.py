@@ -8,8 +8,10 @@ PARITY UNPINNED for `cv2_resize_linear_u8`: the algorithm lives in a third-party
 libopencv exists here), so this function restates OpenCV 4.5.1's published algorithm
 (modules/imgproc/src/resize.cpp: cv::hal::resize -> resizeGeneric_<HResizeLinear<uchar,int,short,2048,...>,
 VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>,...>>, and resizeAreaFast_ for the exact 2x2 case) from the
-source as documented, and is checked only through properties (identity, exact 2x2 area, +-1 LSB of real bilinear,
-constant images, hand-worked vectors in tests/test_oracle_golden.py).  IPP is not in play: for 8-bit linear resize
+source as documented, and is checked through properties (identity, exact 2x2 area, +-1 LSB of real bilinear,
+constant images) and against a SECOND, scalar-by-scalar hand derivation of the same published arithmetic
+(tests/golden/make_cv2_handworked.py -> cv2_resize_handworked.json: 2x2 area route, 5:3 / 8:3 / 3:2 ratios, an
+enlargement, a 0/255 checkerboard, the 1280 -> 480 tap table).  Neither is an output of cv2.  IPP is not in play: for 8-bit linear resize
 OpenCV skips IPP unless `ipp::useIPP_NotExact()` (resize.cpp, ipp_resize).
 """
 import numpy as np

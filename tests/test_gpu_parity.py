@@ -996,3 +996,18 @@ def test_conv_winograd_grouped_and_dispatch(dev):
     finally:
         ops.WINOGRAD = old
     close(a, d, 4e-5 * max(1.0, float(d.abs().max())), 'dispatch: winograd vs implicit GEMM')
+
+
+def test_ingest_u8_vs_handworked_cv2_vectors(dev):
+    """The HIP front-end against the scalar hand derivation of OpenCV's uint8 INTER_LINEAR (tests/golden/
+    cv2_resize_handworked.json, independent of oracle/frame_io.py): lr = resize / 127.5 - 1, bit for bit."""
+    import json
+    from stabstitch2_amd import ops
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cv2_resize_handworked.json')))
+    for name, c in d['cases'].items():
+        src, dst = np.array(c['src'], np.uint8), np.array(c['dst'], np.uint8)
+        dw, dh = c['dsize']
+        hr, lr = ops.ingest_u8(torch.from_numpy(src[None]).to(dev), dh, dw)
+        want = (dst.astype(np.float32).transpose(2, 0, 1) / np.float32(127.5)) - np.float32(1.0)
+        assert np.array_equal(lr[0].cpu().numpy(), want.astype(np.float32)), name
+        assert np.array_equal(hr[0].cpu().numpy(), src.astype(np.float32).transpose(2, 0, 1)), name

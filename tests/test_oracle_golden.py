@@ -307,3 +307,23 @@ def test_frame_io_resize_properties():
     assert hr[1, 5, 7] == img[5, 7, 1] and -1.0 <= lr.min() and lr.max() <= 1.0
     vid = FIO.to_video_frame(np.array([[[255.99998, -0.5]], [[0.999, 256.0]], [[17.5, -3.7]]], np.float32))
     assert vid.shape == (1, 2, 3) and vid[0, 0].tolist() == [255, 0, 17] and vid[0, 1].tolist() == [0, 0, 253]
+
+
+def test_frame_io_vs_handworked_cv2_vectors():
+    """tests/golden/cv2_resize_handworked.json: a second, scalar-by-scalar derivation of OpenCV 4.5.1's uint8 INTER_LINEAR
+    (make_cv2_handworked.py, from resize.cpp as published) -- the 2x2 area route, two non-integer ratios incl. the
+    1280 -> 480 one, an enlargement and a 0/255 checkerboard.  Still not an output of cv2 itself (header of the fixture)."""
+    import json
+    from oracle import frame_io as FIO
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cv2_resize_handworked.json')))
+    assert len(d['cases']) >= 5 and 'resize.cpp' in d['provenance']
+    for name, c in d['cases'].items():
+        src, dst = np.array(c['src'], np.uint8), np.array(c['dst'], np.uint8)
+        assert np.array_equal(FIO.cv2_resize_linear_u8(src, tuple(c['dsize'])), dst), name
+    xo, a0, a1 = FIO.linear_tables(1280, 480)
+    assert [[int(xo[i]), int(a0[i]), int(a1[i])] for i in range(8)] == d['taps_x_1280_480_first8']
+    assert [[int(xo[i]), int(a0[i]), int(a1[i])] for i in range(476, 480)] == d['taps_x_1280_480_last4']
+    r0, r1, b0, b1 = FIO.linear_tables_y(1080, 360)
+    assert [[int(r0[i]), int(r1[i]), int(b0[i]), int(b1[i])] for i in range(4)] == d['taps_y_1080_360_first4']
+    # one value worked by hand: 5 -> 3 columns: dx = 0: fx = 0.5 * (5/3) - 0.5 = 1/3 -> taps (round(2048 * 2/3), round(2048 / 3))
+    assert [list(t) for t in [FIO.linear_tables(5, 3)[k][:1].tolist() for k in range(3)]] == [[0], [1365], [683]]
