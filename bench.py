@@ -87,6 +87,21 @@ class ConvProbe:
             return timed
         ops.conv = wrap(ops.conv, False)
         ops.conv_grouped = wrap(ops.conv_grouped, True)
+        orig_stem = ops.conv_stem
+
+        def timed_stem(buf, wgt, *a, **k):          # 7x7/2 stem on the row-packed 3-channel layout: 147 real products per output
+            if not probe.active:
+                return orig_stem(buf, wgt, *a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_stem(buf, wgt, *a, **k)
+            e1.record()
+            m = out.numel() // out.shape[-1]
+            nbytes = 4 * (buf.numel() + wgt.numel() + out.numel())
+            probe.records.append((e0, e1, m, wgt.shape[-3], 49, 3, nbytes, 1.0))
+            return out
+        ops.conv_stem = timed_stem
         from stabstitch2_amd import layers, smooth_network
         layers.ops = ops
         smooth_network.ops = ops
@@ -96,7 +111,7 @@ class ConvProbe:
         # algorithmic MACs use the channels that carry data (zero-padded taps excluded)
         if cin == 4 and taps == 9:
             return 2          # CCL flow (dx, dy) regressor input
-        return {4: 3, 124: 121, 52: 49}.get(cin, cin)
+        return {4: 3, 124: 121, 52: 49}.get(cin, cin)          # (the stem reports its 3 real channels itself)
 
     def report(self):
         agg = {}

@@ -66,6 +66,18 @@ SS_API int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, co
                  int groups, long long in_gs, long long w_gs, long long out_gs,
                  float* ws, long long ws_floats, void* stream);
 
+/* ---- the network stem: nn.Conv2d(3, 64, 7, stride 2, pad 3)(+BN)(+ReLU) of the ResNet-18 trunk (spatial_network.py:127-129,
+ * temporal_network.py:47-49) on a 3-channel layout whose filter ROWS are contiguous: K = 7 x 24 = 168 instead of
+ * 49 x 4 = 196 of the 4-channel NHWC form (147 real products).
+ *   ss_nchw_to_nhwc3_padded   frames [n][3][h][w] -> [n][h][w + 8][3], 3 zero pixels left / 5 right
+ *   ss_conv_stem3             in_padded as above, wgt [cout][7][24] (wgt[co][dh][3 dw + c] = w[co][c][dh][dw], rest 0),
+ *                             out [n][ho][wo][out_cs]; bias / relu / out_cs / groups as ss_conv_nhwc (in_gs = 0 shares the
+ *                             input between groups) */
+SS_API int ss_nchw_to_nhwc3_padded(const float* in, float* out, int n, int h, int w, void* stream);
+SS_API int ss_conv_stem3(const float* in_padded, const float* wgt, const float* bias, float* out, int n, int h, int w,
+                         int cout, int relu, int out_cs, int groups, long long in_gs, long long w_gs, long long out_gs,
+                         void* stream);
+
 /* ---- the same convolution for 3x3 / stride 1 / pad 1 layers as fused Winograd F(2x2,3x3) on the fp32 matrix cores
  * (2.25x fewer MFMA flops; input and output transforms inside the GEMM kernel, nothing extra through HBM).  Replaces
  * the stride-1 3x3 nn.Conv2d(+BN)(+residual)(+ReLU) of the trunk bodies and regressors (spatial_network.py:132-136,
@@ -140,12 +152,17 @@ SS_API int ss_tps_solve(const float* source, const float* target, float* T, int 
 /* point [n][q][2] evaluated through (source, T) -> out [n][q][2] */
 SS_API int ss_tps_points(const float* point, const float* source, const float* T, float* out, int n, int q,
                   void* stream);
+/* W^-1 (fp64, [66][66]) of the TPS system of ONE control-point set: `torch.inverse(W.double())` of
+ * utils/torch_tps_transform_point.py:113.  For callers that solve from a constant source mesh (see ss_tsmotion). */
+SS_API int ss_tps_inverse(const float* source, double* winv, void* stream);
 /* test_online_tra.py:309-347 for one view, all frames at once: smotion, tmotion [n][63][2] (LR px)
  * -> smesh [n][63][2] = rigid + smotion, tsmotion [n][63][2] (frame 0 = 0).
- * ws: ss_tsmotion_workspace_floats(n) floats. */
+ * Every system of this composition has the RIGID mesh as its source, so T = W^-1 [target; 0] with one constant W^-1:
+ * rigid_winv = ss_tps_inverse(normalised rigid mesh of (img_h, img_w)) computed once by the caller, or NULL (then each
+ * frame runs its own elimination).  ws: ss_tsmotion_workspace_floats(n) floats. */
 SS_API long long ss_tsmotion_workspace_floats(int n);
 SS_API int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
-                float img_h, float img_w, float* ws, void* stream);
+                       float img_h, float img_w, const double* rigid_winv, float* ws, void* stream);
 
 /* ---- K12/K13: dense TPS warp and fusion (utils/torch_tps_transform.py:108-165,
  *      test_online_tra.py:34-58, 138-150) ----------------------------------------------------- */

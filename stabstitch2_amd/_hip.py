@@ -25,6 +25,8 @@ SIGNATURES = {
     'ss_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_conv_workspace_need': (c_ll, [c_i] * 14),
     'ss_conv_nhwc': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 15 + [c_i, c_ll, c_ll, c_ll, c_fp, c_ll, c_st]),
+    'ss_nchw_to_nhwc3_padded': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
+    'ss_conv_stem3': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_ll] * 3 + [c_st]),
     'ss_wino_packed_floats': (c_ll, [c_i, c_i]),
     'ss_wino_pack': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_conv_uses_winograd': (c_i, [c_i] * 9),
@@ -44,7 +46,8 @@ SIGNATURES = {
     'ss_tps_solve': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
     'ss_tps_points': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_st]),
     'ss_tsmotion_workspace_floats': (c_ll, [c_i]),
-    'ss_tsmotion': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_f, c_fp, c_st]),
+    'ss_tps_inverse': (c_i, [c_fp, c_fp, c_st]),
+    'ss_tsmotion': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_f, c_fp, c_fp, c_st]),
     'ss_tps_warp_nchw': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_tps_warp_mask_nchw': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_tps_warp_views': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),

@@ -44,6 +44,7 @@ struct ConvP {
     float* out;
     float* partial;          // split-K workspace [groups*splits][M][Co] or nullptr
     int T, H, W, C;
+    int px_b, row_b;                 // bytes between x-neighbours / rows of the input (C * 4, W * C * 4 for plain NHWC)
     int To, Ho, Wo, Co;
     int kt, kh, kw, s;
     int pt, ph, pw;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         const uint32_t n = ss_div32(t2, p.divTo);
         const int to = (int)(t2 - n * (uint32_t)p.To);
         const int ti0 = to - p.pt, hi0 = ho * p.s - p.ph, wi0 = wo * p.s - p.pw;
-        const int aoff = ((((int)n * p.T + ti0) * p.H + hi0) * p.W + wi0) * p.C * 4;     // bytes
+        const int aoff = (((int)n * p.T + ti0) * p.H + hi0) * p.row_b + wi0 * p.px_b;     // bytes
         // valid taps along each axis form one interval [lo, hi): bit mask = (1 << hi) - (1 << lo)
         auto span = [](int x0, int k, int size) -> unsigned {
             int lo = max(0, -x0), hi = min(k, size - x0);
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
                 int dw = (int)tap - (int)t2 * p.kw;
                 uint32_t dt = ss_fastdiv(t2, p.divKh);
                 int dh = (int)t2 - (int)dt * p.kh;
-                int tapoff = ((((int)dt * p.H + dh) * p.W + dw) * p.C + ci) * 4;
+                int tapoff = ((int)dt * p.H + dh) * p.row_b + dw * p.px_b + ci * 4;
                 tap_tab[e] = k < p.K ? make_uint2((unsigned)tapoff, tap) : make_uint2(0u, 64u);
             }
         }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
         int dw = (int)tap - (int)t2 * p.kw;
         uint32_t dt = ss_fastdiv(t2, p.divKh);
         int dh = (int)t2 - (int)dt * p.kh;
-        int tapoff = ((((int)dt * p.H + dh) * p.W + dw) * p.C + ci) * 4;     // bytes
+        int tapoff = ((int)dt * p.H + dh) * p.row_b + dw * p.px_b + ci * 4;     // bytes
         unsigned sw = (unsigned)dw, sh = 8u + (unsigned)dh, st = 16u + dt;
         // branch-free: an invalid lane ORs its offset up to 0xFFFFFFFF and the descriptor returns zeros
         const unsigned kmask = kok ? 0u : 0xFFFFFFFFu;
@@ -522,6 +523,9 @@ extern "C" long long ss_conv_workspace_need(int n, int t, int h, int w, int cin,
     return splits > 1 ? (long long)groups * splits * M * cout : 0;
 }
 
+static int conv_dispatch(ConvP& p, long long K, long long M, int groups, int taps, float* ws, long long ws_floats,
+                         hipStream_t st);
+
 extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, const float* res, float* out,
                             int n, int t, int h, int w, int cin, int cout, int kt, int kh, int kw, int stride,
                             int pad_t, int pad_h, int pad_w, int relu, int out_cs, int groups, long long in_gs,
@@ -547,6 +551,21 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     if (K >= 65536 || M >= (1ll << 31) || in_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31) ||
         M * (long long)(out_cs > cout ? out_cs : cout) * 4 >= (1ll << 32))
         return SS_ERR_UNSUPPORTED;
+    p.px_b = cin * 4;
+    p.row_b = w * cin * 4;
+    p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
+    p.in_bytes = (unsigned)(in_elems * 4);
+    p.w_bytes = (unsigned)(w_elems * 4);
+    p.relu = relu; p.out_cs = out_cs;
+    return conv_dispatch(p, K, M, groups, kt * kh * kw, ws, ws_floats, (hipStream_t)stream);
+}
+
+// Tile choice, split-K plan and launch of a filled ConvP (shared by ss_conv_nhwc and ss_conv_stem3)
+static int conv_dispatch(ConvP& p, long long K, long long M, int groups, int taps, float* ws, long long ws_floats,
+                         hipStream_t st) {
+    const int cout = p.Co;
+    const int kt = p.kt, kh = p.kh, kw = p.kw, cin = p.C;
+    (void)kt; (void)kh; (void)kw;
     p.K = (int)K; p.M = (int)M;
     p.divC = ss_fastdiv_make((uint32_t)cin);
     p.divKw = ss_fastdiv_make((uint32_t)kw);
@@ -554,11 +573,6 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     p.divWo = ss_div32_make((uint32_t)p.Wo);
     p.divHo = ss_div32_make((uint32_t)p.Ho);
     p.divTo = ss_div32_make((uint32_t)p.To);
-    p.relu = relu; p.out_cs = out_cs;
-    p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
-    p.in_bytes = (unsigned)(in_elems * 4);
-    p.w_bytes = (unsigned)(w_elems * 4);
-    hipStream_t st = (hipStream_t)stream;
     const int nk = ss_cdiv(K, 32);
     p.splits = 1;
     p.tiles_per_split = nk;
@@ -576,15 +590,17 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     int best = 6;
     const int force = g_force_tile;   // tuning aid only
     if (force) best = force;
-    const int taps = kt * kh * kw;
     const bool tail = (K % 32) != 0 && (K % 32) < 16;
+#ifdef SS_TUNING
     if (best == 5) {
         launch_auto<2, 2, 2, 2, 1, 32, 1>(p, groups, st, taps, false);
     } else if (best == 7) {
         launch_auto<2, 2, 2, 1, 1, 32, 1>(p, groups, st, taps, false);
     } else if (best == 16) {
         launch_auto<2, 2, 1, 2, 1, 32, 1>(p, groups, st, taps, false);
-    } else {
+    } else
+#endif
+    {
         // default: 64x64 tiles, single LDS buffer; small problems are additionally split along K so that ~512
         // workgroups exist
         const int splits = conv_splits(M, cout, groups, nk);
@@ -613,6 +629,42 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
         }
     }
     return ss_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The network stem: 7x7 / stride 2 / pad 3 convolution of the 3-channel frame (spatial_network.py:127-129).  With the
+// 4-channel NHWC input of ss_conv_nhwc every filter tap carries a zero channel: K = 49 x 4 = 196 for 147 real products
+// (25 % of the MFMAs multiply zeros).  Here the input is [n][H][W + 8][3] (ss_nchw_to_nhwc3_padded: 3 zero pixels left,
+// 5 right), so the 7 x 3 = 21 values of one filter ROW are contiguous in memory; a row is padded to 24 (the 22nd..24th
+// read the next pixel against zero weights) and the K axis becomes (kh, 24): K = 168, 12.5 % padding, and the tap table
+// has 7 entries (one per filter row: row validity is the only halo left, the x halo is real zeros in the buffer).
+// Same kernel (conv_igemm_kernel), different pitches: x-neighbours are 12 bytes apart, a "tap" is 24 channels wide.
+//   wgt [cout][7][24]: wgt[co][dh][3 dw + c] = w[co][c][dh][dw], entries 21..23 zero  (layers.pack_stem3)
+extern "C" int ss_conv_stem3(const float* in_padded, const float* wgt, const float* bias, float* out, int n, int h, int w,
+                             int cout, int relu, int out_cs, int groups, long long in_gs, long long w_gs, long long out_gs,
+                             void* stream) {
+    if (!in_padded || !wgt || !out || n <= 0 || h <= 0 || w <= 0 || cout <= 0 || groups <= 0 || out_cs < cout)
+        return SS_ERR_ARG;
+    const int wp = w + 8;
+    ConvP p;
+    p.in = in_padded; p.wgt = wgt; p.bias = bias; p.res = nullptr; p.out = out; p.partial = nullptr;
+    p.T = 1; p.H = h; p.W = wp; p.C = 24;
+    p.To = 1;
+    p.Ho = (h + 6 - 7) / 2 + 1;
+    p.Wo = (w + 6 - 7) / 2 + 1;
+    p.Co = cout;
+    if (p.Ho <= 0 || p.Wo <= 0) return SS_ERR_ARG;
+    p.kt = 1; p.kh = 7; p.kw = 1; p.s = 2; p.pt = 0; p.ph = 3; p.pw = 0;      // x padding lives in the buffer
+    const long long K = 7 * 24, M = (long long)n * p.Ho * p.Wo;
+    const long long in_elems = (long long)n * h * wp * 3, w_elems = (long long)cout * K;
+    if (M >= (1ll << 31) || in_elems * 4 >= (1ll << 31) || M * (long long)out_cs * 4 >= (1ll << 32)) return SS_ERR_UNSUPPORTED;
+    p.px_b = 3 * 4;
+    p.row_b = wp * 3 * 4;
+    p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
+    p.in_bytes = (unsigned)(in_elems * 4);
+    p.w_bytes = (unsigned)(w_elems * 4);
+    p.relu = relu; p.out_cs = out_cs;
+    return conv_dispatch(p, K, M, groups, 7, nullptr, 0, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -767,6 +819,35 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
     if (c > 2) v.z = s[2ll * hw];
     if (c > 3) v.w = s[3ll * hw];
     out[pix] = v;
+}
+
+// [n][3][h][w] -> [n][h][w + 8][3] with 3 zero pixels on the left and 5 on the right (the stem's x halo + row padding)
+__global__ __launch_bounds__(256) void nchw_to_nhwc3_padded_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                   int h, int w, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // one thread per (image, row, padded x)
+    if (idx >= total) return;
+    const int wp = w + 8;
+    const int xp = (int)(idx % wp);
+    const long long r = idx / wp;                  // image * h + row
+    const int y = (int)(r % h);
+    const long long b = r / h;
+    const int x = xp - 3;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)x < (unsigned)w) {
+        const float* s = in + (b * 3 * h + y) * (long long)w + x;
+        const long long hw = (long long)h * w;
+        v0 = s[0]; v1 = s[hw]; v2 = s[2 * hw];
+    }
+    float* o = out + idx * 3;
+    o[0] = v0; o[1] = v1; o[2] = v2;
+}
+
+extern "C" int ss_nchw_to_nhwc3_padded(const float* in, float* out, int n, int h, int w, void* stream) {
+    if (!in || !out || n <= 0 || h <= 0 || w <= 0) return SS_ERR_ARG;
+    const long long total = (long long)n * h * (w + 8);
+    hipLaunchKernelGGL(nchw_to_nhwc3_padded_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, h,
+                       w, total);
+    return ss_launch_status();
 }
 
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int c, int h, int w,

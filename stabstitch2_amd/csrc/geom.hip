@@ -374,6 +374,98 @@ extern "C" int ss_tps_points(const float* point, const float* source, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// W^-1 of the 66x66 TPS system of ONE control-point set, in fp64 (torch.inverse(W.double()), utils/
+// torch_tps_transform_point.py:113).  Where the source mesh is a constant -- the tsmotion composition always solves from the
+// RIGID mesh (test_online_tra.py:330, 338) -- the reference's `T = W_inv @ [target; 0]` is a 66x63 matrix product per system
+// once W^-1 is known; the caller caches W^-1 per (image size, device) instead of paying a 94 us latency-bound elimination
+// per call.  In-place Gauss-Jordan inversion with partial pivoting, one workgroup, matrix in LDS.
+__global__ __launch_bounds__(256) void tps_inverse_kernel(const float* __restrict__ source, double* __restrict__ winv) {
+    constexpr int N = SS_NT, LD = SS_NT + 1;
+    __shared__ double A[N * LD];
+    __shared__ float sx[SS_NV], sy[SS_NV];
+    __shared__ double colk[N];
+    __shared__ int perm[N];
+    __shared__ int s_piv;
+    const int tid = threadIdx.x;
+    if (tid < SS_NV) { sx[tid] = source[tid * 2]; sy[tid] = source[tid * 2 + 1]; }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += 256) {
+        const int r = i / N, c = i - r * N;
+        double v = 0.0;
+        if (r < SS_NV) {
+            if (c == 0) v = 1.0;
+            else if (c == 1) v = sx[r];
+            else if (c == 2) v = sy[r];
+            else {           // same fp32 kernel entries as tps_solve_kernel (correctly rounded log)
+                float dx = __fsub_rn(sx[r], sx[c - 3]), dy = __fsub_rn(sy[r], sy[c - 3]);
+                float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                v = (double)__fmul_rn(d2, (float)log((double)__fadd_rn(d2, 1e-6f)));
+            }
+        } else if (c >= 3) {
+            const int k = r - SS_NV;
+            v = k == 0 ? 1.0 : (k == 1 ? (double)sx[c - 3] : (double)sy[c - 3]);
+        }
+        A[r * LD + c] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        if (tid < 64) {                      // pivot: largest |A[r][k]|, r >= k (lowest row wins ties)
+            double best = -1.0;
+            int piv = k;
+            for (int r = k + tid; r < N; r += 64) {
+                const double v = fabs(A[r * LD + k]);
+                if (v > best) { best = v; piv = r; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int op = __shfl_xor(piv, o, 64);
+                if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+            }
+            if (tid == 0) { s_piv = piv; perm[k] = piv; }
+        }
+        __syncthreads();
+        const int piv = s_piv;
+        if (piv != k && tid < N) {           // swap rows k and piv
+            const double t = A[k * LD + tid];
+            A[k * LD + tid] = A[piv * LD + tid];
+            A[piv * LD + tid] = t;
+        }
+        __syncthreads();
+        if (tid < N) colk[tid] = A[tid * LD + k];
+        __syncthreads();
+        const double pinv = 1.0 / colk[k];
+        if (tid < N) A[k * LD + tid] = (tid == k ? 1.0 : A[k * LD + tid]) * pinv;
+        __syncthreads();
+        for (int i = tid; i < N * N; i += 256) {
+            const int r = i / N, c = i - r * N;
+            if (r != k) {
+                const double f = colk[r];
+                const double base = c == k ? 0.0 : A[r * LD + c];
+                A[r * LD + c] = base - f * A[k * LD + c];
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = N - 1; k >= 0; --k) {       // undo the row exchanges as column exchanges, in reverse order
+        const int pk = perm[k];
+        if (pk != k && tid < N) {
+            const double t = A[tid * LD + k];
+            A[tid * LD + k] = A[tid * LD + pk];
+            A[tid * LD + pk] = t;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < N * N; i += 256) winv[i] = A[(i / N) * LD + (i % N)];
+}
+
+extern "C" int ss_tps_inverse(const float* source, double* winv, void* stream) {
+    if (!source || !winv) return SS_ERR_ARG;
+    hipLaunchKernelGGL(tps_inverse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, source, winv);
+    return ss_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // tsmotion (test_online_tra.py:309-347), one view, all frames
 // ws layout: [nrigid 126][ntgt n*126][npts n*126][T n*132]
 __global__ void tsm_prepare_kernel(const float* __restrict__ smotion, const float* __restrict__ tmotion,
@@ -400,15 +492,29 @@ __global__ void tsm_prepare_kernel(const float* __restrict__ smotion, const floa
     npts[(long long)k * 126 + v * 2 + 1] = norm1(__fadd_rn(ry, tmotion[idx * 2 + 1]), img_h);
 }
 
-__global__ void tsm_finish_kernel(const float* __restrict__ ws, const float* __restrict__ smesh,
-                                  float* __restrict__ tsmotion, int n, float img_h, float img_w) {
+// winv != nullptr: T = W^-1 [target; 0] computed here (66 x 63 fp64 products per coordinate, rounded to fp32 like the
+// reference's `T.type(torch.float32)`); else T comes from the per-system elimination
+__global__ __launch_bounds__(256) void tsm_finish_kernel(const float* __restrict__ ws, const float* __restrict__ smesh,
+                                                         const double* __restrict__ winv, float* __restrict__ tsmotion,
+                                                         int n, float img_h, float img_w) {
     __shared__ float sx[SS_NV], sy[SS_NV], Tx[SS_NT], Ty[SS_NT];
+    __shared__ float tg[SS_NV * 2];
     int k = blockIdx.x, v = threadIdx.x;
     const float* nrigid = ws;
+    const float* ntgt = ws + 126;
     const float* npts = ws + 126 + (long long)n * 126;
     const float* T = npts + (long long)n * 126 + (long long)k * 132;
     if (v < SS_NV) { sx[v] = nrigid[v * 2]; sy[v] = nrigid[v * 2 + 1]; }
-    if (v < SS_NT) { Tx[v] = T[v]; Ty[v] = T[SS_NT + v]; }
+    if (winv) {
+        if (v < SS_NV * 2) tg[v] = ntgt[(long long)k * 126 + v];
+        __syncthreads();
+        if (v < 2 * SS_NT) {
+            const int c = v / SS_NT, r = v - c * SS_NT;
+            double acc = 0.0;
+            for (int j = 0; j < SS_NV; ++j) acc = fma(winv[r * SS_NT + j], (double)tg[j * 2 + c], acc);
+            if (c == 0) Tx[r] = (float)acc; else Ty[r] = (float)acc;
+        }
+    } else if (v < SS_NT) { Tx[v] = T[v]; Ty[v] = T[SS_NT + v]; }
     __syncthreads();
     if (v >= SS_NV) return;
     long long o = ((long long)k * SS_NV + v) * 2;
@@ -422,16 +528,17 @@ __global__ void tsm_finish_kernel(const float* __restrict__ ws, const float* __r
 extern "C" long long ss_tsmotion_workspace_floats(int n) { return 126 + (long long)n * (126 + 126 + 132); }
 
 extern "C" int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
-                           float img_h, float img_w, float* ws, void* stream) {
+                           float img_h, float img_w, const double* rigid_winv, float* ws, void* stream) {
     if (!smotion || !tmotion || !smesh || !tsmotion || !ws || n <= 0) return SS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tsm_prepare_kernel, dim3(ss_cdiv(n * SS_NV, 128)), dim3(128), 0, st, smotion, tmotion, smesh, ws,
                        n, img_h, img_w);
     float* ntgt = ws + 126;
     float* T = ntgt + (long long)n * 252;
-    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, st, (const float*)ws, 0ll, (const float*)ntgt, T);
-    hipLaunchKernelGGL(tsm_finish_kernel, dim3(n), dim3(128), 0, st, (const float*)ws, (const float*)smesh, tsmotion,
-                       n, img_h, img_w);
+    if (!rigid_winv)
+        hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, st, (const float*)ws, 0ll, (const float*)ntgt, T);
+    hipLaunchKernelGGL(tsm_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)ws, (const float*)smesh, rigid_winv,
+                       tsmotion, n, img_h, img_w);
     return ss_launch_status();
 }
 

@@ -78,6 +78,20 @@ def pack_conv2d(conv, bn=None):
     return out.contiguous(), bias
 
 
+def pack_stem3(conv, bn):
+    """The 7x7 / stride-2 stem of the trunk for ss_conv_stem3: [cout,3,7,7] (+ folded BN) -> (wgt [cout,7,24], bias):
+    wgt[co][dh][3 dw + c] = w[co][c][dh][dw]; entries 21..23 of every filter row are zero."""
+    w = conv.weight.detach().float()
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    w = w * scale.view(-1, 1, 1, 1)
+    bias = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
+    cout = w.shape[0]
+    assert tuple(w.shape[1:]) == (3, 7, 7)
+    out = torch.zeros((cout, 7, 24), device=w.device, dtype=torch.float32)
+    out[:, :, :21] = w.permute(0, 2, 3, 1).reshape(cout, 7, 21)         # [co][dh][dw][c] -> dw-major, channel fastest
+    return out.contiguous(), bias
+
+
 def pack_conv3d(conv):
     w = conv.weight.detach().float()          # [cout,cin,kt,kh,kw]
     return w.permute(0, 2, 3, 4, 1).contiguous(), conv.bias.detach().float().contiguous()
@@ -139,7 +153,7 @@ class PreparedMixin:
 
 # --------------------------------------------------------------------------- forward helpers (HIP)
 def prep_trunk_stage1(stage1):
-    p = {'conv1': pack_conv2d(stage1[0], stage1[1])}
+    p = {'conv1': pack_stem3(stage1[0], stage1[1])}
     p['layer1'] = [prep_block(b) for b in stage1[4]]
     p['layer2'] = [prep_block(b) for b in stage1[5]]
     return p
@@ -173,29 +187,18 @@ def run_stage1(x_nchw, p, chunk=None):
     """NCHW input(s) in [-1,1] -> nhwc [n,H/8,W/8,128].  `x_nchw` may be a list of [n_i,3,H,W] tensors: they are
     laid out back to back in one NHWC buffer (no torch.cat of the inputs) and run as one batch."""
     chunk = chunk or STAGE1_CHUNK
-    xs = x_nchw if isinstance(x_nchw, (list, tuple)) else [x_nchw]
-    total = sum(x.shape[0] for x in xs)
-    h, w = xs[0].shape[2], xs[0].shape[3]
-    buf = torch.empty((total, h, w, 4), device=xs[0].device, dtype=torch.float32)
-    o = 0
-    for x in xs:
-        ops.nchw_to_nhwc(x, 4, out=buf[o:o + x.shape[0]])
-        o += x.shape[0]
+    buf = ops.stem_input(x_nchw)                     # [total, h, w + 8, 3]
+    total, h, w = buf.shape[0], buf.shape[1], buf.shape[2] - 8
     outs = []
     for s in range(0, total, chunk):
         m = min(chunk, total - s)
-        if CONV1_CHUNK > 0 and m > CONV1_CHUNK:
-            x = torch.empty((m, (h // 2 + 1) // 2, (w // 2 + 1) // 2, 64), device=buf.device, dtype=torch.float32) \
-                if (h % 2 == 0 and w % 2 == 0) else None
-        else:
-            x = None
-        if x is not None:
+        if CONV1_CHUNK > 0 and m > CONV1_CHUNK and h % 2 == 0 and w % 2 == 0:
+            x = torch.empty((m, (h // 2 + 1) // 2, (w // 2 + 1) // 2, 64), device=buf.device, dtype=torch.float32)
             for c0 in range(0, m, CONV1_CHUNK):
-                y = ops.conv(buf[s + c0:s + min(c0 + CONV1_CHUNK, m)], p['conv1'][0], p['conv1'][1], stride=2,
-                             pad=(0, 3, 3), relu=True)
+                y = ops.conv_stem(buf[s + c0:s + min(c0 + CONV1_CHUNK, m)], p['conv1'][0], p['conv1'][1], relu=True)
                 ops.maxpool(y, 3, 2, 1, out=x[c0:c0 + y.shape[0]])
         else:
-            x = ops.conv(buf[s:s + chunk], p['conv1'][0], p['conv1'][1], stride=2, pad=(0, 3, 3), relu=True)
+            x = ops.conv_stem(buf[s:s + chunk], p['conv1'][0], p['conv1'][1], relu=True)
             x = ops.maxpool(x, 3, 2, 1)
         for b in p['layer1']:
             x = run_block(x, b)
@@ -294,15 +297,9 @@ def pair_trunks(pa, pb):
 def run_stage1_pair(xs, pp):
     """The same NCHW inputs through TWO trunks (weights stacked by pair_trunks) -> nhwc [2,n,H/8,W/8,128]:
     every layer is one grouped launch; conv1 reads the shared input once per group (group stride 0)."""
-    xs = xs if isinstance(xs, (list, tuple)) else [xs]
-    total = sum(x.shape[0] for x in xs)
-    h, w = xs[0].shape[2], xs[0].shape[3]
-    buf = torch.empty((total, h, w, 4), device=xs[0].device, dtype=torch.float32)
-    o = 0
-    for x in xs:
-        ops.nchw_to_nhwc(x, 4, out=buf[o:o + x.shape[0]])
-        o += x.shape[0]
-    y = ops.conv_grouped(buf, pp['conv1'][0], pp['conv1'][1], None, stride=2, pad=(0, 3, 3), relu=True)
+    buf = ops.stem_input(xs)
+    total = buf.shape[0]
+    y = ops.conv_stem(buf, pp['conv1'][0], pp['conv1'][1], relu=True)           # [2, total, H/2, W/2, 64]
     y = ops.maxpool(y.view(2 * total, *y.shape[2:]), 3, 2, 1)
     y = y.view(2, total, *y.shape[1:])
     for b in pp['layer1'] + pp['layer2']:
@@ -323,21 +320,16 @@ def run_stem_shared(xs, stem):
     """NCHW inputs (list) -> (pool_a, pool_b) nhwc [n,H/4,W/4,64]: conv1 + ReLU + max-pool of two trunks that read the
     same frames, computed by one 128-filter conv1 (the input tile, the row bookkeeping and the NHWC conversion are
     shared) and a pool that splits the channels; 16-image sub-chunks keep conv1's output MALL-resident."""
-    total = sum(x.shape[0] for x in xs)
-    h, w = xs[0].shape[2], xs[0].shape[3]
-    dev = xs[0].device
-    buf = torch.empty((total, h, w, 4), device=dev, dtype=torch.float32)
-    o = 0
-    for x in xs:
-        ops.nchw_to_nhwc(x, 4, out=buf[o:o + x.shape[0]])
-        o += x.shape[0]
+    buf = ops.stem_input(xs)
+    total, h, w = buf.shape[0], buf.shape[1], buf.shape[2] - 8
+    dev = buf.device
     ho, wo = ((h - 1) // 2 + 2) // 2, ((w - 1) // 2 + 2) // 2
     pa = torch.empty((total, ho, wo, 64), device=dev, dtype=torch.float32)
     pb = torch.empty((total, ho, wo, 64), device=dev, dtype=torch.float32)
     step = CONV1_CHUNK if CONV1_CHUNK > 0 else total
     for c0 in range(0, total, step):
         c1 = min(c0 + step, total)
-        y = ops.conv(buf[c0:c1], stem[0], stem[1], stride=2, pad=(0, 3, 3), relu=True)      # [m,H/2,W/2,128]
+        y = ops.conv_stem(buf[c0:c1], stem[0], stem[1], relu=True)                          # [m,H/2,W/2,128]
         ops.maxpool_split(y, 3, 2, 1, pa[c0:c1], pb[c0:c1])
     return pa, pb
 

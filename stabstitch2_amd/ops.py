@@ -31,6 +31,36 @@ def nhwc_to_nchw(x, c=None):
     return out
 
 
+def stem_input(xs):
+    """NCHW frames (one tensor [n,3,h,w] or a list of them, laid back to back) -> [N,h,w+8,3]: the stem convolution's
+    input layout (3 zero pixels left, 5 right; ss_nchw_to_nhwc3_padded)."""
+    xs = xs if isinstance(xs, (list, tuple)) else [xs]
+    total = sum(x.shape[0] for x in xs)
+    h, w = xs[0].shape[2], xs[0].shape[3]
+    buf = torch.empty((total, h, w + 8, 3), device=xs[0].device, dtype=torch.float32)
+    o = 0
+    for x in xs:
+        assert x.shape[1] == 3 and tuple(x.shape[2:]) == (h, w), x.shape
+        H.call('ss_nchw_to_nhwc3_padded', H.dptr(_f(x)), H.dptr(buf[o:o + x.shape[0]]), x.shape[0], h, w, H.stream())
+        o += x.shape[0]
+    return buf
+
+
+def conv_stem(buf, wgt, bias=None, relu=True):
+    """7x7 / stride 2 / pad 3 stem on `stem_input` frames.  wgt [cout,7,24] (layers.pack_stem3) -> [n,ho,wo,cout];
+    wgt [g,cout,7,24] / bias [g,cout]: g stems reading the SAME frames in one launch -> [g,n,ho,wo,cout]."""
+    n, h, wp, _ = buf.shape
+    w = wp - 8
+    grouped = wgt.dim() == 4
+    g = wgt.shape[0] if grouped else 1
+    cout = wgt.shape[-3]
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty(((g, n, ho, wo, cout) if grouped else (n, ho, wo, cout)), device=buf.device, dtype=torch.float32)
+    H.call('ss_conv_stem3', H.dptr(buf), H.dptr(wgt), H.dptr(bias, True), H.dptr(out), n, h, w, cout, int(relu), cout, g,
+           0, wgt[0].numel() if grouped else 0, out[0].numel() if grouped else 0, H.stream())
+    return out
+
+
 # ------------------------------------------------------------------ conv / pool / fc
 def conv_workspace(device, floats):
     """Split-K scratch for ONE launch, sized by ss_conv_workspace_need and taken from torch's caching allocator on the
@@ -260,14 +290,35 @@ def tps_points(point, source, T):
     return out
 
 
+_rigid_winv = {}
+RIGID_INVERSE_CACHE = True      # host switch for A/B runs and the equivalence test
+
+
+def rigid_winv(img_h, img_w, device):
+    """fp64 W^-1 of the TPS system whose control points are the normalised RIGID mesh of an (img_h, img_w) image: a
+    constant of the tsmotion composition, computed once per (size, device) by ss_tps_inverse."""
+    key = (int(img_h), int(img_w), str(device))
+    w = _rigid_winv.get(key)
+    if w is None:
+        xs = torch.linspace(0.0, float(img_w), 9)
+        ys = torch.linspace(0.0, float(img_h), 7)
+        m = torch.stack((xs.view(1, -1).expand(7, -1), ys.view(-1, 1).expand(-1, 9)), 2).reshape(63, 2)
+        src = torch.stack((m[:, 0] * 2. / float(img_w) - 1., m[:, 1] * 2. / float(img_h) - 1.), 1).contiguous().to(device)
+        w = torch.empty((66, 66), device=device, dtype=torch.float64)
+        H.call('ss_tps_inverse', H.dptr(src), H.dptr(w, dtype=torch.float64), H.stream())
+        _rigid_winv[key] = w
+    return w
+
+
 def tsmotion(smotion, tmotion, img_h=360, img_w=480):
     """smotion, tmotion [n,7,9,2] -> (smesh, tsmotion) [n,7,9,2]."""
     n = smotion.shape[0]
     ws = torch.empty(int(H.lib().ss_tsmotion_workspace_floats(n)), device=smotion.device, dtype=torch.float32)
     smesh = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
     tsm = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
+    winv = rigid_winv(img_h, img_w, smotion.device) if RIGID_INVERSE_CACHE else None
     H.call('ss_tsmotion', H.dptr(_f(smotion)), H.dptr(_f(tmotion)), H.dptr(smesh), H.dptr(tsm), n, float(img_h),
-           float(img_w), H.dptr(ws), H.stream())
+           float(img_w), H.dptr(winv, True, dtype=torch.float64), H.dptr(ws), H.stream())
     return smesh, tsm
 
 

@@ -1011,3 +1011,59 @@ def test_ingest_u8_vs_handworked_cv2_vectors(dev):
         want = (dst.astype(np.float32).transpose(2, 0, 1) / np.float32(127.5)) - np.float32(1.0)
         assert np.array_equal(lr[0].cpu().numpy(), want.astype(np.float32)), name
         assert np.array_equal(hr[0].cpu().numpy(), src.astype(np.float32).transpose(2, 0, 1)), name
+
+
+def test_tsmotion_cached_rigid_inverse(dev, golden):
+    """tsmotion always solves its TPS systems from the RIGID mesh: with the cached fp64 W^-1 (ss_tps_inverse, the
+    reference's own torch.inverse + matmul formulation) the result equals the per-frame elimination and the reference."""
+    from stabstitch2_amd import ops
+    g8 = golden('g8_nets')
+    sm, tm = torch.from_numpy(g8['motion1']).to(dev), torch.from_numpy(g8['tmotion1']).to(dev)
+    a_mesh, a = ops.tsmotion(sm, tm)
+    old = ops.RIGID_INVERSE_CACHE
+    ops.RIGID_INVERSE_CACHE = False
+    try:
+        b_mesh, b = ops.tsmotion(sm, tm)
+    finally:
+        ops.RIGID_INVERSE_CACHE = old
+    assert torch.equal(a_mesh, b_mesh)
+    close(a, b, 2e-5, 'tsmotion: cached inverse vs per-frame elimination')
+    close(a, g8['tsmotion1'], 2e-3, 'tsmotion (cached inverse) vs reference')
+    # W^-1 W = I for the rigid control points (fp64)
+    winv = ops.rigid_winv(360, 480, dev)
+    assert winv.dtype == torch.float64 and tuple(winv.shape) == (66, 66)
+    nr = torch.from_numpy(cases.norm(cases.rigid(360, 480), 360, 480)[0]).double()
+    d2 = ((nr[:, None, :] - nr[None, :, :]) ** 2).sum(2).float()
+    r = (d2 * torch.log(d2 + 1e-6)).double()
+    p = torch.cat((torch.ones(63, 1, dtype=torch.float64), nr), 1)
+    W = torch.cat((torch.cat((p, r), 1), torch.cat((torch.zeros(3, 3, dtype=torch.float64), p.t()), 1)), 0)
+    # (W here uses torch's fp32 log, the kernel a correctly rounded one: the entries differ in the last bit, ~1e-6 through W^-1)
+    assert float((winv.cpu() @ W - torch.eye(66, dtype=torch.float64)).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('n,h,w,cout', [(2, 72, 96, 64), (3, 45, 61, 128), (1, 360, 480, 64), (1, 7, 9, 64)])
+def test_conv_stem_row_packed(dev, n, h, w, cout):
+    """ss_conv_stem3 (7x7 / 2 / pad 3 on the row-packed 3-channel layout, K = 7 x 24) vs F.conv2d + folded BN + ReLU, and
+    vs the 4-channel NHWC form of the same layer; grouped launch = two stems on the same frames."""
+    from stabstitch2_amd import ops, layers as L
+    rs = np.random.RandomState(h * 31 + w)
+    x = torch.from_numpy(rs.normal(0, 1, (n, 3, h, w)).astype(np.float32))
+    conv = torch.nn.Conv2d(3, cout, 7, 2, 3, bias=False)
+    bn = torch.nn.BatchNorm2d(cout).eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy((rs.normal(0, 1, (cout, 3, 7, 7)) / 12.0).astype(np.float32)))
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 2); bn.weight.uniform_(0.8, 1.2); bn.bias.normal_(0, 0.1)
+    ref = F.relu(bn(conv(x)))
+    wgt, bias = L.pack_stem3(conv, bn)
+    assert tuple(wgt.shape) == (cout, 7, 24) and float(wgt[:, :, 21:].abs().max()) == 0.0
+    buf = ops.stem_input([x[:1].to(dev), x[1:].to(dev)] if n > 1 else x.to(dev))
+    assert tuple(buf.shape) == (n, h, w + 8, 3) and float(buf[:, :, :3].abs().max()) == 0.0 and float(buf[:, :, w + 3:].abs().max()) == 0.0
+    out = ops.conv_stem(buf, wgt.to(dev), bias.to(dev), relu=True)
+    close(ops.nhwc_to_nchw(out), ref, 2e-5 * max(1.0, float(ref.abs().max())), 'stem conv vs F.conv2d')
+    w4, b4 = L.pack_conv2d(conv, bn)
+    old = ops.conv(ops.nchw_to_nhwc(x.to(dev), 4), w4.to(dev), b4.to(dev), stride=2, pad=(0, 3, 3), relu=True)
+    close(out, old, 2e-5 * max(1.0, float(ref.abs().max())), 'stem conv vs 4-channel NHWC form')
+    w2 = torch.stack((wgt, wgt.flip(0)), 0).contiguous().to(dev)
+    b2 = torch.stack((bias, bias.flip(0)), 0).contiguous().to(dev)
+    g = ops.conv_stem(buf, w2, b2, relu=True)
+    assert torch.equal(g[0], out) and torch.equal(g[1], out.flip(-1))

@@ -108,6 +108,14 @@ def test_weight_repacking_matches_eval_semantics():
     w2, b2 = L.pack_fc_first(lin, 5, 6)
     nhwc_flat = act.permute(0, 2, 3, 1).reshape(2, -1)
     assert torch.allclose(F.linear(nhwc_flat, w2, b2), lin(act.reshape(2, -1)), atol=1e-6)
+    stem = torch.nn.Conv2d(3, 8, 7, 2, 3, bias=False)
+    bn7 = torch.nn.BatchNorm2d(8).eval()
+    bn7.running_mean.normal_(); bn7.running_var.uniform_(0.5, 2); bn7.weight.data.normal_(); bn7.bias.data.normal_()
+    ws, bs = L.pack_stem3(stem, bn7)                                 # [cout, 7 rows, 24 = 7 taps x 3 channels + 3 zeros]
+    assert ws.shape == (8, 7, 24) and float(ws[..., 21:].abs().max()) == 0.0
+    w_back = ws[..., :21].reshape(8, 7, 7, 3).permute(0, 3, 1, 2)    # [co][c][dh][dw]
+    xs = torch.randn(1, 3, 20, 24)
+    assert torch.allclose(F.conv2d(xs, w_back, bs, stride=2, padding=3), bn7(stem(xs)), atol=1e-5)
     c3 = torch.nn.Conv3d(4, 6, (5, 3, 3), padding=(2, 1, 1))
     w3, b3 = L.pack_conv3d(c3)
     assert w3.shape == (6, 5, 3, 3, 4) and torch.equal(w3[2, 4, 1, 0, 3], c3.weight[2, 3, 4, 1, 0])
