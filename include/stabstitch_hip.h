@@ -179,9 +179,21 @@ SS_API int ss_tps_warp_views(const float* const* imgs, const float* source, cons
                       int h, int w, int hc, int wc, int mode, void* stream);
 /* fused render of one stitched frame, AVERAGE fusion, 2 or 3 views (chained (1+2)+3):
  * imgs: array of `views` device pointers (host array) to [3][h][w]; source [views][63][2];
- * T [views][2][66]; out [3][hc][wc]. */
-SS_API int ss_render_average(const float* const* imgs, const float* source, const float* T, float* out, int views,
-                      int h, int w, int hc, int wc, int mode, void* stream);
+ * T [views][2][66]; out [3][hc][wc].
+ * footprint: NULL = every view is evaluated at every canvas pixel (the reference's arithmetic everywhere, including the
+ * rounding residue its clamped sampler returns outside a view's image); or this frame's block of ss_render_footprints:
+ * 64 x 8-pixel tiles outside a view's mesh hull skip its 63-term spline and take its contribution as exactly 0
+ * (differs from the reference there by that residue, <~ 1e-2 grey levels of machine-dependent noise). */
+SS_API int ss_render_average(const float* const* imgs, const float* source, const float* T, const float* footprint,
+                             float* out, int views, int h, int w, int hc, int wc, int mode, void* stream);
+/* footprints of frames x views splines (source [frames][views][63][2], T [frames][views][2][66]) on an hc x wc canvas, one
+ * launch: per frame ss_render_footprint_floats(views, hc, wc) floats = exactly evaluated sampling coordinates on the
+ * lattice of tile corners, the bounding box of each view's control points (its mesh hull) and the frame's tile order
+ * (tiles sorted by the number of views that reach them, most expensive first); a tile is skipped for a view when it lies
+ * outside the hull AND its four corners sample more than 8 pixels outside the (h x w) image (csrc/render.hip). */
+SS_API long long ss_render_footprint_floats(int views, int hc, int wc);
+SS_API int ss_render_footprints(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
+                                int hc, int wc, void* stream);
 /* LINEAR fusion (linear_blender): ref, tgt [3][hc][wc]; ref_m, tgt_m [hc][wc]; out [3][hc][wc];
  * mask1_out optional [hc][wc]; ws: ss_linear_blend_workspace_floats(hc, wc) floats. */
 SS_API long long ss_linear_blend_workspace_floats(int hc, int wc);

@@ -55,7 +55,9 @@ SIGNATURES = {
     'ss_mask_union': (c_i, [c_fp, c_fp, c_fp, c_ll, c_st]),
     'ss_ingest_u8': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_canvas_to_u8': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
-    'ss_render_average': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_render_average': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_render_footprint_floats': (c_ll, [c_i, c_i, c_i]),
+    'ss_render_footprints': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
     'ss_linear_blend_workspace_floats': (c_ll, [c_i, c_i]),
     'ss_linear_blend': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_st]),
     'ss_mesh_bbox': (c_i, [c_fp, c_i, c_f, c_f, c_fp, c_i, c_st]),

@@ -111,6 +111,34 @@ __device__ __forceinline__ void tps_eval_pair(const float* __restrict__ src0, co
     oy = ay;
 }
 
+// ONE spline at two points with packed math (the single-view tiles of the fused render evaluate two canvas rows per
+// lane); per point the operations and their order are those of tps_eval_pair / tps_eval_fast: bit-identical coordinates.
+__device__ __forceinline__ void tps_eval_two_points(const float* __restrict__ src, const float* __restrict__ T, float x,
+                                                    float y0, float y1, ss_f2& ox, ss_f2& oy) {
+    const float* Tx = T;
+    const float* Ty = T + SS_NT;
+    ss_f2 ax = {fmaf(Tx[2], y0, fmaf(Tx[1], x, Tx[0])), fmaf(Tx[2], y1, fmaf(Tx[1], x, Tx[0]))};
+    ss_f2 ay = {fmaf(Ty[2], y0, fmaf(Ty[1], x, Ty[0])), fmaf(Ty[2], y1, fmaf(Ty[1], x, Ty[0]))};
+    const ss_f2 xx = {x, x}, yy = {y0, y1};
+    const ss_f2 eps = {1e-6f, 1e-6f};
+#pragma unroll 9
+    for (int k = 0; k < SS_NV; ++k) {
+        const ss_f2 sx = {src[2 * k], src[2 * k]};
+        const ss_f2 sy = {src[2 * k + 1], src[2 * k + 1]};
+        ss_f2 dx = xx - sx, dy = yy - sy;
+        ss_f2 d2 = dx * dx + dy * dy;
+        ss_f2 a = d2 + eps;
+        ss_f2 lg = {__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)};
+        ss_f2 r = d2 * (lg * 0.6931471805599453f);
+        const ss_f2 tx = {Tx[3 + k], Tx[3 + k]};
+        const ss_f2 ty = {Ty[3 + k], Ty[3 + k]};
+        ax = __builtin_elementwise_fma(tx, r, ax);
+        ay = __builtin_elementwise_fma(ty, r, ay);
+    }
+    ox = ax;
+    oy = ay;
+}
+
 // scalar twin of tps_eval_pair (same operations in the same order -> bit-identical coordinates), used by the
 // generic per-view warp so that the fused render can be checked against it exactly
 __device__ __forceinline__ void tps_eval_fast(const float* __restrict__ src, const float* __restrict__ Tx,

@@ -179,68 +179,265 @@ __device__ __forceinline__ float avg_fuse(float a, float b) {
     return __fadd_rn(__fmul_rn(a, a / s), __fmul_rn(b, b / s));
 }
 
-template <int VIEWS>
-__global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, const float* __restrict__ source,
-                                                             const float* __restrict__ T, float* __restrict__ out,
-                                                             int h, int w, int hc, int wc, int mode) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= wc || y >= hc) return;
-    float gx = linspace_at(-1.f, 1.f, wc, x), gy = linspace_at(-1.f, 1.f, hc, y);
-    const long long hw = (long long)h * w, ohw = (long long)hc * wc;
-    float v[VIEWS][3];
-    float xs[VIEWS], ys[VIEWS];
-    {
-        ss_f2 px, py;
-        tps_eval_pair(source, source + SS_NV * 2, T, T + 2 * SS_NT, gx, gy, px, py);
-        xs[0] = px.x; xs[1] = px.y; ys[0] = py.x; ys[1] = py.y;
-        if (VIEWS == 3) {
-            tps_eval_pair(source + 2 * SS_NV * 2, source + 2 * SS_NV * 2, T + 4 * SS_NT, T + 4 * SS_NT, gx, gy, px, py);
-            xs[VIEWS - 1] = px.x; ys[VIEWS - 1] = py.x;
+// ---- footprints: which 64 x 8 canvas tiles can a view contribute to? -------------------------------------------------
+// Outside a view's footprint the reference's clamped-index sampler returns no image content, only the rounding residue
+// of (P + Q) - P - Q (|r| <~ 1e-2 grey levels, different on every machine -- DESIGN.md 4); yet those pixels cost the full
+// 63-term spline evaluation, and on the benchmark canvas a third of all (pixel, view) pairs lie there.  With a footprint
+// block the fused render skips them and treats the view's contribution as exactly 0.
+//   lattice[v][i][j] = (xn, yn) = sampling coordinate of view v at canvas pixel (x = 64 j, y = 8 i), i <= ceil(hc / 8),
+//   j <= ceil(wc / 64) (the last row / column lies on or beyond the canvas edge: the spline is defined everywhere);
+//   hull[v] = (xmin, xmax, ymin, ymax): bounding box of the view's 63 control points in normalised canvas coordinates --
+//   the view's mesh on the canvas; its border vertices map exactly onto the image border (TPS interpolation).
+// A tile is OUTSIDE view v when BOTH hold:
+//   (a) it lies outside the mesh hull grown by 8 canvas pixels, and
+//   (b) the exactly evaluated sampling coordinates of its four corners all lie beyond the same image side by more than
+//       8 source pixels (a spline would have to bend by 8 px inside a 64 x 8-pixel tile, 0.4 mesh cells, to come back).
+// (A rigorous interpolation-error bound from sum |T_k| was tried instead of (b)'s fixed margin: the RBF weights of a
+// near-affine warp cancel, the bound does not -- it came out at 100-140 source pixels and kept a third of the skippable
+// tiles.)  tests/test_gpu_parity.py::test_render_footprint_skipping checks on pipeline meshes that every skipped pixel is
+// outside (validity mask of the full evaluation ~ 0) and that nothing else changes.
+__global__ void render_lattice_kernel(const float* __restrict__ source, const float* __restrict__ T,
+                                      float* __restrict__ fp, long long frame_stride, int views, int hc, int wc,
+                                      int ny, int nx) {
+    const int fv = blockIdx.y;                       // frame * views + view
+    const int frame = fv / views, view = fv - frame * views;
+    float* lattice = fp + frame * frame_stride + (long long)view * ny * nx * 2;
+    float* margin = fp + frame * frame_stride + (long long)views * ny * nx * 2 + 4 * view;       // hull (xmin, xmax, ymin, ymax)
+    const float* src = source + (long long)fv * SS_NV * 2;
+    const float* Tx = T + (long long)fv * 2 * SS_NT;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 2) {       // hull of the control points: thread 0 -> x range, thread 1 -> y range
+        float lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < SS_NV; ++k) {
+            const float c = src[2 * k + threadIdx.x];
+            lo = fminf(lo, c);
+            hi = fmaxf(hi, c);
         }
+        margin[2 * threadIdx.x] = lo;
+        margin[2 * threadIdx.x + 1] = hi;
     }
-#pragma unroll
-    for (int k = 0; k < VIEWS; ++k) {
-        const float xn = xs[k], yn = ys[k];
-        const float* in = rv.img[k];
-        if (mode == SS_WARP_NORMAL) {
-            SsTaps t = taps_normal(xn, yn, w, h);
-            long long ia = (long long)t.y0 * w + t.x0, ib = (long long)t.y1 * w + t.x0;
-            long long ic = (long long)t.y0 * w + t.x1, id = (long long)t.y1 * w + t.x1;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float* pl = in + ch * hw;
-                v[k][ch] = blend4(t, pl[ia], pl[ib], pl[ic], pl[id]);
-            }
-        } else {
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) v[k][ch] = sample_fast(in + ch * hw, xn, yn, w, h);
-        }
+    if (idx >= ny * nx) return;
+    const int i = idx / nx, j = idx - i * nx;
+    const float gx = -1.f + 2.f * (float)(64 * j) / (float)(wc - 1), gy = -1.f + 2.f * (float)(8 * i) / (float)(hc - 1);
+    float xn, yn;
+    tps_eval_fast(src, Tx, Tx + SS_NT, gx, gy, xn, yn);
+    lattice[idx * 2] = xn;
+    lattice[idx * 2 + 1] = yn;
+}
+
+// bit v set = view v may contribute to tile (by, bx)
+__device__ __forceinline__ unsigned tile_views(const float* __restrict__ fp, int views, int by, int bx, int ny, int nx,
+                                               int h, int w, int hc, int wc) {
+    const float* hull = fp + (long long)views * ny * nx * 2;
+    // the tile in normalised canvas coordinates, grown by 8 canvas pixels
+    const float sxn = 2.f / (float)(wc - 1), syn = 2.f / (float)(hc - 1);
+    const float tx0 = -1.f + sxn * (float)(64 * bx - 8), tx1 = -1.f + sxn * (float)(64 * bx + 63 + 8);
+    const float ty0 = -1.f + syn * (float)(8 * by - 8), ty1 = -1.f + syn * (float)(8 * by + 7 + 8);
+    const float mx = 1.f + 16.f / (float)w, my = 1.f + 16.f / (float)h;       // 8 source pixels beyond the image
+    unsigned mask = 0u;
+    for (int v = 0; v < views; ++v) {
+        const float* L = fp + ((long long)v * ny * nx + (long long)by * nx + bx) * 2;
+        const float x00 = L[0], y00 = L[1], x01 = L[2], y01 = L[3];
+        const float x10 = L[2 * nx], y10 = L[2 * nx + 1], x11 = L[2 * nx + 2], y11 = L[2 * nx + 3];
+        const bool off_hull = tx1 < hull[4 * v] || tx0 > hull[4 * v + 1] || ty1 < hull[4 * v + 2] || ty0 > hull[4 * v + 3];
+        const bool off_image = (fminf(fminf(x00, x01), fminf(x10, x11)) > mx) || (fmaxf(fmaxf(x00, x01), fmaxf(x10, x11)) < -mx) ||
+                               (fminf(fminf(y00, y01), fminf(y10, y11)) > my) || (fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) < -my);
+        if (!(off_hull && off_image)) mask |= 1u << v;
     }
-    float* o = out + (long long)y * wc + x;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        float f = avg_fuse(v[0][ch], v[1][ch]);
-        if (VIEWS == 3) f = avg_fuse(f, v[2][ch]);
-        o[ch * ohw] = f;
+    return mask;
+}
+
+
+// Tile order of one frame: the fused render takes its tiles from this table, most expensive class first (tiles reached
+// by 3, 2, 1, 0 views cost ~2 : 1 : 0.5 : 0 spline evaluations per pixel).  With ~11 workgroups per CU and mixed costs a
+// row-major order left the CUs 25 % apart (measured: 55 us per frame against 45 for the cost-weighted sum of the tile
+// classes); longest-first hands the expensive tiles out evenly and fills in with the cheap ones.
+//   entry = bx | by << 12 | mask << 24
+__global__ __launch_bounds__(256) void render_order_kernel(float* __restrict__ fp, long long frame_stride, int views, int h,
+                                                           int w, int hc, int wc, int ny, int nx) {
+    __shared__ unsigned cnt[4], base[4];
+    float* f = fp + (long long)blockIdx.x * frame_stride;
+    unsigned* order = reinterpret_cast<unsigned*>(f + (long long)views * ny * nx * 2 + 4 * views);
+    const int nbx = nx - 1, nby = ny - 1, nt = nbx * nby;
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        const unsigned m = tile_views(f, views, t / nbx, t % nbx, ny, nx, h, w, hc, wc);
+        atomicAdd(&cnt[3 - __popc(m)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned a = 0u;
+        for (int c = 0; c < 4; ++c) { base[c] = a; a += cnt[c]; cnt[c] = 0u; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        const int by = t / nbx, bx = t - by * nbx;
+        const unsigned m = tile_views(f, views, by, bx, ny, nx, h, w, hc, wc);
+        const int c = 3 - __popc(m);
+        order[base[c] + atomicAdd(&cnt[c], 1u)] = (unsigned)bx | ((unsigned)by << 12) | (m << 24);
     }
 }
 
-extern "C" int ss_render_average(const float* const* imgs, const float* source, const float* T, float* out, int views,
-                                 int h, int w, int hc, int wc, int mode, void* stream) {
-    if (!imgs || !source || !T || !out || (views != 2 && views != 3) || h <= 1 || w <= 1 || hc <= 1 || wc <= 1 ||
-        (mode != SS_WARP_NORMAL && mode != SS_WARP_FAST))
+extern "C" long long ss_render_footprint_floats(int views, int hc, int wc) {
+    if (views <= 0 || hc <= 1 || wc <= 1) return 0;
+    return (long long)views * ((long long)(ss_cdiv(hc, 8) + 1) * (ss_cdiv(wc, 64) + 1) * 2 + 4) +
+           (long long)ss_cdiv(hc, 8) * ss_cdiv(wc, 64);       // + the tile order table
+}
+
+// footprints of `frames` x `views` splines in one launch: fp [frames][ lattice [views][ny][nx][2] | margin [views][2] ]
+extern "C" int ss_render_footprints(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
+                                    int hc, int wc, void* stream) {
+    if (!source || !T || !fp || frames <= 0 || views <= 0 || views > 3 || h <= 1 || w <= 1 || hc <= 1 || wc <= 1)
         return SS_ERR_ARG;
+    const int ny = ss_cdiv(hc, 8) + 1, nx = ss_cdiv(wc, 64) + 1;
+    // the footprint of frame f (lattice of every view, then the margins) lives at fp + f * ss_render_footprint_floats(...)
+    const long long stride = ss_render_footprint_floats(views, hc, wc);
+    if (ny > 4096 || nx > 4096) return SS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(render_lattice_kernel, dim3(ss_cdiv(ny * nx, 128), frames * views), dim3(128), 0, (hipStream_t)stream,
+                       source, T, fp, stride, views, hc, wc, ny, nx);
+    hipLaunchKernelGGL(render_order_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, fp, stride, views, h, w, hc, wc,
+                       ny, nx);
+    return ss_launch_status();
+}
+
+__device__ __forceinline__ void sample3(const float* __restrict__ in, float xn, float yn, int w, int h, long long hw, int mode,
+                                        float (&v)[3]) {
+    if (mode == SS_WARP_NORMAL) {
+        SsTaps t = taps_normal(xn, yn, w, h);
+        long long ia = (long long)t.y0 * w + t.x0, ib = (long long)t.y1 * w + t.x0;
+        long long ic = (long long)t.y0 * w + t.x1, id = (long long)t.y1 * w + t.x1;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float* pl = in + ch * hw;
+            v[ch] = blend4(t, pl[ia], pl[ib], pl[ic], pl[id]);
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) v[ch] = sample_fast(in + ch * hw, xn, yn, w, h);
+    }
+}
+
+// fp == nullptr: every view is evaluated at every pixel (the reference's arithmetic everywhere, residues included);
+// otherwise tiles are classified by `tile_views` and a view that cannot reach a tile contributes exactly 0 there.
+template <int VIEWS>
+__global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, const float* __restrict__ source,
+                                                             const float* __restrict__ T, const float* __restrict__ fp,
+                                                             float* __restrict__ out, int h, int w, int hc, int wc,
+                                                             int mode) {
+    // workgroup = 64 x 8 canvas pixels; wave w owns rows w and w + 4 of the tile: as two sequential evaluations of the
+    // packed view pair where two or three views reach the tile, as ONE evaluation of two points (packed over the rows)
+    // where a single view does -- all four waves (= all four SIMDs) stay busy either way
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long hw = (long long)h * w, ohw = (long long)hc * wc;
+    const int ny = (hc + 7) / 8 + 1, nx = (wc + 63) / 64 + 1;
+    int tbx, tby;
+    unsigned mask;
+    if (fp) {                                       // tile and its view set from the frame's order table (longest first)
+        const unsigned* order = reinterpret_cast<const unsigned*>(fp + (long long)VIEWS * ny * nx * 2 + 4 * VIEWS);
+        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);
+        tbx = (int)(e & 0xFFFu); tby = (int)((e >> 12) & 0xFFFu); mask = e >> 24;
+    } else {
+        tby = blockIdx.x / (nx - 1); tbx = blockIdx.x - tby * (nx - 1); mask = (1u << VIEWS) - 1u;
+    }
+    const int x = tbx * 64 + lx;
+#ifdef SS_TUNING
+    if ((mode >> 8) == 9) mask = ((tbx + tby) & 1) ? 3u : 1u;          // checkerboard of single / both
+    else if ((mode >> 8) == 10) mask = (tbx < (nx - 1) / 2) ? 1u : 3u;        // left half single, right half both
+    else if (mode >> 8) mask = (unsigned)(mode >> 8) - 1u;          // forced tile class (timing experiments)
+    mode &= 0xFF;
+#endif
+    const int ya = tby * 8 + wv, yb = ya + 4;
+    if (x >= wc || ya >= hc) return;
+    const float gx = linspace_at(-1.f, 1.f, wc, x);
+    if (mask == 0u) {                               // no view reaches this tile: avg_fuse(0, 0) = 0
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            out[ch * ohw + (long long)ya * wc + x] = 0.f;
+            if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = 0.f;
+        }
+        return;
+    }
+    if ((mask & (mask - 1u)) == 0u) {               // ONE view reaches the tile
+        const int k = mask == 1u ? 0 : (mask == 2u ? 1 : 2);
+        const float gya = linspace_at(-1.f, 1.f, hc, ya), gyb = linspace_at(-1.f, 1.f, hc, min(yb, hc - 1));
+        ss_f2 px, py;
+        tps_eval_two_points(source + k * SS_NV * 2, T + k * 2 * SS_NT, gx, gya, gyb, px, py);
+        const float* in = rv.img[k];
+        float va[3], vb[3];
+        sample3(in, px.x, py.x, w, h, hw, mode, va);
+        sample3(in, px.y, py.y, w, h, hw, mode, vb);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            // the chained fusion with zeros in the other views' places, in the reference's order ((1 (+) 2) (+) 3)
+            float fa, fb;
+            if (k == 0) { fa = avg_fuse(va[ch], 0.f); fb = avg_fuse(vb[ch], 0.f); }
+            else if (k == 1) { fa = avg_fuse(0.f, va[ch]); fb = avg_fuse(0.f, vb[ch]); }
+            else { fa = avg_fuse(avg_fuse(0.f, 0.f), va[ch]); fb = avg_fuse(avg_fuse(0.f, 0.f), vb[ch]); }
+            if (VIEWS == 3 && k < 2) { fa = avg_fuse(fa, 0.f); fb = avg_fuse(fb, 0.f); }
+            out[ch * ohw + (long long)ya * wc + x] = fa;
+            if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = fb;
+        }
+        return;
+    }
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = rr ? yb : ya;
+        if (y >= hc) break;
+        const float gy = linspace_at(-1.f, 1.f, hc, y);
+        float v[VIEWS][3];
+        float xs[VIEWS], ys[VIEWS];
+        if (VIEWS == 2 || mask == 3u) {
+            ss_f2 px, py;
+            tps_eval_pair(source, source + SS_NV * 2, T, T + 2 * SS_NT, gx, gy, px, py);
+            xs[0] = px.x; xs[1] = px.y; ys[0] = py.x; ys[1] = py.y;
+        } else if (VIEWS == 3 && mask == 5u) {
+            ss_f2 px, py;
+            tps_eval_pair(source, source + 2 * SS_NV * 2, T, T + 4 * SS_NT, gx, gy, px, py);
+            xs[0] = px.x; xs[VIEWS - 1] = px.y; ys[0] = py.x; ys[VIEWS - 1] = py.y;
+        } else if (VIEWS == 3 && mask == 6u) {
+            ss_f2 px, py;
+            tps_eval_pair(source + SS_NV * 2, source + 2 * SS_NV * 2, T + 2 * SS_NT, T + 4 * SS_NT, gx, gy, px, py);
+            xs[1] = px.x; xs[VIEWS - 1] = px.y; ys[1] = py.x; ys[VIEWS - 1] = py.y;
+        } else if (VIEWS == 3) {                    // all three
+            ss_f2 px, py;
+            tps_eval_pair(source, source + SS_NV * 2, T, T + 2 * SS_NT, gx, gy, px, py);
+            xs[0] = px.x; xs[1] = px.y; ys[0] = py.x; ys[1] = py.y;
+            tps_eval_pair(source + 2 * SS_NV * 2, source + 2 * SS_NV * 2, T + 4 * SS_NT, T + 4 * SS_NT, gx, gy, px, py);
+            xs[VIEWS - 1] = px.x; ys[VIEWS - 1] = py.x;
+        }
+#pragma unroll
+        for (int k = 0; k < VIEWS; ++k) {
+            if (mask & (1u << k)) sample3(rv.img[k], xs[k], ys[k], w, h, hw, mode, v[k]);
+            else { v[k][0] = 0.f; v[k][1] = 0.f; v[k][2] = 0.f; }
+        }
+        float* o = out + (long long)y * wc + x;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float f = avg_fuse(v[0][ch], v[1][ch]);
+            if (VIEWS == 3) f = avg_fuse(f, v[2][ch]);
+            o[ch * ohw] = f;
+        }
+    }
+}
+
+extern "C" int ss_render_average(const float* const* imgs, const float* source, const float* T, const float* footprint,
+                                 float* out, int views, int h, int w, int hc, int wc, int mode, void* stream) {
+    if (!imgs || !source || !T || !out || (views != 2 && views != 3) || h <= 1 || w <= 1 || hc <= 1 || wc <= 1 ||
+        ((mode & 0xFF) != SS_WARP_NORMAL && (mode & 0xFF) != SS_WARP_FAST))
+        return SS_ERR_ARG;
+#ifndef SS_TUNING
+    if (mode >> 8) return SS_ERR_ARG;
+#endif
     RenderViews rv;
     for (int i = 0; i < 3; ++i) rv.img[i] = i < views ? imgs[i] : nullptr;
     for (int i = 0; i < views; ++i)
         if (!rv.img[i]) return SS_ERR_ARG;
-    dim3 g(ss_cdiv(wc, 64), ss_cdiv(hc, 4), 1);
+    dim3 g(ss_cdiv(wc, 64) * ss_cdiv(hc, 8), 1, 1);
     hipStream_t st = (hipStream_t)stream;
     if (views == 2)
-        hipLaunchKernelGGL((render_average_kernel<2>), g, dim3(256), 0, st, rv, source, T, out, h, w, hc, wc, mode);
+        hipLaunchKernelGGL((render_average_kernel<2>), g, dim3(256), 0, st, rv, source, T, footprint, out, h, w, hc, wc, mode);
     else
-        hipLaunchKernelGGL((render_average_kernel<3>), g, dim3(256), 0, st, rv, source, T, out, h, w, hc, wc, mode);
+        hipLaunchKernelGGL((render_average_kernel<3>), g, dim3(256), 0, st, rv, source, T, footprint, out, h, w, hc, wc, mode);
     return ss_launch_status();
 }
 

@@ -334,16 +334,28 @@ def tps_warp(U, source, T, hc, wc, mode='NORMAL', with_mask=False):
     return out
 
 
-def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None):
-    """imgs: list of 2|3 device tensors [1,3,h,w] / [3,h,w]; source [V,63,2]; T [V,2,66] -> [3,hc,wc]."""
+def render_footprints(source, T, h, w, hc, wc):
+    """source [n,V,63,2], T [n,V,2,66], images h x w -> footprints [n, ss_render_footprint_floats] of every (frame, view) on
+    the hc x wc canvas (tile-corner sampling coordinates, mesh hulls, tile order), two small launches for the whole clip."""
+    n, v = source.shape[0], source.shape[1]
+    per = int(H.lib().ss_render_footprint_floats(v, hc, wc))
+    fp = torch.empty((n, per), device=source.device, dtype=torch.float32)
+    H.call('ss_render_footprints', H.dptr(_f(source)), H.dptr(_f(T)), H.dptr(fp), n, v, h, w, hc, wc, H.stream())
+    return fp
+
+
+def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None, footprint=None):
+    """imgs: list of 2|3 device tensors [1,3,h,w] / [3,h,w]; source [V,63,2]; T [V,2,66] -> [3,hc,wc].
+    footprint: this frame's row of `render_footprints` (views that cannot reach a tile are skipped there and count as
+    exactly 0), or None (every view evaluated everywhere)."""
     v = len(imgs)
     imgs = [_f(i) for i in imgs]
     h, w = imgs[0].shape[-2:]
     arr = H.ptr_array(imgs)
     if out is None:
         out = torch.empty((3, hc, wc), device=imgs[0].device, dtype=torch.float32)
-    H.call('ss_render_average', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(out), v, h, w, hc, wc, MODES[mode],
-           H.stream())
+    H.call('ss_render_average', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(footprint, True), H.dptr(out), v, h, w, hc, wc,
+           MODES[mode], H.stream())
     return out
 
 

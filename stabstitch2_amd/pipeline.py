@@ -262,6 +262,12 @@ def norm_rigid_mesh(img_h, img_w, device):
     return t
 
 
+# AVERAGE render: skip a view's 63-term spline on canvas tiles it provably cannot reach (ops.render_footprints) and take
+# its contribution there as exactly 0 instead of the rounding residue of the reference's clamped sampler.
+# SS_SKIP_OUTSIDE=0: evaluate every view at every pixel.
+SKIP_OUTSIDE = os.environ.get('SS_SKIP_OUTSIDE', '1') == '1'
+
+
 # ------------------------------------------------------------------ render
 @torch.no_grad()
 def render_plan(meshes, img_h, img_w, prescaled=False):
@@ -294,10 +300,11 @@ def render_frames(img_lists, meshes, warp_mode='NORMAL', fusion_mode='AVERAGE', 
     hc, wc, src, T = render_plan(meshes, img_h, img_w, prescaled)
     if out is None:
         out = torch.empty((n, 3, hc, wc), device=dev, dtype=torch.float32)
+    fp = ops.render_footprints(src, T, img_h, img_w, hc, wc) if (SKIP_OUTSIDE and fusion_mode == 'AVERAGE') else None
     for i in range(n):
         imgs = [img_lists[k][i].to(dev, non_blocking=True) for k in range(v)]
         if fusion_mode == 'AVERAGE':
-            ops.render_average(imgs, src[i], T[i], hc, wc, warp_mode, out=out[i])
+            ops.render_average(imgs, src[i], T[i], hc, wc, warp_mode, out=out[i], footprint=None if fp is None else fp[i])
         else:
             w = ops.tps_warp_views(imgs, src[i], T[i], hc, wc, warp_mode)            # [V,4,Hc,Wc]
             if v == 2:

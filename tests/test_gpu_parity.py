@@ -1067,3 +1067,71 @@ def test_conv_stem_row_packed(dev, n, h, w, cout):
     b2 = torch.stack((bias, bias.flip(0)), 0).contiguous().to(dev)
     g = ops.conv_stem(buf, w2, b2, relu=True)
     assert torch.equal(g[0], out) and torch.equal(g[1], out.flip(-1))
+
+
+@pytest.mark.parametrize('views', [2, 3])
+def test_render_footprint_skipping(dev, hip_nets, views):
+    """AVERAGE render with footprints (a view's spline is skipped on tiles it provably cannot reach, its contribution
+    taken as exactly 0) against the full evaluation: bit-identical wherever no view was skipped, within the rounding
+    residue of the clamped sampler (<= 5e-3 grey levels) wherever some view is valid, and a skipped view is really
+    outside: the full evaluation's validity mask is ~0 on every pixel of a skipped tile."""
+    from stabstitch2_amd import ops, pipeline
+    n, h, w = 7, 720, 1280
+    hr, lr = synth.make_clip_device(n, h, w, seed=3, views=views, device=dev)
+    if views == 2:
+        acc = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+        meshes, pres = [acc['smooth_mesh1'], acc['smooth_mesh2']], False
+    else:
+        a12 = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+        a23 = pipeline.estimate_meshes(hip_nets, lr[1], lr[2])
+        meshes = list(pipeline.three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'],
+                                                  a23['smooth_mesh2'], h, w))
+        pres = True
+    hc, wc, src, T = pipeline.render_plan(meshes, h, w, pres)
+    fp = ops.render_footprints(src, T, h, w, hc, wc)
+    ny, nx = (hc + 7) // 8 + 1, (wc + 63) // 64 + 1
+    assert fp.shape == (n, views * ny * nx * 2 + views * 4 + (ny - 1) * (nx - 1))
+    assert bool(torch.isfinite(fp[:, :views * ny * nx * 2 + views * 4]).all())
+    skipped_frac = []
+    for i in (0, n - 1):
+        imgs = [hr[k][i] for k in range(views)]
+        full = ops.render_average(imgs, src[i], T[i], hc, wc, 'NORMAL')
+        skip = ops.render_average(imgs, src[i], T[i], hc, wc, 'NORMAL', footprint=fp[i])
+        wm = ops.tps_warp(torch.stack(imgs, 0), src[i], T[i], hc, wc, 'NORMAL', with_mask=True)[:, 3]      # [V,hc,wc]
+        # re-derive the tile classification on the host from the footprint block
+        lat = fp[i, :views * ny * nx * 2].view(views, ny, nx, 2)
+        hull = fp[i, views * ny * nx * 2:views * ny * nx * 2 + 4 * views].view(views, 4)
+        need = torch.ones((views, ny - 1, nx - 1), dtype=torch.bool, device=dev)
+        bxs = torch.arange(nx - 1, device=dev, dtype=torch.float32)
+        bys = torch.arange(ny - 1, device=dev, dtype=torch.float32)
+        tx0 = -1 + 2.0 / (wc - 1) * (64 * bxs - 8); tx1 = -1 + 2.0 / (wc - 1) * (64 * bxs + 71)
+        ty0 = -1 + 2.0 / (hc - 1) * (8 * bys - 8); ty1 = -1 + 2.0 / (hc - 1) * (8 * bys + 15)
+        for v in range(views):
+            off_hull = ((tx1 < hull[v, 0]) | (tx0 > hull[v, 1]))[None, :] | ((ty1 < hull[v, 2]) | (ty0 > hull[v, 3]))[:, None]
+            off_img = torch.zeros_like(off_hull)
+            for c, m in ((0, 1.0 + 16.0 / w), (1, 1.0 + 16.0 / h)):
+                q = torch.stack((lat[v, :-1, :-1, c], lat[v, :-1, 1:, c], lat[v, 1:, :-1, c], lat[v, 1:, 1:, c]), 0)
+                off_img |= (q.min(0).values > m) | (q.max(0).values < -m)
+            need[v] = ~(off_hull & off_img)
+        tile = need.repeat_interleave(8, 1).repeat_interleave(64, 2)[:, :hc, :wc]                           # per pixel
+        skipped_frac.append(1.0 - float(tile.float().mean()))
+        # (1) a skipped view is outside: its validity mask is ~0 on all those pixels
+        assert float(wm[~tile].abs().max()) < 1e-2, float(wm[~tile].abs().max())
+        # (2) nothing skipped -> bit identical
+        allv = tile.all(0)
+        assert torch.equal(skip[:, allv], full[:, allv])
+        # (3) some view valid -> equal up to the residue the skipped views would have contributed
+        # (three views: where only view 3 is valid the reference's chained AVERAGE is chaotic -- avg(residue, residue) feeds
+        #  the second fusion, DESIGN.md 4 -- so the sharp comparison covers the pixels views 1 or 2 reach, the rest the median)
+        anyvalid = (wm[:2] > 0.5).any(0)
+        d = (skip - full).abs()[:, anyvalid]
+        assert float(d.max()) < 5e-2, float(d.max())
+        rest = (wm > 0.5).any(0) & ~anyvalid
+        if bool(rest.any()):
+            assert float((skip - full).abs()[:, rest].median()) < 2e-2
+        # (4) no view reaches the tile -> exactly 0
+        none = ~tile.any(0)
+        assert float(skip[:, none].abs().max()) == 0.0 if bool(none.any()) else True
+    assert min(skipped_frac) > 0.25, skipped_frac             # a quarter of the (pixel, view) pairs at least, on this geometry
+    if os.environ.get('SS_VERBOSE'):
+        print('  skipped (pixel, view) fraction: %s' % skipped_frac)
