@@ -68,7 +68,10 @@ class OnlineStitcher:
                          ops.mesh_normalize(mesh2, self.bbox, self.h, self.w)), 0)
         T = ops.tps_solve(src, self.nrigid.expand(2, -1, -1).contiguous())
         if self.fusion_mode == 'AVERAGE':
-            return ops.render_average([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode)
+            fp = None
+            if pipeline.SKIP_OUTSIDE:        # same footprint skipping as the offline render (pipeline.render_frames)
+                fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc)[0]
+            return ops.render_average([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode, footprint=fp)
         w = ops.tps_warp_views([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode)
         return ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
 
