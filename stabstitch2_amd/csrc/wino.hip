@@ -31,6 +31,7 @@
 // Two workgroups per CU (64 KB LDS, <= 256 registers); the waves of a workgroup are decoupled inside the K loop (one
 // barrier per chunk), so one wave's transform runs under the other waves' MFMAs.
 #include "common.h"
+#include <type_traits>
 
 typedef float w_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned w_u32x4 __attribute__((ext_vector_type(4)));
@@ -47,6 +48,7 @@ struct WinoP {
     SsDiv32 divBx, divBy;    // m-block index -> (image, block row, block column)
     unsigned nbx, nby;       // tile blocks per image row / column
     unsigned ncb;            // 64-channel output blocks
+    unsigned nmb, njobs;     // pair kernel: tile blocks in total; (pair of tile blocks, cout block) jobs of one group
     SsDiv32 divNcb;
     long long in_gs, u_gs, out_gs;      // element strides between groups
     unsigned in_bytes, out_bytes, u_bytes;
@@ -343,6 +345,394 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
 }
 
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENT (tuning build only, ss_debug_set(7, 2); tools/cmp_wino_variants.py, tools/diag_wino_pair.py;
+// profiles/r02_wino_pair_experiment.txt): bit-identical to the kernel above, its K loop runs at the matrix pipe's pace
+// (9.0k cycles per 128-MFMA chunk vs 9.2k for MFMAs alone), but with one wave per SIMD nothing hides the epilogue and
+// the restart of the stream (28k cycles per job against 36k of MFMAs on layer1), and hipcc spills the job state around
+// them: 391 / 321 / 268 us on layer1 / 2 / 3 where the kernel above takes 342 / 296 / 249 us.  Not dispatched.
+#ifdef SS_TUNING
+// PAIR kernel: the same arithmetic, scheduled for ONE workgroup per CU (512 registers per lane: 256 accumulator
+// registers + 256 for everything else).  With two workgroups per CU (kernel above) the matrix pipe idles whenever both
+// resident waves of a SIMD are outside their MFMA runs at the same time (measured: 64-66 % MFMA busy); here ONE wave
+// per SIMD keeps the pipe fed by interleaving everything else into its own MFMA stream:
+//   job = TWO consecutive tile blocks (2 x 32 tiles) x 64 output channels: every filter register feeds two MFMAs
+//         (half the filter traffic per flop of the kernel above), 4 x 2 x 2 accumulator tiles = 256 registers;
+//   the K loop is one stream of 8 blocks of 16 MFMAs per chunk (tile block 0: positions 0..3, tile block 1: positions
+//   0..3); while tile block 0 multiplies, the wave transforms tile block 1 of the same chunk, and while tile block 1
+//   multiplies, tile block 0 of the NEXT chunk -- a quarter of a transform (2 channels: 8 LDS reads, ~20 VALU) per
+//   block, the reads issued one block before their use.  Raw patches go global -> registers two chunks ahead and
+//   registers -> LDS one chunk ahead (one barrier per chunk, in the middle of the stream); a position's filters are
+//   reloaded for the next chunk right after their last MFMA of this one (3 blocks = 3072 MFMA cycles before the next use);
+//   PERSISTENT workgroups: the grid is one workgroup per CU and the stream simply continues into the next job -- the
+//   last chunk of a job prefetches / transforms chunk 0 of the job after it -- so only the T stage + combine of the
+//   epilogue (own LDS region, it never aliases the raw buffers) interrupt the MFMA stream.
+template <int TBH, int TBW, bool RES>
+__global__ __launch_bounds__(256, 1) void conv_wino_pair_kernel(WinoP p) {
+    static_assert(TBH * TBW == 32, "32 tiles per tile block");
+    constexpr int BN = 64;
+    constexpr int RH = 2 * TBH + 2, RW = 2 * TBW + 2;
+    constexpr int RPIX = RH * RW;
+    constexpr int RWP = TBW == 4 ? 12 : 24;
+    constexpr int PLANE = RH * RWP + 4;
+    constexpr int NE = (RPIX * 4 + 255) / 256;
+    constexpr int RAWF = 16 * PLANE;                        // one raw buffer: 16 channel planes of one tile block
+    constexpr int STAGEF = 4 * 2 * 32 * BN;                 // T stage of one tile block (64 KB)
+    // raw[parity][tile block] during the K loop + the T stage: 120..127 KB of the CU's 160 KB
+    // (the stage first: all its addresses within the 64 KB reach of an LDS instruction's offset field from one base)
+    __shared__ __attribute__((aligned(16))) float smem_all[STAGEF + 4 * RAWF];
+    float* const stage = smem_all;
+    float* const smem = smem_all + STAGEF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // job sequence of this workgroup: every XCD sweeps one contiguous run of jobs (all cout blocks of a pair of tile
+    // blocks back to back), its workgroups together
+    unsigned job, job_end, job_step;
+    {
+        const unsigned nwg = gridDim.x, b = blockIdx.x;
+        if (nwg >= 16) {
+            const unsigned q = p.njobs / 8, r = p.njobs % 8, xcd = b % 8, slot = b / 8;
+            const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+            job_step = nwg / 8 + (xcd < nwg % 8 ? 1u : 0u);
+            job = start + slot;
+            job_end = start + q + (xcd < r ? 1u : 0u);
+        } else {
+            job = b; job_end = p.njobs; job_step = nwg;
+        }
+    }
+    if (job >= job_end) return;
+    const int grp = blockIdx.z;
+    const __amdgpu_buffer_rsrc_t rin = w_rsrc(p.in + (long long)grp * p.in_gs, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t ru = w_rsrc(p.U + (long long)grp * p.u_gs, p.u_bytes);
+    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    const __amdgpu_buffer_rsrc_t rout = w_rsrc(out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = w_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
+
+    // invalid raw items: an offset that stays outside the buffer when the chunk offset (< 64 KB) is added -- the
+    // descriptor's bounds check returns zeros (host: in_bytes <= RAW_INVALID)
+    constexpr unsigned RAW_INVALID = 0xFFFF0000u;
+    struct Job {
+        unsigned cbk, u_wave;
+        unsigned img[2];
+        int oy0[2], ox0[2];
+        unsigned rbase[2][NE];             // byte offset of (pixel, channel quad), or RAW_INVALID
+    };
+    int rlds[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int item = tid + 256 * e;
+        const int pix = item >> 2, q = item & 3;
+        const int ry = pix / RW, rx = pix - ry * RW;
+        // items past the patch (RPIX * 4 is not a multiple of 256) land in the 4-dword pad behind their planes: no branch
+        rlds[e] = (4 * q) * PLANE + (item < RPIX * 4 ? ry * RWP + rx : RH * RWP);
+    }
+    auto setup = [&](Job& j, unsigned lin) {
+        const unsigned pm = ss_div32(lin, p.divNcb);
+        j.cbk = lin - pm * p.ncb;
+        j.u_wave = (j.cbk * 2) * (unsigned)p.nchunk * 32768u + (unsigned)wave * 8192u;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const unsigned mb = 2 * pm + tb;
+            const unsigned t1 = ss_div32(mb, p.divBx);
+            const int bx = (int)(mb - t1 * p.nbx);
+            const unsigned img = ss_div32(t1, p.divBy);
+            const int by = (int)(t1 - img * p.nby);
+            const bool valid = mb < p.nmb;                  // an odd number of tile blocks: the last job's second one is empty
+            j.img[tb] = valid ? img : 0u;
+            j.oy0[tb] = valid ? by * (2 * TBH) : (1 << 28);
+            j.ox0[tb] = bx * (2 * TBW);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int item = tid + 256 * e;
+                const int pix = item >> 2, q = item & 3;
+                const int ry = pix / RW, rx = pix - ry * RW;
+                const int iy = j.oy0[tb] - 1 + ry, ix = j.ox0[tb] - 1 + rx;
+                const bool ok = item < RPIX * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                j.rbase[tb][e] = ok ? ((((unsigned)j.img[tb] * p.H + iy) * p.W + ix) * (unsigned)p.C + 4u * q) * 4u : RAW_INVALID;
+            }
+        }
+    };
+    Job cur, nxt;
+    setup(cur, job);
+    const int myq = tid & 3;
+
+    const int kh = lane >> 5;
+    const int m_tile = lane & 31;
+    const int m_ty = m_tile / TBW, m_tx = m_tile - m_ty * TBW;
+    const int t_src = (8 * kh) * PLANE + (2 * m_ty) * RWP + 2 * m_tx;
+    const int t_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int t_rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const w_f32x2 t_sg = wave == 1 ? (w_f32x2){1.f, 1.f} : (w_f32x2){-1.f, -1.f};
+    const unsigned u_lane = (unsigned)lane * 16u;
+    const unsigned u_blk = (unsigned)p.nchunk * 32768u;
+
+    w_f32x16 acc[4][2][2];       // [position of the wave's row][tile block][32-channel block]
+    float av[2][4][8];           // A operands: [tile block][position][channel 8 kh + s]
+    w_f32x4 U[4][2][2];          // filters of the chunk: [position][32-channel block][half] (4 MFMA steps each)
+    w_f32x4 rr[2][NE];           // raw patch in flight
+    w_f32x2 tq[2][4];            // LDS reads in flight: 2 channels x (row a cols 01, row a cols 23, row b cols 01, row b cols 23)
+
+    auto raw_issue = [&](int cc, bool from_next) {
+        const unsigned coff = (unsigned)cc * 64u;
+        const unsigned cinv = ((cc * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const unsigned off = ((from_next ? nxt.rbase[tb][e] : cur.rbase[tb][e]) + coff) | cinv;
+                rr[tb][e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
+            }
+    };
+    auto raw_store = [&](float* dst) {                       // dst: the parity's two tile-block buffers
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[tb * RAWF + rlds[e] + k * PLANE] = rr[tb][e][k];
+    };
+    auto u_issue = [&](int j, unsigned u_wave, int cc) {
+        if (W_ABLATE(1)) return;
+        const unsigned base = u_wave + (unsigned)cc * 32768u + (unsigned)j * 2048u;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int so = (int)__builtin_amdgcn_readfirstlane(base + (unsigned)cb * u_blk);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                U[j][cb][h] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * h, so, 0));
+        }
+    };
+    // a quarter of a tile block's input transform: channels 2 pair, 2 pair + 1 of this lane's 8
+    auto rd = [&](const float* buf, int pair) {
+        if (W_ABLATE(8)) return;
+        const float* src = buf + t_src + (2 * pair) * PLANE;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float* pa = src + ch * PLANE + t_ra * RWP;
+            const float* pb = src + ch * PLANE + t_rb * RWP;
+            tq[ch][0] = *reinterpret_cast<const w_f32x2*>(pa);
+            tq[ch][1] = *reinterpret_cast<const w_f32x2*>(pa + 2);
+            tq[ch][2] = *reinterpret_cast<const w_f32x2*>(pb);
+            tq[ch][3] = *reinterpret_cast<const w_f32x2*>(pb + 2);
+        }
+    };
+    auto xf = [&](int tb, int pair, bool pin = false) {
+        if (W_ABLATE(8)) return;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int c = 2 * pair + ch;
+            const w_f32x2 r0 = __builtin_elementwise_fma(tq[ch][2], t_sg, tq[ch][0]);
+            const w_f32x2 r1 = __builtin_elementwise_fma(tq[ch][3], t_sg, tq[ch][1]);
+            const w_f32x2 d = r0 - r1;
+            av[tb][0][c] = d[0];
+            av[tb][1][c] = r0[1] + r1[0];
+            av[tb][2][c] = r1[0] - r0[1];
+            av[tb][3][c] = d[1];
+            // pin the results here: in the last chunk of a job they are used only after the epilogue, and the compiler
+            // otherwise SINKS the transform there -- spilling the 64 LDS-read registers it needs to scratch on the way
+            if (pin) asm volatile("" : "+v"(av[tb][0][c]), "+v"(av[tb][1][c]), "+v"(av[tb][2][c]), "+v"(av[tb][3][c]));
+        }
+    };
+    const w_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // 16 MFMAs: position j of tile block tb, both channel blocks alternating (independent accumulators back to back).
+    // `first`: chunk 0 of a job starts its accumulators from zero (no 256-register clear per job).
+    auto mma = [&](int tb, int j, bool first) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                acc[j][tb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tb][j][s], U[j][cb][s >> 2][s & 3],
+                                                                     (first && s == 0) ? zero16 : acc[j][tb][cb], 0, 0, 0);
+    };
+    // interleave pattern of one block of 16 MFMAs: the block's LDS reads (4 ds_read2) behind the first MFMAs, then per
+    // MFMA up to `DSW` LDS writes / `VM` buffer loads, and VALU work everywhere
+#define W_SGB_BLOCK(DSW, VM)                                                            \
+    do {                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                          \
+        }                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+            if (DSW) __builtin_amdgcn_sched_group_barrier(0x200, DSW, 0);               \
+            if (VM) __builtin_amdgcn_sched_group_barrier(0x020, VM, 0);                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                          \
+        }                                                                               \
+    } while (0)
+
+    // LDS-only barrier: __syncthreads() also fences global memory (s_waitcnt vmcnt(0)): every prefetch in flight --
+    // and, after an epilogue, every store -- would be waited for at every barrier
+    auto lds_barrier = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+#ifdef SS_TUNING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#define P_STAMP(i) do { if (p.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define P_STAMP(i) do { } while (0)
+#endif
+
+    // epilogue addressing.  thread -> (pixel, channel quad): pixel 16 e + (tid >> 4) -> tile 4 e + wave (wave-uniform:
+    // scalar address arithmetic), row / column inside the 2x2 tile from tid bits 5 / 4, channels 4 (tid & 15) ..
+    constexpr int NI = 8;
+    const int cq = tid & 15;
+    const int pa = (tid >> 5) & 1, pb = (tid >> 4) & 1;
+    const unsigned thr_off = ((unsigned)(pa * p.W + pb) * (unsigned)p.out_cs + 4u * cq) * 4u;
+    const float* srd = stage + ((pa * 2 + pb) * 32 + wave) * BN + 4 * cq;              // + 4 e tiles
+    const float sg = pa ? -1.f : 1.f;                       // row 0 of the tile: T0 + T1 + T2, row 1: T1 - T2 - T3
+    const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+
+    int par = 0;
+    raw_issue(0, false);                                    // chunk 0 of the first job
+    for (;;) {
+        const bool has_next = job + job_step < job_end;
+        setup(nxt, has_next ? job + job_step : job);      // the last job names itself: prefetches requested, never used
+        // ---- job start: chunk 0 (requested before the previous epilogue) -> LDS, transformed for tile block 0; filters
+        // of chunk 0 and the raw patch of chunk 1 requested.  ~2k cycles without MFMAs per job.
+        raw_store(smem + (par * 2) * RAWF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u_issue(j, cur.u_wave, 0);
+        lds_barrier();
+        raw_issue(1, false);
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) { rd(smem + (par * 2) * RAWF, pr); xf(0, pr); }
+        rd(smem + (par * 2 + 1) * RAWF, 0);
+        P_STAMP(0);
+
+        unsigned goff[2][NI];
+        w_u32x4 rv[2][NI];
+        auto res_issue = [&](int tb) {
+#pragma unroll
+            for (int e = 0; e < NI; ++e) {
+                const int tile = 4 * e + wave;
+                const int ty = tile / TBW, tx = tile - ty * TBW;
+                const int oy = cur.oy0[tb] + 2 * ty, ox = cur.ox0[tb] + 2 * tx;        // scalars
+                const unsigned sbase = ((((unsigned)cur.img[tb] * p.H + oy) * p.W + ox) * (unsigned)p.out_cs + cur.cbk * BN) * 4u;
+                const bool ok = oy + pa < p.H && ox + pb < p.W;
+                goff[tb][e] = ok ? sbase + thr_off : 0xFFFFFFFFu;
+            }
+            if (RES) {
+#pragma unroll
+                for (int e = 0; e < NI; ++e) rv[tb][e] = __builtin_amdgcn_raw_buffer_load_b128(rres, goff[tb][e], 0, 0);
+            }
+        };
+        // one chunk = 8 blocks of 16 MFMAs.  kind: 0 first chunk of the job (accumulators start from zero), 1 middle,
+        // 2 last: nothing of the next chunk to stage or transform (the next job restarts the stream after the epilogue:
+        // carrying the transformed operands, LDS reads and filters of its chunk 0 across the epilogue was measured -- 60+
+        // registers too many, scratch traffic in the epilogue); the residual is requested instead.
+        auto chunk = [&](int c, auto kind_c) __attribute__((always_inline)) {
+            constexpr int kind = decltype(kind_c)::value;
+            constexpr bool first = kind == 0, last = kind == 2;
+            float* bc = smem + (par * 2) * RAWF;           // chunk c:     [tile block] raw buffers
+            float* bn = smem + ((par ^ 1) * 2) * RAWF;     // chunk c + 1
+            // tile block 0 multiplies, tile block 1 of this chunk is transformed
+            xf(1, 0); rd(bc + RAWF, 1); mma(0, 0, first); W_SGB_BLOCK(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(1, 1); rd(bc + RAWF, 2); mma(0, 1, first); W_SGB_BLOCK(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // chunk c + 1: registers -> LDS under the MFMAs (its buffers were last read one chunk ago, before the previous barrier)
+            xf(1, 2); rd(bc + RAWF, 3);
+            if (!last && !W_ABLATE(2)) raw_store(bn);
+            mma(0, 2, first); W_SGB_BLOCK(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last && !W_ABLATE(16)) lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // chunk c + 2 requested (the next job's chunk 0 from the last but one chunk: it waits in registers)
+            if (!last && !W_ABLATE(2)) {
+                const bool wrap = c + 2 >= p.nchunk;
+                raw_issue(wrap ? 0 : c + 2, wrap);
+            }
+            xf(1, 3); if (!last) rd(bn, 0); mma(0, 3, first); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // tile block 1 multiplies, tile block 0 of the next chunk is transformed; a position's filters are reloaded
+            // for the next chunk behind their last MFMA of this one
+            if (!last) { xf(0, 0); rd(bn, 1); }
+            mma(1, 0, first); if (!last) u_issue(0, cur.u_wave, c + 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (last) res_issue(0);                         // into the registers of the (dead) tile block 0 operands
+            if (!last) { xf(0, 1); rd(bn, 2); }
+            mma(1, 1, first); if (!last) u_issue(1, cur.u_wave, c + 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) { xf(0, 2); rd(bn, 3); }
+            mma(1, 2, first); if (!last) u_issue(2, cur.u_wave, c + 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) { xf(0, 3); rd(bn + RAWF, 0); }
+            mma(1, 3, first); if (!last) u_issue(3, cur.u_wave, c + 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            par ^= 1;
+        };
+        chunk(0, std::integral_constant<int, 0>());
+        P_STAMP(1);
+        for (int c = 1; c + 1 < p.nchunk; ++c) chunk(c, std::integral_constant<int, 1>());
+        chunk(p.nchunk - 1, std::integral_constant<int, 2>());
+        P_STAMP(2);
+
+        // ------------------------------------------------------------ epilogue (as the kernel above), one tile block at a time
+        w_f32x4 bias4 = (w_f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *reinterpret_cast<const w_f32x4*>(p.bias + (long long)grp * p.Co + cur.cbk * BN + 4 * cq);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            if (tb == 1) lds_barrier();                     // the combine of tile block 0 is done with the stage
+            {
+                float* srow = stage + (wave * 2) * 32 * BN + (lane & 31);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        const float m0 = acc[0][tb][blk][r], m1 = acc[1][tb][blk][r], m2 = acc[2][tb][blk][r], m3 = acc[3][tb][blk][r];
+                        srow[tile * BN + blk * 32] = (m0 + m1) + m2;
+                        srow[(32 + tile) * BN + blk * 32] = (m1 - m2) - m3;
+                        // four accumulator rows at a time: left alone the scheduler reads all 128 accumulators of the
+                        // tile block into registers first (scratch)
+                        ;
+                    }
+            }
+            // residual of both tile blocks requested here: the accumulators of this tile block are dead, their registers
+            // take the loads (requested inside the last chunk they were spilled to scratch one by one)
+            if (tb == 0) res_issue(1);
+            lds_barrier();
+            P_STAMP(3);
+#pragma unroll
+            for (int e = 0; e < NI; ++e) {
+                const float* s0 = srd + 4 * e * BN;
+                const w_f32x4 x = *reinterpret_cast<const w_f32x4*>(s0);
+                const w_f32x4 y = *reinterpret_cast<const w_f32x4*>(s0 + 2 * 32 * BN);
+                const w_f32x4 z = *reinterpret_cast<const w_f32x4*>(s0 + 4 * 32 * BN);
+                w_f32x4 v = (x + sg * y) + sg * z;
+                v = v + bias4;
+                if (RES) v = v + __builtin_bit_cast(w_f32x4, rv[tb][e]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], relu_lo);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w_u32x4, v), rout, goff[tb][e], 0, 0);
+                ;
+            }
+            P_STAMP(4);
+        }
+        if (!has_next) break;
+        job += job_step;
+        cur = nxt;
+    }
+#undef W_SGB_BLOCK
+#undef P_STAMP
+#ifdef SS_TUNING
+    if (p.dbg && tid == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 10;
+        for (int i = 0; i < 6; ++i) d[i] = tacc[i];
+        d[6] = tstart;
+        d[7] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+}
+#endif  // SS_TUNING
+
+// ------------------------------------------------------------------------------------------------
 // Filter transform + packing: U = G g G^T in fp64, rounded once to fp32, stored in the B-operand register layout of the
 // kernel above (v_mfma_f32_32x32x2_f32: B[k = lane >> 5][j = lane & 31]):
 //   U[cout/32][chunk][pos][half][lane][e] = (G g G^T)[pos] of (cout = 32 cb + (lane & 31), cin = 16 chunk + 8 (lane >> 5) + 4 half + e),
@@ -393,6 +783,7 @@ extern "C" int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, 
 #ifdef SS_TUNING
 int g_wino_ablate = 0;                   // ss_debug_set key 6
 int g_wino_nb1_max_cin = 0;              // ss_debug_set key 5
+int g_wino_variant = 0;                  // ss_debug_set key 7: 2 = pair kernel (experiment)
 #else
 constexpr int g_wino_nb1_max_cin = 0;
 #endif
@@ -451,8 +842,26 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
 #endif
     const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
     if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
-    dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
+#ifdef SS_TUNING
+    // pair kernel (one persistent workgroup per CU, two tile blocks per job): needs >= 2 chunks for its prefetch distance
+    if (g_wino_variant == 2 && nb == 2 && p.nchunk >= 2 && p.nchunk <= 512 && in_elems * 4 <= 0xFFFF0000ll) {
+        p.nmb = (unsigned)((long long)n * p.nbx * p.nby);
+        p.njobs = (unsigned)(((long long)p.nmb + 1) / 2 * p.ncb);
+        long long cap = (long long)(256 / groups) & ~7ll;
+        if (cap < 8) cap = 8;
+        dim3 gp((unsigned)(p.njobs < cap ? p.njobs : cap), 1, groups);
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_pair_kernel<8, 4, true>), gp, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_pair_kernel<8, 4, false>), gp, dim3(256), 0, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_pair_kernel<4, 8, true>), gp, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_pair_kernel<4, 8, false>), gp, dim3(256), 0, st, p);
+        }
+        return ss_launch_status();
+    }
+#endif
+    dim3 g((unsigned)wgs, 1, groups);
 #ifdef SS_TUNING      // 32-channel blocks / three workgroups per CU: measured slower on every layer (tools/diag_wino.py); tools build only
     if (nb == 1) {
         if (tbh == 8) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1>), g, dim3(256), 0, st, p);
