@@ -81,7 +81,7 @@ typedef float w_f32x2 __attribute__((ext_vector_type(2)));
 // NB = 32-channel output blocks per workgroup: 2 (64 channels, 128 accumulator registers, two workgroups per CU) or
 // 1 (32 channels, 64 accumulator registers, THREE workgroups per CU: the epilogue / prologue of one workgroup hides
 // behind the MFMAs of two others -- the short-K layers (cin = 64: 4 chunks) spend a quarter of a workgroup's life there)
-template <int TBH, int TBW, int NB>
+template <int TBH, int TBW, int NB, bool RES>
 __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p) {
     static_assert(TBH * TBW == 32, "32 tiles per workgroup");
     constexpr int BN = 32 * NB;                             // output channels per workgroup
@@ -276,9 +276,8 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     // (Y[0][b] = T0 + T1 + T2, Y[1][b] = T1 - T2 - T3, fixed order), bias (folded BatchNorm), residual, ReLU, and
     // global memory sees whole 256-byte pixel rows as 16-byte accesses (out-of-range offsets outside the image).
     float* __restrict__ out = p.out + (long long)grp * p.out_gs;
-    const float* __restrict__ res = p.res ? p.res + (long long)grp * p.out_gs : nullptr;
     const __amdgpu_buffer_rsrc_t rout = w_rsrc(out, p.out_bytes);
-    const __amdgpu_buffer_rsrc_t rres = w_rsrc(res ? res : out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = w_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
     // this thread's output items: (pixel, channel quad); BN / 4 quads per pixel -> 128 * BN / 4 / 256 = 4 NB items
     constexpr int QP = BN / 4, NI = 4 * NB, PSTEP = 256 / QP;
     const int cq = tid % QP;
@@ -293,10 +292,13 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         const bool ok = oy < p.H && ox < p.W;
         goff[e] = ok ? ((((unsigned)img * p.H + oy) * p.W + ox) * (unsigned)p.out_cs + cbk * BN + 4u * cq) * 4u : 0xFFFFFFFFu;
     }
-    if (res) {
+    if (RES) {
 #pragma unroll
         for (int e = 0; e < NI; ++e) rv[e] = __builtin_amdgcn_raw_buffer_load_b128(rres, goff[e], 0, 0);
     }
+    // (RES is a template parameter and ReLU a clamp against 0 / -inf: with uniform branches per item the combine below
+    // ran one pixel at a time -- three LDS reads, wait, add, branch, store)
+    const float relu_lo = p.relu ? 0.f : -__builtin_inff();
     w_f32x4 bias4 = (w_f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const w_f32x4*>(p.bias + (long long)grp * p.Co + cbk * BN + 4 * cq);
     __syncthreads();                            // every wave is done with the raw buffers (the stage aliases them)
@@ -315,24 +317,32 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     }
     __syncthreads();
     W_STAMP(7);
+    // four pixels at a time: 12 LDS reads in flight, then the adds and stores
 #pragma unroll
-    for (int e = 0; e < NI; ++e) {
-        const int px = e * PSTEP + tid / QP;
-        const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
-        // a = 0: rows 0, 1, 2 added; a = 1: row 1 minus rows 2, 3
-        const float* s0 = smem + ((a * 2 + b) * 32 + tile) * BN + 4 * cq;
-        const w_f32x4 x = *reinterpret_cast<const w_f32x4*>(s0);
-        const w_f32x4 y = *reinterpret_cast<const w_f32x4*>(s0 + 2 * 32 * BN);
-        const w_f32x4 z = *reinterpret_cast<const w_f32x4*>(s0 + 4 * 32 * BN);
-        const float sg = a ? -1.f : 1.f;
-        w_f32x4 v = (x + sg * y) + sg * z;
-        v = v + bias4;
-        if (res) v = v + __builtin_bit_cast(w_f32x4, rv[e]);
-        if (p.relu) {
+    for (int e0 = 0; e0 < NI; e0 += 4) {
+        w_f32x4 x[4], y[4], z[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        for (int i = 0; i < 4; ++i) {
+            const int px = (e0 + i) * PSTEP + tid / QP;
+            const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
+            // a = 0: rows 0, 1, 2 added; a = 1: row 1 minus rows 2, 3
+            const float* s0 = smem + ((a * 2 + b) * 32 + tile) * BN + 4 * cq;
+            x[i] = *reinterpret_cast<const w_f32x4*>(s0);
+            y[i] = *reinterpret_cast<const w_f32x4*>(s0 + 2 * 32 * BN);
+            z[i] = *reinterpret_cast<const w_f32x4*>(s0 + 4 * 32 * BN);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w_u32x4, v), rout, goff[e], 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + i;
+            const int px = e * PSTEP + tid / QP;
+            const float sg = ((px >> 1) & 1) ? -1.f : 1.f;
+            w_f32x4 v = (x[i] + sg * y[i]) + sg * z[i];
+            v = v + bias4;
+            if (RES) v = v + __builtin_bit_cast(w_f32x4, rv[e]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], relu_lo);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w_u32x4, v), rout, goff[e], 0, 0);
+        }
     }
 #ifdef SS_TUNING
     if (p.dbg && tid == 0) {
@@ -864,12 +874,22 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
     dim3 g((unsigned)wgs, 1, groups);
 #ifdef SS_TUNING      // 32-channel blocks / three workgroups per CU: measured slower on every layer (tools/diag_wino.py); tools build only
     if (nb == 1) {
-        if (tbh == 8) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1>), g, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1>), g, dim3(256), 0, st, p);
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1, true>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1, false>), g, dim3(256), 0, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1, true>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1, false>), g, dim3(256), 0, st, p);
+        }
         return ss_launch_status();
     }
 #endif
-    if (tbh == 8) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2>), g, dim3(256), 0, st, p);
+    if (tbh == 8) {
+        if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false>), g, dim3(256), 0, st, p);
+    } else {
+        if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false>), g, dim3(256), 0, st, p);
+    }
     return ss_launch_status();
 }
