@@ -14,7 +14,7 @@
 //   transform domain (positions 4i..4i+3) for all 32 tiles and all 64 output channels: 4 x 2 accumulator tiles of
 //   v_mfma_f32_32x32x2_f32 = 128 registers.
 //   per chunk:
-//     * raw (2TBH+2) x (2TBW+2) x 16ch input patch: coalesced 16-byte buffer loads issued one chunk ahead (halo / M tail
+//     * raw (2TBH+2) x (2TBW+2) x 16ch input patch: coalesced 16-byte buffer loads issued two chunks ahead (halo / M tail
 //       / channel tail through the descriptor's bounds check: invalid lanes get offset 0xFFFFFFFF and read zeros),
 //       registers -> LDS transposed to channel planes [channel][row][col] (two buffers, one barrier per chunk);
 //     * input transform B^T d B IN THE MFMA OPERAND LAYOUT: lane (tile = lane & 31, k half = lane >> 5) reads rows
@@ -23,13 +23,14 @@
 //       of the wave's 4 positions.  The transformed input never exists in memory (first version: 128 KB of LDS
 //       reads per chunk for the A operands, LDS-bound);
 //     * 64 MFMAs per wave: B operand = transformed filters PRE-PACKED in the register layout of the instruction, global
-//       -> VGPR, fully coalesced 1 KB loads, prefetched one position (1024 MFMA cycles) ahead; each filter element is
-//       needed by exactly one wave of the workgroup, so nothing is lost by skipping LDS;
+//       -> VGPR, fully coalesced 1 KB loads, prefetched three 8-MFMA blocks (1536 MFMA cycles) ahead; each filter
+//       element is needed by exactly one wave of the workgroup, so nothing is lost by skipping LDS;
+//     all of it as ONE instruction stream per wave: the chunk is 8 blocks of 8 MFMAs, and the transform of the channels
+//     the next blocks need, the LDS staging of the next chunk and the filter loads sit between the MFMAs (see STREAM below);
 //   epilogue: wave i forms T[i][b] = sum_j M[i][j] A[j][b] in registers, stages it in LDS; then each thread sums the
 //   three T rows of its pixels in a fixed order (A^T), adds bias (folded BatchNorm) / residual, applies ReLU and stores
 //   whole 256-byte pixel rows with 16-byte accesses (out-of-range offsets for pixels outside the image: no branches).
-// Two workgroups per CU (64 KB LDS, <= 256 registers); the waves of a workgroup are decoupled inside the K loop (one
-// barrier per chunk), so one wave's transform runs under the other waves' MFMAs.
+// Two workgroups per CU (64 KB LDS, <= 256 registers): one workgroup's prologue / epilogue runs under the other's stream.
 #include "common.h"
 #include <type_traits>
 
@@ -78,12 +79,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float* base, unsi
 typedef float w_f32x16 __attribute__((ext_vector_type(16)));
 typedef float w_f32x2 __attribute__((ext_vector_type(2)));
 
+// Two schedules of the K loop (template parameter STREAM; same tiles, prologue and epilogue, bit-identical results):
+//   STREAM (dispatched): every wave runs ONE instruction stream in which its own input transform, LDS staging and filter
+//     loads sit in the issue slots between its MFMAs (sched_group_barrier).  Measured against the alternating schedule
+//     (tools/cmp_wino_variants.py): layer1 / 2 / 3 and the regressor shape 4 / 10 / 7 / 23 % faster, MFMA pipe 64 -> 69 %
+//     busy over the Winograd launches of a clip, +2 % frames/s.
+//   alternating (first version; tuning build only, ss_debug_set(7, 1)): per chunk a transform phase at raised priority,
+//     then 64 MFMAs with the filter loads pinned between them.  The matrix pipe idles whenever both resident waves of a
+//     SIMD are outside their MFMA runs at the same time, and a workgroup whose neighbour is in its prologue / epilogue
+//     (a quarter of a workgroup's life on layer1) keeps the pipe only ~60 % busy on its own.
 // NB = 32-channel output blocks per workgroup: 2 (64 channels, 128 accumulator registers, two workgroups per CU) or
 // 1 (32 channels, 64 accumulator registers, THREE workgroups per CU: the epilogue / prologue of one workgroup hides
 // behind the MFMAs of two others -- the short-K layers (cin = 64: 4 chunks) spend a quarter of a workgroup's life there)
-template <int TBH, int TBW, int NB, bool RES>
+template <int TBH, int TBW, int NB, bool RES, bool STREAM>
 __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p) {
     static_assert(TBH * TBW == 32, "32 tiles per workgroup");
+    static_assert(!STREAM || NB == 2, "the stream schedule is written for 64-channel blocks");
     constexpr int BN = 32 * NB;                             // output channels per workgroup
     constexpr int RH = 2 * TBH + 2, RW = 2 * TBW + 2;      // raw input patch (pixels)
     constexpr int RPIX = RH * RW;
@@ -142,7 +153,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         const bool ok = item < RPIX * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         rbase[e] = ((((unsigned)img * p.H + iy) * p.W + ix) * (unsigned)p.C + 4u * q) * 4u;
         rinv[e] = ok ? 0u : 0xFFFFFFFFu;
-        rlds[e] = (4 * q) * PLANE + ry * RWP + rx;           // channel 4q of this pixel; the quad's channels are PLANE apart
+        // channel 4q of this pixel (the quad's channels are PLANE apart); items past the patch (RPIX * 4 is not a multiple
+        // of 256) land in the 4-dword pad behind their planes: no branch around the LDS writes
+        rlds[e] = (4 * q) * PLANE + (item < RPIX * 4 ? ry * RWP + rx : RH * RWP);
     }
     const int myq = tid & 3;                                // channel quad of this thread's raw items
 
@@ -171,101 +184,229 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    w_f32x4 rr[NE];
-    auto raw_issue = [&](int c) {
-        if (W_ABLATE(2)) return;
-        const unsigned coff = (unsigned)c * 64u;
-        const unsigned cinv = ((c * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
+    if constexpr (STREAM) {
+        w_f32x4 rr[NE];
+        auto raw_issue = [&](int c) {
+            const unsigned coff = (unsigned)c * 64u;
+            const unsigned cinv = ((c * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-        for (int e = 0; e < NE; ++e)
-            rr[e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0));
-    };
-    // filters of (chunk c, position 4 wave + j): u[blk][half] = 4 floats = MFMA steps 4 half .. 4 half + 3
-    auto u_issue = [&](w_f32x4 (&u)[NB][2], int c, int j) {
-        if (W_ABLATE(1)) return;
-        const unsigned base = u_wave + (unsigned)c * 32768u + (unsigned)j * 2048u;
+            for (int e = 0; e < NE; ++e)
+                rr[e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0));
+        };
+        auto raw_store = [&](float* buf) {
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            const int so = (int)__builtin_amdgcn_readfirstlane(base + (unsigned)blk * u_blk);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                u[blk][h] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * h, so, 0));
-        }
-    };
-    float av[4][8];              // A operands of this chunk: av[j][s] = V[position 4 wave + j][tile][channel 8 kh + s]
-    const w_f32x2 t_sg = wave == 1 ? (w_f32x2){1.f, 1.f} : (w_f32x2){-1.f, -1.f};     // row stage: d[ra] + sg * d[rb] (exact)
-    auto transform = [&](const float* buf) {
-        const float* src = buf + t_src;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float* pa = src + c * PLANE + t_ra * RWP;
-            const float* pb = src + c * PLANE + t_rb * RWP;
-            const w_f32x2 xa0 = *reinterpret_cast<const w_f32x2*>(pa), xa1 = *reinterpret_cast<const w_f32x2*>(pa + 2);
-            const w_f32x2 xb0 = *reinterpret_cast<const w_f32x2*>(pb), xb1 = *reinterpret_cast<const w_f32x2*>(pb + 2);
-            const w_f32x2 r0 = __builtin_elementwise_fma(xb0, t_sg, xa0);      // (r0, r1)
-            const w_f32x2 r1 = __builtin_elementwise_fma(xb1, t_sg, xa1);      // (r2, r3)
-            const w_f32x2 d = r0 - r1;                                         // (r0 - r2, r1 - r3) = positions 0 and 3
-            av[0][c] = d[0];
-            av[1][c] = r0[1] + r1[0];
-            av[2][c] = r1[0] - r0[1];
-            av[3][c] = d[1];
-        }
-    };
-    auto mma = [&](int j, const w_f32x4 (&u)[NB][2]) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
-                acc[j][blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s], u[blk][s >> 2][s & 3], acc[j][blk], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // filters one position (16 NB/2 MFMAs) ahead in two alternating register sets.  (One set per position, reloaded three
-    // positions ahead, was measured slower: 256 registers with spills, 367 vs 313 us on layer1.)
-    w_f32x4 ua[NB][2], ub[NB][2];
-    raw_issue(0);
-    u_issue(ua, 0, 0);
-    W_STAMP(1);
-    for (int c = 0; c < p.nchunk; ++c) {
-        float* buf = smem + (c & 1) * RAWF;
-        // registers -> LDS, transposed to channel planes.  Two buffers: the waves still transforming chunk c - 1 read the
-        // other one, and everyone passed the previous barrier after its chunk c - 2 reads: ONE barrier per chunk.
-#pragma unroll
-        for (int e = 0; e < NE; ++e)
-            if (!W_ABLATE(2) && (NE * 256 == RPIX * 4 || tid + 256 * e < RPIX * 4)) {
+            for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) buf[rlds[e] + k * PLANE] = rr[e][k];
+        };
+        // filters of one BLOCK = (chunk c, position 4 wave + j, half h): u[blk] = 4 floats = MFMA steps 4 h .. 4 h + 3.
+        // Four register sets: block k multiplies with set k & 3 while the loads of block k + 3 go to the set block k - 1 used.
+        w_f32x4 u[4][NB];
+        auto u_issue = [&](int set, int c, int j, int h) {
+            const unsigned base = u_wave + (unsigned)c * 32768u + (unsigned)j * 2048u;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int so = (int)__builtin_amdgcn_readfirstlane(base + (unsigned)blk * u_blk);
+                u[set][blk] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * h, so, 0));
             }
-        __syncthreads();
-        if (c == 0) W_STAMP(5);
-        // next chunk's raw patch: branch free (the last iteration re-requests its own chunk, results unused -- with a
-        // conditional the compiler drains the prefetch of the path that issued none)
-        const int cn = c + 1 < p.nchunk ? c + 1 : c;
-        raw_issue(cn);
-        if (!W_ABLATE(2)) transform(buf);
-        if (c == 0) W_STAMP(6);
+        };
+        float av[4][8];              // A operands: av[j][s] = V[position 4 wave + j][tile][channel 8 kh + s]
+        const w_f32x2 t_sg = wave == 1 ? (w_f32x2){1.f, 1.f} : (w_f32x2){-1.f, -1.f};     // row stage: d[ra] + sg * d[rb] (exact)
+        // the input transform, one channel at a time: rd() requests the two patch rows, xf() (one block later) turns them
+        // into the four A operands of that channel
+        w_f32x2 tq[4];
+        auto rd = [&](const float* buf, int ch) {
+            const float* pa = buf + t_src + ch * PLANE + t_ra * RWP;
+            const float* pb = buf + t_src + ch * PLANE + t_rb * RWP;
+            tq[0] = *reinterpret_cast<const w_f32x2*>(pa);
+            tq[1] = *reinterpret_cast<const w_f32x2*>(pa + 2);
+            tq[2] = *reinterpret_cast<const w_f32x2*>(pb);
+            tq[3] = *reinterpret_cast<const w_f32x2*>(pb + 2);
+        };
+        auto xf = [&](int ch) {
+            const w_f32x2 r0 = __builtin_elementwise_fma(tq[2], t_sg, tq[0]);      // (r0, r1)
+            const w_f32x2 r1 = __builtin_elementwise_fma(tq[3], t_sg, tq[1]);      // (r2, r3)
+            const w_f32x2 d = r0 - r1;                                             // (r0 - r2, r1 - r3) = positions 0 and 3
+            av[0][ch] = d[0];
+            av[1][ch] = r0[1] + r1[0];
+            av[2][ch] = r1[0] - r0[1];
+            av[3][ch] = d[1];
+        };
+        // 8 MFMAs: position j, channels 4 h .. 4 h + 3 of the chunk, both 32-channel blocks alternating
+        auto mma = [&](int set, int j, int h) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+                    acc[j][blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][4 * h + s], u[set][blk][s], acc[j][blk], 0, 0, 0);
+        };
+        // interleave pattern of one block: the block's 2 LDS reads behind the first MFMAs, its 2 filter loads behind the next
+        // two, `DSW` LDS writes per MFMA where the block stages a raw patch, VALU work everywhere
+#define W_SGB_BLOCK(DSW, VM)                                                            \
+        do {                                                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                          \
+            }                                                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+                if (DSW) __builtin_amdgcn_sched_group_barrier(0x200, DSW, 0);               \
+                if (VM) __builtin_amdgcn_sched_group_barrier(0x020, VM, 0);                 \
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                          \
+            }                                                                               \
+        } while (0)
+        auto lds_barrier = [&]() {       // __syncthreads() minus its global-memory fence (it would drain every prefetch in flight)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        };
+
+        // ---- stream prologue: chunk 0 in LDS, its channels 0..3 transformed, chunk 1 and the first three filter blocks in flight
+        raw_issue(0);
+        u_issue(0, 0, 0, 0);
+        u_issue(1, 0, 1, 0);
+        u_issue(2, 0, 2, 0);
+        raw_store(smem);
+        lds_barrier();
+        W_STAMP(5);
+        raw_issue(p.nchunk > 1 ? 1 : 0);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) { rd(smem, ch); xf(ch); }
+        rd(smem, 4);
+        W_STAMP(6);
+        W_STAMP(1);
         __builtin_amdgcn_s_setprio(0);
-        // the sched_barriers pin every group of loads in front of the MFMAs it overlaps with (left alone, the scheduler
-        // sinks them into the MFMA run to shorten live ranges and the next position then waits for L2)
-        __builtin_amdgcn_sched_barrier(0);
-        u_issue(ub, c, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, ua);
-        __builtin_amdgcn_sched_barrier(0);
-        u_issue(ua, c, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, ub);
-        __builtin_amdgcn_sched_barrier(0);
-        u_issue(ub, c, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(2, ua);
-        __builtin_amdgcn_sched_barrier(0);
-        u_issue(ua, cn, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(3, ub);
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- the stream: 8 blocks of 8 MFMAs per chunk.  First half: channels 0..3 of the chunk multiply while channels 4..7
+        // are transformed; second half: channels 4..7 multiply while channels 0..3 of the NEXT chunk are transformed (its raw
+        // patch goes registers -> LDS inside block (0, 2), one barrier per chunk after that block).  Every accumulator sees its
+        // (chunk, step) products in the same order as in conv_wino_kernel: the results are bit-identical.
+        for (int c = 0; c < p.nchunk; ++c) {
+            float* bc = smem + (c & 1) * RAWF;                  // raw patch of chunk c
+            float* bn = smem + ((c + 1) & 1) * RAWF;            // chunk c + 1
+            // (the last iteration re-requests its own chunk: branch free, results unused)
+            const int cn = c + 1 < p.nchunk ? c + 1 : c;
+            const int cnn = c + 2 < p.nchunk ? c + 2 : cn;
+            __builtin_amdgcn_sched_barrier(0);
+            xf(4); rd(bc, 5); mma(0, 0, 0); u_issue(3, c, 3, 0); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(5); rd(bc, 6); mma(1, 1, 0); u_issue(0, c, 0, 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(6); rd(bc, 7); raw_store(bn); mma(2, 2, 0); u_issue(1, c, 1, 1); W_SGB_BLOCK(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            raw_issue(cnn);
+            xf(7); rd(bn, 0); mma(3, 3, 0); u_issue(2, c, 2, 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(0); rd(bn, 1); mma(0, 0, 1); u_issue(3, c, 3, 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(1); rd(bn, 2); mma(1, 1, 1); u_issue(0, cn, 0, 0); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(2); rd(bn, 3); mma(2, 2, 1); u_issue(1, cn, 1, 0); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(3); rd(bn, 4); mma(3, 3, 1); u_issue(2, cn, 2, 0); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(3);
+#undef W_SGB_BLOCK
+    } else {
+        w_f32x4 rr[NE];
+        auto raw_issue = [&](int c) {
+            if (W_ABLATE(2)) return;
+            const unsigned coff = (unsigned)c * 64u;
+            const unsigned cinv = ((c * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                rr[e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0));
+        };
+        // filters of (chunk c, position 4 wave + j): u[blk][half] = 4 floats = MFMA steps 4 half .. 4 half + 3
+        auto u_issue = [&](w_f32x4 (&u)[NB][2], int c, int j) {
+            if (W_ABLATE(1)) return;
+            const unsigned base = u_wave + (unsigned)c * 32768u + (unsigned)j * 2048u;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int so = (int)__builtin_amdgcn_readfirstlane(base + (unsigned)blk * u_blk);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    u[blk][h] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * h, so, 0));
+            }
+        };
+        float av[4][8];              // A operands of this chunk: av[j][s] = V[position 4 wave + j][tile][channel 8 kh + s]
+        const w_f32x2 t_sg = wave == 1 ? (w_f32x2){1.f, 1.f} : (w_f32x2){-1.f, -1.f};     // row stage: d[ra] + sg * d[rb] (exact)
+        auto transform = [&](const float* buf) {
+            const float* src = buf + t_src;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float* pa = src + c * PLANE + t_ra * RWP;
+                const float* pb = src + c * PLANE + t_rb * RWP;
+                const w_f32x2 xa0 = *reinterpret_cast<const w_f32x2*>(pa), xa1 = *reinterpret_cast<const w_f32x2*>(pa + 2);
+                const w_f32x2 xb0 = *reinterpret_cast<const w_f32x2*>(pb), xb1 = *reinterpret_cast<const w_f32x2*>(pb + 2);
+                const w_f32x2 r0 = __builtin_elementwise_fma(xb0, t_sg, xa0);      // (r0, r1)
+                const w_f32x2 r1 = __builtin_elementwise_fma(xb1, t_sg, xa1);      // (r2, r3)
+                const w_f32x2 d = r0 - r1;                                         // (r0 - r2, r1 - r3) = positions 0 and 3
+                av[0][c] = d[0];
+                av[1][c] = r0[1] + r1[0];
+                av[2][c] = r1[0] - r0[1];
+                av[3][c] = d[1];
+            }
+        };
+        auto mma = [&](int j, const w_f32x4 (&u)[NB][2]) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+                    acc[j][blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s], u[blk][s >> 2][s & 3], acc[j][blk], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // filters one position (16 NB/2 MFMAs) ahead in two alternating register sets.  (One set per position, reloaded three
+        // positions ahead, was measured slower: 256 registers with spills, 367 vs 313 us on layer1.)
+        w_f32x4 ua[NB][2], ub[NB][2];
+        raw_issue(0);
+        u_issue(ua, 0, 0);
+        W_STAMP(1);
+        for (int c = 0; c < p.nchunk; ++c) {
+            float* buf = smem + (c & 1) * RAWF;
+            // registers -> LDS, transposed to channel planes.  Two buffers: the waves still transforming chunk c - 1 read the
+            // other one, and everyone passed the previous barrier after its chunk c - 2 reads: ONE barrier per chunk.
+            if (!W_ABLATE(2)) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) buf[rlds[e] + k * PLANE] = rr[e][k];
+            }
+            __syncthreads();
+            if (c == 0) W_STAMP(5);
+            // next chunk's raw patch: branch free (the last iteration re-requests its own chunk, results unused -- with a
+            // conditional the compiler drains the prefetch of the path that issued none)
+            const int cn = c + 1 < p.nchunk ? c + 1 : c;
+            raw_issue(cn);
+            if (!W_ABLATE(2)) transform(buf);
+            if (c == 0) W_STAMP(6);
+            __builtin_amdgcn_s_setprio(0);
+            // the sched_barriers pin every group of loads in front of the MFMAs it overlaps with (left alone, the scheduler
+            // sinks them into the MFMA run to shorten live ranges and the next position then waits for L2)
+            __builtin_amdgcn_sched_barrier(0);
+            u_issue(ub, c, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, ua);
+            __builtin_amdgcn_sched_barrier(0);
+            u_issue(ua, c, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, ub);
+            __builtin_amdgcn_sched_barrier(0);
+            u_issue(ub, c, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(2, ua);
+            __builtin_amdgcn_sched_barrier(0);
+            u_issue(ua, cn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(3, ub);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
+        }
     }
     W_STAMP(2);
     if (W_ABLATE(4)) return;
@@ -793,7 +934,7 @@ extern "C" int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, 
 #ifdef SS_TUNING
 int g_wino_ablate = 0;                   // ss_debug_set key 6
 int g_wino_nb1_max_cin = 0;              // ss_debug_set key 5
-int g_wino_variant = 0;                  // ss_debug_set key 7: 2 = pair kernel (experiment)
+int g_wino_variant = 0;                  // ss_debug_set key 7: 0 stream kernel (dispatched), 1 phase-alternating kernel, 2 pair kernel
 #else
 constexpr int g_wino_nb1_max_cin = 0;
 #endif
@@ -875,21 +1016,33 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
 #ifdef SS_TUNING      // 32-channel blocks / three workgroups per CU: measured slower on every layer (tools/diag_wino.py); tools build only
     if (nb == 1) {
         if (tbh == 8) {
-            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1, true>), g, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1, false>), g, dim3(256), 0, st, p);
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1, true, false>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 1, false, false>), g, dim3(256), 0, st, p);
         } else {
-            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1, true>), g, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1, false>), g, dim3(256), 0, st, p);
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1, true, false>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 1, false, false>), g, dim3(256), 0, st, p);
+        }
+        return ss_launch_status();
+    }
+#endif
+#ifdef SS_TUNING      // the phase-alternating kernel: comparison runs only (tools/cmp_wino_variants.py, tools/diag_wino.py)
+    if (g_wino_variant == 1) {
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, false>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, false>), g, dim3(256), 0, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, false>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, false>), g, dim3(256), 0, st, p);
         }
         return ss_launch_status();
     }
 #endif
     if (tbh == 8) {
-        if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true>), g, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false>), g, dim3(256), 0, st, p);
+        if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true>), g, dim3(256), 0, st, p);
     } else {
-        if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true>), g, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false>), g, dim3(256), 0, st, p);
+        if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, true>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true>), g, dim3(256), 0, st, p);
     }
     return ss_launch_status();
 }

@@ -1,5 +1,6 @@
-"""Pair kernel vs one-tile-block kernel (tuning build, ss_debug_set key 7): outputs must be bit-identical (same
-accumulation order), plus timing of both.   python tools/cmp_wino_variants.py"""
+"""Winograd kernel schedules against each other (tuning build, ss_debug_set key 7: 0 stream = dispatched, 1 alternating,
+2 pair kernel): outputs must be bit-identical (same accumulation order), plus timing of both.
+    python tools/cmp_wino_variants.py [shapes]          WINO_VARIANT=2 for the pair kernel; "single" = variant 1"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabstitch2_amd import ops
@@ -15,7 +16,7 @@ for name in names:
     x = torch.randn(n, h, w, cin, device=dev); wt = torch.randn(cout, 1, 3, 3, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     res = torch.randn(n, h, w, cout, device=dev)
     outs, times = [], []
-    for variant in (1, 2):
+    for variant in (1, int(os.environ.get("WINO_VARIANT", "0"))):
         lib.ss_debug_set(7, variant)
         for r in (None, res):
             out = ops.conv_winograd(x, wt, b, r, relu=r is not None)
@@ -30,5 +31,5 @@ for name in names:
     lib.ss_debug_set(7, 0)
     d0 = (outs[0] - outs[2]).abs().max().item(); d1 = (outs[1] - outs[3]).abs().max().item()
     gf = 2.0 * n * h * w * cout * 9 * cin / 1e9
-    print('%-7s max|single - pair| = %.3g / %.3g (with residual+relu); single %.1f us (%.0f TF/s eq), pair %.1f us (%.0f TF/s eq)'
+    print('%-7s max|single - variant| = %.3g / %.3g (with residual+relu); single %.1f us (%.0f TF/s eq), variant %.1f us (%.0f TF/s eq)'
           % (name, d0, d1, times[0], gf / times[0] * 1e3, times[1], gf / times[1] * 1e3))

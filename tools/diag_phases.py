@@ -8,20 +8,29 @@ lib = _tuning.lib()
 dev = torch.device('cuda:0')
 SHAPES = {'layer1': (64, 90, 120, 64, 64, 3, 1, 1), 'layer2': (64, 45, 60, 128, 128, 3, 1, 1), 'layer3': (64, 23, 30, 256, 256, 3, 1, 1)}
 for name in sys.argv[1].split(','):
-    n, h, w, cin, cout, k, s, p = SHAPES[name]
-    x = torch.randn(n, h, w, cin, device=dev); wt = torch.randn(cout, 1, k, k, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
-    out = ops.conv(x, wt, b, stride=s, pad=(0, p, p), relu=True)
-    res = torch.randn_like(out)
-    m = out.numel() // cout
-    nblk = ((m + 63) // 64) * ((cout + 63) // 64)
+    if name == 'stem':          # the 7x7/2 stem on the row-packed 3-channel layout (two trunks' filters: cout 128)
+        xs = [torch.randn(16, 3, 360, 480, device=dev)]
+        buf = ops.stem_input(xs); wt = torch.randn(128, 7, 24, device=dev) * 0.05; b = torch.randn(128, device=dev)
+        run = lambda: ops.conv_stem(buf, wt, b, relu=True)
+        out = run(); cout = 128; m = out.numel() // cout
+        nblk = ((m + 127) // 128) * ((cout + 63) // 64) + 64
+    else:
+        n, h, w, cin, cout, k, s, p = SHAPES[name]
+        x = torch.randn(n, h, w, cin, device=dev); wt = torch.randn(cout, 1, k, k, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
+        out = ops.conv(x, wt, b, stride=s, pad=(0, p, p), relu=True)
+        res = torch.randn_like(out)
+        run = lambda: ops.conv(x, wt, b, res=res, stride=s, pad=(0, p, p), relu=True, out=out)
+        m = out.numel() // cout
+        nblk = ((m + 63) // 64) * ((cout + 63) // 64)
     dbg = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
-    for _ in range(3): ops.conv(x, wt, b, res=res, stride=s, pad=(0, p, p), relu=True, out=out)
+    for _ in range(3): run()
     torch.cuda.synchronize()
     lib.ss_debug_ptr(ctypes.c_void_p(dbg.data_ptr()))
-    ops.conv(x, wt, b, res=res, stride=s, pad=(0, p, p), relu=True, out=out)
+    run()
     torch.cuda.synchronize()
     lib.ss_debug_ptr(None)
     d = dbg.cpu().numpy().astype(np.int64)
+    d = d[d[:, 0] > 0]; nblk = len(d)
     t0 = d[:, 0].min()
     pro, loop, epi = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]
     total = d[:, 3].max() - t0
