@@ -177,12 +177,14 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     const unsigned u_blk = (unsigned)p.nchunk * 32768u;
 
     w_f32x16 acc[4][NB];
+    auto acc_clear = [&]() {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
 
     if constexpr (STREAM) {
         w_f32x4 rr[NE];
@@ -267,6 +269,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         u_issue(0, 0, 0, 0);
         u_issue(1, 0, 1, 0);
         u_issue(2, 0, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc_clear();                                        // 128 moves under the latency of the first loads
+        __builtin_amdgcn_sched_barrier(0);
         raw_store(smem);
         lds_barrier();
         W_STAMP(5);
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         __builtin_amdgcn_s_setprio(3);
 #undef W_SGB_BLOCK
     } else {
+        acc_clear();
         w_f32x4 rr[NE];
         auto raw_issue = [&](int c) {
             if (W_ABLATE(2)) return;

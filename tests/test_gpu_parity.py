@@ -998,6 +998,41 @@ def test_conv_winograd_grouped_and_dispatch(dev):
     close(a, d, 4e-5 * max(1.0, float(d.abs().max())), 'dispatch: winograd vs implicit GEMM')
 
 
+def test_conv_winograd_schedules_bit_identical(dev, request):
+    """The dispatched stream schedule of the Winograd K loop against the phase-alternating schedule it replaced (kept in
+    the tools/ build, ss_debug_set(7, 1)): every accumulator receives its products in the same order, so the outputs
+    must be EQUAL -- ragged maps, channel tails, residual / ReLU, grouped launches; and the product build must match."""
+    from stabstitch2_amd import ops, _hip
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_tuning', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'tools', '_tuning.py'))
+    tuning = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tuning)
+    product = _hip.lib()
+    request.addfinalizer(lambda: setattr(_hip, '_lib', product))
+    lib = tuning.lib()
+    request.addfinalizer(lambda: lib.ss_debug_set(7, 0))
+    rs = np.random.RandomState(77)
+    for (n, cin, cout, h, w, g) in ((64, 64, 64, 90, 120, 1), (16, 128, 128, 45, 60, 1), (8, 256, 256, 23, 30, 1),
+                                    (3, 36, 64, 37, 53, 1), (1, 32, 128, 8, 8, 1), (5, 160, 64, 11, 15, 2), (2, 20, 64, 3, 5, 1)):
+        shape = (g, n, h, w, cin) if g > 1 else (n, h, w, cin)
+        x = torch.from_numpy(rs.normal(0, 1, shape).astype(np.float32)).to(dev)
+        wt = torch.from_numpy((rs.normal(0, 1, ((g,) if g > 1 else ()) + (cout, 1, 3, 3, cin)) / np.sqrt(9 * cin)).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rs.normal(0, 1, ((g,) if g > 1 else ()) + (cout,)).astype(np.float32)).to(dev)
+        r = torch.from_numpy(rs.normal(0, 1, shape[:-1] + (cout,)).astype(np.float32)).to(dev)
+        for (res, relu) in ((None, False), (r, True)):
+            outs = []
+            for variant in (0, 1):
+                lib.ss_debug_set(7, variant)
+                outs.append(ops.conv_winograd(x, wt, b, res, relu=relu))
+            lib.ss_debug_set(7, 0)
+            assert torch.equal(outs[0], outs[1]), ('stream vs alternating schedule', (n, cin, cout, h, w, g, relu))
+            _hip._lib = product
+            prod = ops.conv_winograd(x, wt, b, res, relu=relu)
+            _hip._lib = lib
+            assert torch.equal(prod, outs[0]), 'product and tuning builds differ'
+
+
 def test_ingest_u8_vs_handworked_cv2_vectors(dev):
     """The HIP front-end against the scalar hand derivation of OpenCV's uint8 INTER_LINEAR (tests/golden/
     cv2_resize_handworked.json, independent of oracle/frame_io.py): lr = resize / 127.5 - 1, bit for bit."""
