@@ -77,84 +77,71 @@ __device__ __forceinline__ void tps_eval_interleaved(const float* __restrict__ s
     oy = ay;
 }
 
-// Two splines at once (the two views of a stitched frame) with packed fp32 math; log via the hardware log2
-// (v_log_f32, 1 ulp) times ln2.  The argument d2 + 1e-6 lies in [1e-6, ~16], so no denormal / range handling is
+// The dense warp's spline evaluation.  One arithmetic, two shapes (a scalar one for the generic per-view warp and a
+// packed one for the fused render; same operations in the same order -> bit-identical coordinates, so the fused kernel
+// can be checked against the chained one exactly):
+//     per control point k:  dx = x - sx_k;  d2 = fma(dx, dx, dy2_k)  with dy2_k = fl((y - sy_k)^2);
+//                           r  = d2 * log2(d2 + 1e-6);   Sx = fma(tx_k, r, Sx);  Sy = fma(ty_k, r, Sy)
+//     result:               fma(Sx, ln 2, T0 + T1 x + T2 y)      (the spline's radial sum is formed in log2 units)
+// log2 is the hardware v_log_f32 (1 ulp).  The argument lies in [1e-6, ~16], so no denormal / range handling is
 // needed; the result differs from an accurate logf by <= ~1.5 ulp, the same class as the reference's own vectorised
 // logf, and two orders below the reference's fp32-vs-fp64 coordinate noise.
 typedef float ss_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void tps_eval_pair(const float* __restrict__ src0, const float* __restrict__ src1,
-                                              const float* __restrict__ T0, const float* __restrict__ T1, float x,
-                                              float y, ss_f2& ox, ss_f2& oy) {
-    const float* Tx0 = T0;
-    const float* Ty0 = T0 + SS_NT;
-    const float* Tx1 = T1;
-    const float* Ty1 = T1 + SS_NT;
-    ss_f2 ax = {fmaf(Tx0[2], y, fmaf(Tx0[1], x, Tx0[0])), fmaf(Tx1[2], y, fmaf(Tx1[1], x, Tx1[0]))};
-    ss_f2 ay = {fmaf(Ty0[2], y, fmaf(Ty0[1], x, Ty0[0])), fmaf(Ty1[2], y, fmaf(Ty1[1], x, Ty1[0]))};
-    const ss_f2 xx = {x, x}, yy = {y, y};
-    const ss_f2 eps = {1e-6f, 1e-6f};
-#pragma unroll 9
-    for (int k = 0; k < SS_NV; ++k) {
-        ss_f2 sx = {src0[2 * k], src1[2 * k]};
-        ss_f2 sy = {src0[2 * k + 1], src1[2 * k + 1]};
-        ss_f2 dx = xx - sx, dy = yy - sy;
-        ss_f2 d2 = dx * dx + dy * dy;
-        ss_f2 a = d2 + eps;
-        ss_f2 lg = {__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)};
-        ss_f2 r = d2 * (lg * 0.6931471805599453f);
-        ss_f2 tx = {Tx0[3 + k], Tx1[3 + k]};
-        ss_f2 ty = {Ty0[3 + k], Ty1[3 + k]};
-        ax = __builtin_elementwise_fma(tx, r, ax);
-        ay = __builtin_elementwise_fma(ty, r, ay);
-    }
-    ox = ax;
-    oy = ay;
-}
+#define SS_LN2 0.6931471805599453f
 
-// ONE spline at two points with packed math (the single-view tiles of the fused render evaluate two canvas rows per
-// lane); per point the operations and their order are those of tps_eval_pair / tps_eval_fast: bit-identical coordinates.
-__device__ __forceinline__ void tps_eval_two_points(const float* __restrict__ src, const float* __restrict__ T, float x,
-                                                    float y0, float y1, ss_f2& ox, ss_f2& oy) {
-    const float* Tx = T;
-    const float* Ty = T + SS_NT;
-    ss_f2 ax = {fmaf(Tx[2], y0, fmaf(Tx[1], x, Tx[0])), fmaf(Tx[2], y1, fmaf(Tx[1], x, Tx[0]))};
-    ss_f2 ay = {fmaf(Ty[2], y0, fmaf(Ty[1], x, Ty[0])), fmaf(Ty[2], y1, fmaf(Ty[1], x, Ty[0]))};
-    const ss_f2 xx = {x, x}, yy = {y0, y1};
-    const ss_f2 eps = {1e-6f, 1e-6f};
-#pragma unroll 9
-    for (int k = 0; k < SS_NV; ++k) {
-        const ss_f2 sx = {src[2 * k], src[2 * k]};
-        const ss_f2 sy = {src[2 * k + 1], src[2 * k + 1]};
-        ss_f2 dx = xx - sx, dy = yy - sy;
-        ss_f2 d2 = dx * dx + dy * dy;
-        ss_f2 a = d2 + eps;
-        ss_f2 lg = {__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)};
-        ss_f2 r = d2 * (lg * 0.6931471805599453f);
-        const ss_f2 tx = {Tx[3 + k], Tx[3 + k]};
-        const ss_f2 ty = {Ty[3 + k], Ty[3 + k]};
-        ax = __builtin_elementwise_fma(tx, r, ax);
-        ay = __builtin_elementwise_fma(ty, r, ay);
-    }
-    ox = ax;
-    oy = ay;
-}
-
-// scalar twin of tps_eval_pair (same operations in the same order -> bit-identical coordinates), used by the
-// generic per-view warp so that the fused render can be checked against it exactly
 __device__ __forceinline__ void tps_eval_fast(const float* __restrict__ src, const float* __restrict__ Tx,
                                               const float* __restrict__ Ty, float x, float y, float& ox, float& oy) {
-    float ax = fmaf(Tx[2], y, fmaf(Tx[1], x, Tx[0]));
-    float ay = fmaf(Ty[2], y, fmaf(Ty[1], x, Ty[0]));
+    float sx = 0.f, sy = 0.f;
 #pragma unroll 9
     for (int k = 0; k < SS_NV; ++k) {
-        float dx = x - src[2 * k], dy = y - src[2 * k + 1];
-        float d2 = dx * dx + dy * dy;
-        float r = d2 * (__builtin_amdgcn_logf(d2 + 1e-6f) * 0.6931471805599453f);
-        ax = fmaf(Tx[3 + k], r, ax);
-        ay = fmaf(Ty[3 + k], r, ay);
+        const float dx = __fsub_rn(x, src[2 * k]), dy = __fsub_rn(y, src[2 * k + 1]);
+        const float d2 = fmaf(dx, dx, __fmul_rn(dy, dy));
+        const float r = __fmul_rn(d2, __builtin_amdgcn_logf(__fadd_rn(d2, 1e-6f)));
+        sx = fmaf(Tx[3 + k], r, sx);
+        sy = fmaf(Ty[3 + k], r, sy);
     }
-    ox = ax;
-    oy = ay;
+    ox = fmaf(sx, SS_LN2, fmaf(Tx[2], y, fmaf(Tx[1], x, Tx[0])));
+    oy = fmaf(sy, SS_LN2, fmaf(Ty[2], y, fmaf(Ty[1], x, Ty[0])));
+}
+
+// ONE spline at the same column x of TWO canvas rows (y0, y1), packed over the rows.  Everything that depends on the
+// row only -- dy2_k of both rows -- is wave-uniform in the fused render (a wave = 64 columns of the same two rows): the
+// wave computes the 63 pairs once (lane k: control point k, tps_rows_table) and every lane reads them back as LDS
+// broadcasts; dx is shared by the two rows.  Per control point and lane: 6 VALU instructions + 2 v_log_f32 for two
+// points (the version that evaluated dx, dy and their squares per lane: 9 + 2).
+__device__ __forceinline__ void tps_rows_table(const float* __restrict__ src, float y0, float y1, int lane,
+                                               ss_f2* __restrict__ tab) {
+    if (lane < SS_NV) {
+        const float sy = src[2 * lane + 1];
+        const float d0 = __fsub_rn(y0, sy), d1 = __fsub_rn(y1, sy);
+        tab[lane] = (ss_f2){__fmul_rn(d0, d0), __fmul_rn(d1, d1)};
+    }
+}
+__device__ __forceinline__ void tps_eval_rows(const float* __restrict__ src, const float* __restrict__ T,
+                                              const ss_f2* __restrict__ tab, float x, float y0, float y1, ss_f2& ox,
+                                              ss_f2& oy) {
+    const float* Tx = T;
+    const float* Ty = T + SS_NT;
+    ss_f2 sx = {0.f, 0.f}, sy = {0.f, 0.f};
+    const ss_f2 eps = {1e-6f, 1e-6f};
+#pragma unroll 9
+    for (int k = 0; k < SS_NV; ++k) {
+        const float dx = __fsub_rn(x, src[2 * k]);
+        const ss_f2 dxx = {dx, dx};
+        const ss_f2 d2 = __builtin_elementwise_fma(dxx, dxx, tab[k]);
+        const ss_f2 a = d2 + eps;
+        const ss_f2 lg = {__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)};
+        const ss_f2 r = d2 * lg;
+        const ss_f2 tx = {Tx[3 + k], Tx[3 + k]};
+        const ss_f2 ty = {Ty[3 + k], Ty[3 + k]};
+        sx = __builtin_elementwise_fma(tx, r, sx);
+        sy = __builtin_elementwise_fma(ty, r, sy);
+    }
+    const ss_f2 ax = {fmaf(Tx[2], y0, fmaf(Tx[1], x, Tx[0])), fmaf(Tx[2], y1, fmaf(Tx[1], x, Tx[0]))};
+    const ss_f2 ay = {fmaf(Ty[2], y0, fmaf(Ty[1], x, Ty[0])), fmaf(Ty[2], y1, fmaf(Ty[1], x, Ty[0]))};
+    const ss_f2 ln2 = {SS_LN2, SS_LN2};
+    ox = __builtin_elementwise_fma(sx, ln2, ax);
+    oy = __builtin_elementwise_fma(sy, ln2, ay);
 }
 
 __device__ __forceinline__ float norm1(float v, float size) { return __fsub_rn(__fmul_rn(v, 2.0f) / size, 1.0f); }

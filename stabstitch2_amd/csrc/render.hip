@@ -325,9 +325,8 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
                                                              const float* __restrict__ T, const float* __restrict__ fp,
                                                              float* __restrict__ out, int h, int w, int hc, int wc,
                                                              int mode) {
-    // workgroup = 64 x 8 canvas pixels; wave w owns rows w and w + 4 of the tile: as two sequential evaluations of the
-    // packed view pair where two or three views reach the tile, as ONE evaluation of two points (packed over the rows)
-    // where a single view does -- all four waves (= all four SIMDs) stay busy either way
+    // workgroup = 64 x 8 canvas pixels; wave w owns rows w and w + 4 of the tile and evaluates, for every view that
+    // reaches the tile, that view's spline at its 64 columns of both rows (packed over the rows)
     const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long hw = (long long)h * w, ohw = (long long)hc * wc;
     const int ny = (hc + 7) / 8 + 1, nx = (wc + 63) / 64 + 1;
@@ -348,75 +347,49 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
     mode &= 0xFF;
 #endif
     const int ya = tby * 8 + wv, yb = ya + 4;
-    if (x >= wc || ya >= hc) return;
-    const float gx = linspace_at(-1.f, 1.f, wc, x);
+    if (tbx * 64 >= wc || ya >= hc) return;       // (whole waves only: the lanes past the canvas edge still help build the table)
+    const bool xin = x < wc;
+    const float gx = linspace_at(-1.f, 1.f, wc, min(x, wc - 1));
     if (mask == 0u) {                               // no view reaches this tile: avg_fuse(0, 0) = 0
+        if (xin) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            out[ch * ohw + (long long)ya * wc + x] = 0.f;
-            if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = 0.f;
+            for (int ch = 0; ch < 3; ++ch) {
+                out[ch * ohw + (long long)ya * wc + x] = 0.f;
+                if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = 0.f;
+            }
         }
         return;
     }
-    if ((mask & (mask - 1u)) == 0u) {               // ONE view reaches the tile
-        const int k = mask == 1u ? 0 : (mask == 2u ? 1 : 2);
-        const float gya = linspace_at(-1.f, 1.f, hc, ya), gyb = linspace_at(-1.f, 1.f, hc, min(yb, hc - 1));
-        ss_f2 px, py;
-        tps_eval_two_points(source + k * SS_NV * 2, T + k * 2 * SS_NT, gx, gya, gyb, px, py);
-        const float* in = rv.img[k];
-        float va[3], vb[3];
-        sample3(in, px.x, py.x, w, h, hw, mode, va);
-        sample3(in, px.y, py.y, w, h, hw, mode, vb);
+    // every view that reaches the tile: its spline at this lane's column of the wave's two rows (packed over the rows);
+    // the row-only part of the radial terms comes from a per-wave LDS table (tps_rows_table)
+    __shared__ ss_f2 dytab[4][VIEWS][64];
+    const float gya = linspace_at(-1.f, 1.f, hc, ya), gyb = linspace_at(-1.f, 1.f, hc, min(yb, hc - 1));
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            // the chained fusion with zeros in the other views' places, in the reference's order ((1 (+) 2) (+) 3)
-            float fa, fb;
-            if (k == 0) { fa = avg_fuse(va[ch], 0.f); fb = avg_fuse(vb[ch], 0.f); }
-            else if (k == 1) { fa = avg_fuse(0.f, va[ch]); fb = avg_fuse(0.f, vb[ch]); }
-            else { fa = avg_fuse(avg_fuse(0.f, 0.f), va[ch]); fb = avg_fuse(avg_fuse(0.f, 0.f), vb[ch]); }
-            if (VIEWS == 3 && k < 2) { fa = avg_fuse(fa, 0.f); fb = avg_fuse(fb, 0.f); }
-            out[ch * ohw + (long long)ya * wc + x] = fa;
-            if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = fb;
+    for (int k = 0; k < VIEWS; ++k)
+        if (mask & (1u << k)) tps_rows_table(source + k * SS_NV * 2, gya, gyb, lx, dytab[wv][k]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same wave reads it back: ordering only, no barrier
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float va[VIEWS][3], vb[VIEWS][3];
+#pragma unroll
+    for (int k = 0; k < VIEWS; ++k) {
+        if (mask & (1u << k)) {
+            ss_f2 px, py;
+            tps_eval_rows(source + k * SS_NV * 2, T + k * 2 * SS_NT, dytab[wv][k], gx, gya, gyb, px, py);
+            sample3(rv.img[k], px.x, py.x, w, h, hw, mode, va[k]);
+            sample3(rv.img[k], px.y, py.y, w, h, hw, mode, vb[k]);
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { va[k][ch] = 0.f; vb[k][ch] = 0.f; }
         }
-        return;
     }
-    for (int rr = 0; rr < 2; ++rr) {
-        const int y = rr ? yb : ya;
-        if (y >= hc) break;
-        const float gy = linspace_at(-1.f, 1.f, hc, y);
-        float v[VIEWS][3];
-        float xs[VIEWS], ys[VIEWS];
-        if (VIEWS == 2 || mask == 3u) {
-            ss_f2 px, py;
-            tps_eval_pair(source, source + SS_NV * 2, T, T + 2 * SS_NT, gx, gy, px, py);
-            xs[0] = px.x; xs[1] = px.y; ys[0] = py.x; ys[1] = py.y;
-        } else if (VIEWS == 3 && mask == 5u) {
-            ss_f2 px, py;
-            tps_eval_pair(source, source + 2 * SS_NV * 2, T, T + 4 * SS_NT, gx, gy, px, py);
-            xs[0] = px.x; xs[VIEWS - 1] = px.y; ys[0] = py.x; ys[VIEWS - 1] = py.y;
-        } else if (VIEWS == 3 && mask == 6u) {
-            ss_f2 px, py;
-            tps_eval_pair(source + SS_NV * 2, source + 2 * SS_NV * 2, T + 2 * SS_NT, T + 4 * SS_NT, gx, gy, px, py);
-            xs[1] = px.x; xs[VIEWS - 1] = px.y; ys[1] = py.x; ys[VIEWS - 1] = py.y;
-        } else if (VIEWS == 3) {                    // all three
-            ss_f2 px, py;
-            tps_eval_pair(source, source + SS_NV * 2, T, T + 2 * SS_NT, gx, gy, px, py);
-            xs[0] = px.x; xs[1] = px.y; ys[0] = py.x; ys[1] = py.y;
-            tps_eval_pair(source + 2 * SS_NV * 2, source + 2 * SS_NV * 2, T + 4 * SS_NT, T + 4 * SS_NT, gx, gy, px, py);
-            xs[VIEWS - 1] = px.x; ys[VIEWS - 1] = py.x;
-        }
+    if (!xin) return;
 #pragma unroll
-        for (int k = 0; k < VIEWS; ++k) {
-            if (mask & (1u << k)) sample3(rv.img[k], xs[k], ys[k], w, h, hw, mode, v[k]);
-            else { v[k][0] = 0.f; v[k][1] = 0.f; v[k][2] = 0.f; }
-        }
-        float* o = out + (long long)y * wc + x;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float f = avg_fuse(v[0][ch], v[1][ch]);
-            if (VIEWS == 3) f = avg_fuse(f, v[2][ch]);
-            o[ch * ohw] = f;
-        }
+    for (int ch = 0; ch < 3; ++ch) {
+        // the chained fusion in the reference's order ((1 (+) 2) (+) 3), zeros in the places of views that do not reach
+        float fa = avg_fuse(va[0][ch], va[1][ch]), fb = avg_fuse(vb[0][ch], vb[1][ch]);
+        if (VIEWS == 3) { fa = avg_fuse(fa, va[2][ch]); fb = avg_fuse(fb, vb[2][ch]); }
+        out[ch * ohw + (long long)ya * wc + x] = fa;
+        if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = fb;
     }
 }
 

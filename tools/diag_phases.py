@@ -6,7 +6,7 @@ from stabstitch2_amd import ops, _hip
 import _tuning
 lib = _tuning.lib()
 dev = torch.device('cuda:0')
-SHAPES = {'layer1': (64, 90, 120, 64, 64, 3, 1, 1), 'layer2': (64, 45, 60, 128, 128, 3, 1, 1), 'layer3': (64, 23, 30, 256, 256, 3, 1, 1)}
+SHAPES = {'l2s2': (64, 90, 120, 64, 128, 3, 2, 1), 'l3s2': (64, 45, 60, 128, 256, 3, 2, 1), 'layer1': (64, 90, 120, 64, 64, 3, 1, 1), 'layer2': (64, 45, 60, 128, 128, 3, 1, 1), 'layer3': (64, 23, 30, 256, 256, 3, 1, 1)}
 for name in sys.argv[1].split(','):
     if name == 'stem':          # the 7x7/2 stem on the row-packed 3-channel layout (two trunks' filters: cout 128)
         xs = [torch.randn(16, 3, 360, 480, device=dev)]
