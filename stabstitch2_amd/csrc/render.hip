@@ -46,36 +46,53 @@ __device__ __forceinline__ float fast_mask(float xn, float yn, int w, int h) {
     return r;
 }
 
+// Both rows of a wave (tile = 64 columns x 8 rows, wave w owns rows w and w + 4) through tps_eval_rows: the row-only part
+// of the radial terms from the wave's own LDS table.  -> normalised sampling coordinates of (x, ya) and (x, yb).
+__device__ __forceinline__ void warp_rows_coords(const float* __restrict__ src, const float* __restrict__ T, ss_f2* tab,
+                                                 int lane, int x, int ya, int yb, int hc, int wc, ss_f2& xn, ss_f2& yn) {
+    const float gx = linspace_at(-1.f, 1.f, wc, min(x, wc - 1));
+    const float gya = linspace_at(-1.f, 1.f, hc, ya), gyb = linspace_at(-1.f, 1.f, hc, min(yb, hc - 1));
+    tps_rows_table(src, gya, gyb, lane, tab);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the same wave reads it back: ordering only
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    tps_eval_rows(src, T, tab, gx, gya, gyb, xn, yn);
+}
+
 // append_mask: emit one extra channel = warp of an all-ones plane (test_online_tra.py:144-147)
 __global__ __launch_bounds__(256) void tps_warp_kernel(const float* __restrict__ U, const float* __restrict__ source,
                                                        const float* __restrict__ T, float* __restrict__ out, int c,
                                                        int h, int w, int hc, int wc, int mode, int append_mask) {
+    __shared__ ss_f2 dytab[4][64];
     const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= wc || y >= hc) return;
-    const float* src = source + (long long)b * SS_NV * 2;
-    const float* Tx = T + (long long)b * 2 * SS_NT;
-    const float* Ty = Tx + SS_NT;
-    float gx = linspace_at(-1.f, 1.f, wc, x), gy = linspace_at(-1.f, 1.f, hc, y);
-    float xn, yn;
-    tps_eval_fast(src, Tx, Ty, gx, gy, xn, yn);
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lx;
+    const int ya = blockIdx.y * 8 + wv, yb = ya + 4;
+    if (ya >= hc) return;                       // whole waves only: lanes past the canvas edge still help build the table
+    ss_f2 xn2, yn2;
+    warp_rows_coords(source + (long long)b * SS_NV * 2, T + (long long)b * 2 * SS_NT, dytab[wv], lx, x, ya, yb, hc, wc, xn2, yn2);
+    if (x >= wc) return;
     const long long hw = (long long)h * w, ohw = (long long)hc * wc;
     const int co = c + (append_mask ? 1 : 0);
-    float* o = out + (long long)b * co * ohw + (long long)y * wc + x;
     const float* in = U + (long long)b * c * hw;
-    if (mode == SS_WARP_NORMAL) {
-        SsTaps t = taps_normal(xn, yn, w, h);
-        long long ia = (long long)t.y0 * w + t.x0, ib = (long long)t.y1 * w + t.x0;
-        long long ic = (long long)t.y0 * w + t.x1, id = (long long)t.y1 * w + t.x1;
-        for (int ch = 0; ch < c; ++ch) {
-            const float* pl = in + ch * hw;
-            o[ch * ohw] = blend4(t, pl[ia], pl[ib], pl[ic], pl[id]);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = rr ? yb : ya;
+        if (y >= hc) break;
+        const float xn = rr ? xn2.y : xn2.x, yn = rr ? yn2.y : yn2.x;
+        float* o = out + (long long)b * co * ohw + (long long)y * wc + x;
+        if (mode == SS_WARP_NORMAL) {
+            SsTaps t = taps_normal(xn, yn, w, h);
+            long long ia = (long long)t.y0 * w + t.x0, ib = (long long)t.y1 * w + t.x0;
+            long long ic = (long long)t.y0 * w + t.x1, id = (long long)t.y1 * w + t.x1;
+            for (int ch = 0; ch < c; ++ch) {
+                const float* pl = in + ch * hw;
+                o[ch * ohw] = blend4(t, pl[ia], pl[ib], pl[ic], pl[id]);
+            }
+            if (append_mask) o[c * ohw] = blend4(t, 1.f, 1.f, 1.f, 1.f);
+        } else {
+            for (int ch = 0; ch < c; ++ch) o[ch * ohw] = sample_fast(in + ch * hw, xn, yn, w, h);
+            if (append_mask) o[c * ohw] = fast_mask(xn, yn, w, h);
         }
-        if (append_mask) o[c * ohw] = blend4(t, 1.f, 1.f, 1.f, 1.f);
-    } else {
-        for (int ch = 0; ch < c; ++ch) o[ch * ohw] = sample_fast(in + ch * hw, xn, yn, w, h);
-        if (append_mask) o[c * ohw] = fast_mask(xn, yn, w, h);
     }
 }
 
@@ -84,7 +101,7 @@ static int launch_warp(const float* U, const float* source, const float* T, floa
     if (!U || !source || !T || !out || b <= 0 || c <= 0 || h <= 1 || w <= 1 || hc <= 1 || wc <= 1 ||
         (mode != SS_WARP_NORMAL && mode != SS_WARP_FAST))
         return SS_ERR_ARG;
-    dim3 g(ss_cdiv(wc, 64), ss_cdiv(hc, 4), b);
+    dim3 g(ss_cdiv(wc, 64), ss_cdiv(hc, 8), b);
     hipLaunchKernelGGL(tps_warp_kernel, g, dim3(256), 0, (hipStream_t)stream, U, source, T, out, c, h, w, hc, wc, mode,
                        append_mask);
     return ss_launch_status();
@@ -109,32 +126,38 @@ struct RenderViews {
 __global__ __launch_bounds__(256) void tps_warp_views_kernel(RenderViews rv, const float* __restrict__ source,
                                                              const float* __restrict__ T, float* __restrict__ out,
                                                              int h, int w, int hc, int wc, int mode) {
+    __shared__ ss_f2 dytab[4][64];
     const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= wc || y >= hc) return;
-    const float* src = source + (long long)b * SS_NV * 2;
-    const float* Tx = T + (long long)b * 2 * SS_NT;
-    float gx = linspace_at(-1.f, 1.f, wc, x), gy = linspace_at(-1.f, 1.f, hc, y);
-    float xn, yn;
-    tps_eval_fast(src, Tx, Tx + SS_NT, gx, gy, xn, yn);
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lx;
+    const int ya = blockIdx.y * 8 + wv, yb = ya + 4;
+    if (ya >= hc) return;
+    ss_f2 xn2, yn2;
+    warp_rows_coords(source + (long long)b * SS_NV * 2, T + (long long)b * 2 * SS_NT, dytab[wv], lx, x, ya, yb, hc, wc, xn2, yn2);
+    if (x >= wc) return;
     const long long hw = (long long)h * w, ohw = (long long)hc * wc;
-    float* o = out + (long long)b * 4 * ohw + (long long)y * wc + x;
     const float* in = b == 0 ? rv.img[0] : (b == 1 ? rv.img[1] : rv.img[2]);
-    if (mode == SS_WARP_NORMAL) {
-        SsTaps t = taps_normal(xn, yn, w, h);
-        long long ia = (long long)t.y0 * w + t.x0, ib = (long long)t.y1 * w + t.x0;
-        long long ic = (long long)t.y0 * w + t.x1, id = (long long)t.y1 * w + t.x1;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float* pl = in + ch * hw;
-            o[ch * ohw] = blend4(t, pl[ia], pl[ib], pl[ic], pl[id]);
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = rr ? yb : ya;
+        if (y >= hc) break;
+        const float xn = rr ? xn2.y : xn2.x, yn = rr ? yn2.y : yn2.x;
+        float* o = out + (long long)b * 4 * ohw + (long long)y * wc + x;
+        if (mode == SS_WARP_NORMAL) {
+            SsTaps t = taps_normal(xn, yn, w, h);
+            long long ia = (long long)t.y0 * w + t.x0, ib = (long long)t.y1 * w + t.x0;
+            long long ic = (long long)t.y0 * w + t.x1, id = (long long)t.y1 * w + t.x1;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float* pl = in + ch * hw;
+                o[ch * ohw] = blend4(t, pl[ia], pl[ib], pl[ic], pl[id]);
+            }
+            o[3 * ohw] = blend4(t, 1.f, 1.f, 1.f, 1.f);
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) o[ch * ohw] = sample_fast(in + ch * hw, xn, yn, w, h);
+            o[3 * ohw] = fast_mask(xn, yn, w, h);
         }
-        o[3 * ohw] = blend4(t, 1.f, 1.f, 1.f, 1.f);
-    } else {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) o[ch * ohw] = sample_fast(in + ch * hw, xn, yn, w, h);
-        o[3 * ohw] = fast_mask(xn, yn, w, h);
     }
 }
 
@@ -147,7 +170,7 @@ extern "C" int ss_tps_warp_views(const float* const* imgs, const float* source, 
     for (int i = 0; i < 3; ++i) rv.img[i] = i < views ? imgs[i] : nullptr;
     for (int i = 0; i < views; ++i)
         if (!rv.img[i]) return SS_ERR_ARG;
-    dim3 g(ss_cdiv(wc, 64), ss_cdiv(hc, 4), views);
+    dim3 g(ss_cdiv(wc, 64), ss_cdiv(hc, 8), views);
     hipLaunchKernelGGL(tps_warp_views_kernel, g, dim3(256), 0, (hipStream_t)stream, rv, source, T, out, h, w, hc, wc,
                        mode);
     return ss_launch_status();
