@@ -88,7 +88,7 @@ SS_API int ss_conv_stem3(const float* in_padded, const float* wgt, const float* 
  *   ss_conv3x3_wino_nhwc(...)                in [n][h][w][cin], out [n][h][w][out_cs]; cin % 4 == 0, cout % 64 == 0;
  *                                            bias / res / relu / out_cs / groups as ss_conv_nhwc (u_gs = packed floats per group)
  *   ss_conv_uses_winograd(...)               the engine's own dispatch rule for a layer geometry (1 = Winograd pays:
- *                                            3x3 s1, cin >= 32, cout % 64 == 0, >= 70 % of the tile slots used, >= 512
+ *                                            3x3 s1, cin >= 32, cout % 64 == 0, >= 70 % of the tile slots used, >= 96
  *                                            workgroups); callers may apply any rule, results agree to fp32 rounding */
 SS_API long long ss_wino_packed_floats(int cout, int cin);
 SS_API int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, int groups, void* stream);

@@ -962,7 +962,9 @@ extern "C" int ss_conv_uses_winograd(int kt, int kh, int kw, int stride, int cin
     double eff;
     wino_blocks(ho, wo, tbh, tbw, eff);
     const long long wgs = (long long)images * ss_cdiv((ho + 1) / 2, tbh) * ss_cdiv((wo + 1) / 2, tbw) * (cout / 64);
-    return eff >= 0.70 && wgs >= 512;
+    // >= 96 workgroups: below that the launch is one workgroup deep and its K loop (~2.3 us per chunk) is slower than the
+    // split-K implicit GEMM spread over the whole chip (tools/wino_threshold.py: 256->256 at 23x30 x2: 41 vs 30 us)
+    return eff >= 0.70 && wgs >= 96;
 }
 
 extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
