@@ -176,6 +176,31 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     const unsigned u_wave = (cbk * NB) * (unsigned)p.nchunk * 32768u + (unsigned)wave * 8192u;     // + blk * nchunk * 32 KB
     const unsigned u_blk = (unsigned)p.nchunk * 32768u;
 
+    // epilogue addressing, and the residual's loads (issued inside the last chunk by the stream schedule)
+    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    const __amdgpu_buffer_rsrc_t rout = w_rsrc(out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = w_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
+    // this thread's output items: (pixel, channel quad); BN / 4 quads per pixel -> 128 * BN / 4 / 256 = 4 NB items
+    constexpr int QP = BN / 4, NI = 4 * NB, PSTEP = 256 / QP;
+    const int cq = tid % QP;
+    unsigned goff[NI];
+    w_u32x4 rv[NI];
+    auto res_issue = [&]() {
+#pragma unroll
+        for (int e = 0; e < NI; ++e) {
+            const int px = e * PSTEP + tid / QP;
+            const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
+            const int ty = tile / TBW, tx = tile - ty * TBW;
+            const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + b;
+            const bool ok = oy < p.H && ox < p.W;
+            goff[e] = ok ? ((((unsigned)img * p.H + oy) * p.W + ox) * (unsigned)p.out_cs + cbk * BN + 4u * cq) * 4u : 0xFFFFFFFFu;
+        }
+        if (RES) {
+#pragma unroll
+            for (int e = 0; e < NI; ++e) rv[e] = __builtin_amdgcn_raw_buffer_load_b128(rres, goff[e], 0, 0);
+        }
+    };
+
     w_f32x16 acc[4][NB];
     auto acc_clear = [&]() {
 #pragma unroll
@@ -286,12 +311,13 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         // are transformed; second half: channels 4..7 multiply while channels 0..3 of the NEXT chunk are transformed (its raw
         // patch goes registers -> LDS inside block (0, 2), one barrier per chunk after that block).  Every accumulator sees its
         // (chunk, step) products in the same order as in conv_wino_kernel: the results are bit-identical.
-        for (int c = 0; c < p.nchunk; ++c) {
+        // The LAST chunk is peeled: nothing of a next chunk to stage, transform or request -- the residual's loads take
+        // the freed registers and arrive under its MFMAs instead of in front of the epilogue.
+        for (int c = 0; c + 1 < p.nchunk; ++c) {
             float* bc = smem + (c & 1) * RAWF;                  // raw patch of chunk c
             float* bn = smem + ((c + 1) & 1) * RAWF;            // chunk c + 1
-            // (the last iteration re-requests its own chunk: branch free, results unused)
-            const int cn = c + 1 < p.nchunk ? c + 1 : c;
-            const int cnn = c + 2 < p.nchunk ? c + 2 : cn;
+            const int cn = c + 1;
+            const int cnn = c + 2 < p.nchunk ? c + 2 : cn;      // (the last but one iteration re-requests chunk c + 1: branch free, unused)
             __builtin_amdgcn_sched_barrier(0);
             xf(4); rd(bc, 5); mma(0, 0, 0); u_issue(3, c, 3, 0); W_SGB_BLOCK(0, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -311,6 +337,28 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             xf(2); rd(bn, 3); mma(2, 2, 1); u_issue(1, cn, 1, 0); W_SGB_BLOCK(0, 1);
             __builtin_amdgcn_sched_barrier(0);
             xf(3); rd(bn, 4); mma(3, 3, 1); u_issue(2, cn, 2, 0); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const int c = p.nchunk - 1;
+            float* bc = smem + (c & 1) * RAWF;
+            __builtin_amdgcn_sched_barrier(0);
+            xf(4); rd(bc, 5); mma(0, 0, 0); u_issue(3, c, 3, 0); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(5); rd(bc, 6); mma(1, 1, 0); u_issue(0, c, 0, 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(6); rd(bc, 7); mma(2, 2, 0); u_issue(1, c, 1, 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xf(7); mma(3, 3, 0); u_issue(2, c, 2, 1); W_SGB_BLOCK(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            res_issue();
+            mma(0, 0, 1); u_issue(3, c, 3, 1); W_SGB_BLOCK(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(2, 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(3, 3, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(3);
@@ -422,27 +470,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     // S[i][b][tile][64 couts]; then every thread owns 8 x (pixel, 4 couts), adds the three T rows of its pixel
     // (Y[0][b] = T0 + T1 + T2, Y[1][b] = T1 - T2 - T3, fixed order), bias (folded BatchNorm), residual, ReLU, and
     // global memory sees whole 256-byte pixel rows as 16-byte accesses (out-of-range offsets outside the image).
-    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
-    const __amdgpu_buffer_rsrc_t rout = w_rsrc(out, p.out_bytes);
-    const __amdgpu_buffer_rsrc_t rres = w_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
-    // this thread's output items: (pixel, channel quad); BN / 4 quads per pixel -> 128 * BN / 4 / 256 = 4 NB items
-    constexpr int QP = BN / 4, NI = 4 * NB, PSTEP = 256 / QP;
-    const int cq = tid % QP;
-    unsigned goff[NI];
-    w_u32x4 rv[NI];
-#pragma unroll
-    for (int e = 0; e < NI; ++e) {
-        const int px = e * PSTEP + tid / QP;
-        const int tile = px >> 2, a = (px >> 1) & 1, b = px & 1;
-        const int ty = tile / TBW, tx = tile - ty * TBW;
-        const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + b;
-        const bool ok = oy < p.H && ox < p.W;
-        goff[e] = ok ? ((((unsigned)img * p.H + oy) * p.W + ox) * (unsigned)p.out_cs + cbk * BN + 4u * cq) * 4u : 0xFFFFFFFFu;
-    }
-    if (RES) {
-#pragma unroll
-        for (int e = 0; e < NI; ++e) rv[e] = __builtin_amdgcn_raw_buffer_load_b128(rres, goff[e], 0, 0);
-    }
+    if (!STREAM) res_issue();
     // (RES is a template parameter and ReLU a clamp against 0 / -inf: with uniform branches per item the combine below
     // ran one pixel at a time -- three LDS reads, wait, add, branch, store)
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();

@@ -1014,7 +1014,8 @@ def test_conv_winograd_schedules_bit_identical(dev, request):
     request.addfinalizer(lambda: lib.ss_debug_set(7, 0))
     rs = np.random.RandomState(77)
     for (n, cin, cout, h, w, g) in ((64, 64, 64, 90, 120, 1), (16, 128, 128, 45, 60, 1), (8, 256, 256, 23, 30, 1),
-                                    (3, 36, 64, 37, 53, 1), (1, 32, 128, 8, 8, 1), (5, 160, 64, 11, 15, 2), (2, 20, 64, 3, 5, 1)):
+                                    (3, 36, 64, 37, 53, 1), (1, 32, 128, 8, 8, 1), (5, 160, 64, 11, 15, 2), (2, 20, 64, 3, 5, 1),
+                                    (2, 16, 64, 9, 7, 1), (1, 4, 64, 5, 5, 1)):        # one chunk: the peeled last chunk is the first
         shape = (g, n, h, w, cin) if g > 1 else (n, h, w, cin)
         x = torch.from_numpy(rs.normal(0, 1, shape).astype(np.float32)).to(dev)
         wt = torch.from_numpy((rs.normal(0, 1, ((g,) if g > 1 else ()) + (cout, 1, 3, 3, cin)) / np.sqrt(9 * cin)).astype(np.float32)).to(dev)
