@@ -306,6 +306,20 @@ def other_configs(nets, dev, args):
     entry('720p 2-view fusion LINEAR', n, dt, 3, o[1], o[2])
     dt, o = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets, 'FAST', 'AVERAGE'), sync, 1, 3)
     entry('720p 2-view warp FAST', n, dt, 3, o[1], o[2])
+    # opt-in arithmetic of the Winograd GEMMs: fp32 products formed exactly from three bf16 slices per operand (nine slice
+    # products) on the bf16 matrix pipe, fp32 accumulation (ops.WINO_MATH, csrc/wino.hip SLICED).  NOT the headline.
+    from stabstitch2_amd import ops
+    base = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets)
+    old_math = ops.WINO_MATH
+    ops.WINO_MATH = 'bf16x9'
+    try:
+        dt, o = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets), sync, 2, 5)
+        dm = max(float((o[3] - base[3]).abs().max()), float((o[4] - base[4]).abs().max()))
+        entry('720p 2-view, Winograd GEMMs as exact bf16x9 slice products (opt-in SS_WINO_MATH=bf16x9)', n, dt, 5, o[1], o[2],
+              'every fp32 x fp32 product from 3 bf16 slices per operand, all 9 slice products, fp32 accumulation; smooth meshes '
+              'differ from the fp32-MFMA path by %.1e px (max); canvas %s' % (dm, 'equal' if (o[1], o[2]) == (base[1], base[2]) else 'DIFFERENT'))
+    finally:
+        ops.WINO_MATH = old_math
     # host-to-host: uint8 frames in pinned host memory -> stitched uint8 frames in pinned host memory (H2D + ingest +
     # path + uint8 sink + D2H of every fused frame, as the reference's printed fps includes .cpu())
     u8 = [hr[v].permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).contiguous().cpu().pin_memory() for v in range(2)]

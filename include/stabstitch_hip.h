@@ -91,6 +91,15 @@ SS_API int ss_conv_stem3(const float* in_padded, const float* wgt, const float* 
  *                                            3x3 s1, cin >= 32, cout % 64 == 0, >= 70 % of the tile slots used, >= 96
  *                                            workgroups); callers may apply any rule, results agree to fp32 rounding */
 SS_API long long ss_wino_packed_floats(int cout, int cin);
+/* Opt-in variant of the same convolution: every fp32 x fp32 product is formed EXACTLY from three bf16 slices per operand
+ * (all nine slice products) on the bf16 matrix pipe and accumulated in fp32 -- results agree with ss_conv3x3_wino_nhwc to
+ * fp32 rounding (different accumulation order), not bit for bit.  ss_wino_pack3 slices the transformed filters once
+ * (1.5x the bytes of ss_wino_pack); same argument meaning as the fp32 entry points. */
+SS_API long long ss_wino_packed3_floats(int cout, int cin);
+SS_API int ss_wino_pack3(const float* wgt, float* packed3, int cout, int cin, int groups, void* stream);
+SS_API int ss_conv3x3_wino3_nhwc(const float* in, const float* packed3, const float* bias, const float* res, float* out,
+                          int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
+                          long long in_gs, long long u_gs, long long out_gs, void* stream);
 SS_API int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, int groups, void* stream);
 SS_API int ss_conv_uses_winograd(int kt, int kh, int kw, int stride, int cin, int cout, int ho, int wo, int images);
 SS_API int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,

@@ -91,10 +91,11 @@ typedef float w_f32x2 __attribute__((ext_vector_type(2)));
 // NB = 32-channel output blocks per workgroup: 2 (64 channels, 128 accumulator registers, two workgroups per CU) or
 // 1 (32 channels, 64 accumulator registers, THREE workgroups per CU: the epilogue / prologue of one workgroup hides
 // behind the MFMAs of two others -- the short-K layers (cin = 64: 4 chunks) spend a quarter of a workgroup's life there)
-template <int TBH, int TBW, int NB, bool RES, bool STREAM>
+template <int TBH, int TBW, int NB, bool RES, bool STREAM, bool SLICED = false>
 __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p) {
     static_assert(TBH * TBW == 32, "32 tiles per workgroup");
     static_assert(!STREAM || NB == 2, "the stream schedule is written for 64-channel blocks");
+    static_assert(!SLICED || (NB == 2 && !STREAM), "sliced products: 64-channel blocks, phase-alternating schedule");
     constexpr int BN = 32 * NB;                             // output channels per workgroup
     constexpr int RH = 2 * TBH + 2, RW = 2 * TBW + 2;      // raw input patch (pixels)
     constexpr int RPIX = RH * RW;
@@ -211,6 +212,106 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     };
 
+    if constexpr (SLICED) {
+        // ---- fp32 x fp32 products on the bf16 matrix pipe (opt-in, ss_conv3x3_wino3_nhwc): every operand is the EXACT sum of
+        // three bf16 slices (a = a1 + a2 + a3: 3 x 8 significand bits; the filters are sliced once at pack time, the
+        // transformed input here), and all nine slice products -- each exact in fp32 -- go through
+        // v_mfma_f32_32x32x16_bf16 into the fp32 accumulators: 9 instructions of 8 passes per 16 channels where the fp32
+        // pipe needs 8 instructions of 16 passes.  Nothing of a product is dropped; only the order of the fp32
+        // accumulation differs from the fp32-MFMA kernel (results agree to fp32 rounding, not bit for bit).
+        typedef __bf16 w_bf8 __attribute__((ext_vector_type(8)));
+        typedef __bf16 w_bf2 __attribute__((ext_vector_type(2)));
+        acc_clear();
+        w_f32x4 rr[NE];
+        auto raw_issue = [&](int c) {
+            const unsigned coff = (unsigned)c * 64u;
+            const unsigned cinv = ((c * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                rr[e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0));
+        };
+        // packed filter slices: [cout/32][chunk][pos][slice][lane][8 bf16] -> 3 KB per position, 48 KB per (cout block, chunk)
+        const unsigned u3_wave = (cbk * NB) * (unsigned)p.nchunk * 49152u + (unsigned)wave * 12288u;
+        const unsigned u3_blk = (unsigned)p.nchunk * 49152u;
+        auto u_issue3 = [&](w_u32x4 (&u)[3], int c, int j, int blk) {
+            const int so = (int)__builtin_amdgcn_readfirstlane(u3_wave + (unsigned)c * 49152u + (unsigned)j * 3072u + (unsigned)blk * u3_blk);
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) u[sl] = __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * sl, so, 0);
+        };
+        float av[4][8];
+        const w_f32x2 t_sg = wave == 1 ? (w_f32x2){1.f, 1.f} : (w_f32x2){-1.f, -1.f};
+        auto transform = [&](const float* buf) {
+            const float* src = buf + t_src;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float* pa = src + c * PLANE + t_ra * RWP;
+                const float* pb = src + c * PLANE + t_rb * RWP;
+                const w_f32x2 xa0 = *reinterpret_cast<const w_f32x2*>(pa), xa1 = *reinterpret_cast<const w_f32x2*>(pa + 2);
+                const w_f32x2 xb0 = *reinterpret_cast<const w_f32x2*>(pb), xb1 = *reinterpret_cast<const w_f32x2*>(pb + 2);
+                const w_f32x2 r0 = __builtin_elementwise_fma(xb0, t_sg, xa0);
+                const w_f32x2 r1 = __builtin_elementwise_fma(xb1, t_sg, xa1);
+                const w_f32x2 d = r0 - r1;
+                av[0][c] = d[0];
+                av[1][c] = r0[1] + r1[0];
+                av[2][c] = r1[0] - r0[1];
+                av[3][c] = d[1];
+            }
+        };
+        // the 8 fp32 A operands of position j -> three bf16x8 slices (round to nearest even; the residuals are exact)
+        w_u32x4 as[3];
+        auto split = [&](int j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const w_f32x2 x = {av[j][2 * q], av[j][2 * q + 1]};
+                const w_bf2 p1 = __builtin_convertvector(x, w_bf2);
+                const w_f32x2 r = x - __builtin_convertvector(p1, w_f32x2);
+                const w_bf2 p2 = __builtin_convertvector(r, w_bf2);
+                const w_f32x2 r2 = r - __builtin_convertvector(p2, w_f32x2);
+                const w_bf2 p3 = __builtin_convertvector(r2, w_bf2);
+                as[0][q] = __builtin_bit_cast(unsigned, p1);
+                as[1][q] = __builtin_bit_cast(unsigned, p2);
+                as[2][q] = __builtin_bit_cast(unsigned, p3);
+            }
+        };
+        auto mma9 = [&](int j, int blk, const w_u32x4 (&u)[3]) {
+#pragma unroll
+            for (int sa = 2; sa >= 0; --sa)          // smallest products first
+#pragma unroll
+                for (int sb = 2; sb >= 0; --sb)
+                    acc[j][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w_bf8, as[sa]), __builtin_bit_cast(w_bf8, u[sb]),
+                                                                        acc[j][blk], 0, 0, 0);
+        };
+        w_u32x4 ua[3], ub[3];
+        raw_issue(0);
+        u_issue3(ua, 0, 0, 0);
+        W_STAMP(1);
+        for (int c = 0; c < p.nchunk; ++c) {
+            float* buf = smem + (c & 1) * RAWF;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) buf[rlds[e] + k * PLANE] = rr[e][k];
+            __syncthreads();
+            const int cn = c + 1 < p.nchunk ? c + 1 : c;
+            raw_issue(cn);
+            transform(buf);
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                split(j);
+                __builtin_amdgcn_sched_barrier(0);
+                u_issue3(ub, c, j, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma9(j, 0, ua);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < 3) u_issue3(ua, c, j + 1, 0); else u_issue3(ua, cn, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma9(j, 1, ub);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(3);
+        }
+    } else
     if constexpr (STREAM) {
         w_f32x4 rr[NE];
         auto raw_issue = [&](int c) {
@@ -951,6 +1052,61 @@ __global__ void wino_pack_kernel(const float* __restrict__ wgt, float* __restric
     reinterpret_cast<float4*>(U + (long long)grp * u_gs)[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// Filter slices for the bf16-pipe variant: U = G g G^T in fp64, rounded once to fp32 (the SAME value the fp32 kernel
+// multiplies with), then written as three bf16 slices u1 + u2 + u3 = U exactly, in the B-operand register layout of
+// v_mfma_f32_32x32x16_bf16 (B[k = 8 (lane >> 5) + e][n = lane & 31]):
+//   U3[cout/32][chunk][pos][slice][lane][e] = slice of (G g G^T)[pos] of (cout = 32 cb + (lane & 31), cin = 16 chunk + 8 (lane >> 5) + e)
+__global__ void wino_pack3_kernel(const float* __restrict__ wgt, unsigned* __restrict__ U3, int cout, int cin, int nchunk,
+                                  long long w_gs, long long u_gs) {
+    const long long per = (long long)(cout / 32) * nchunk * 16 * 64;      // (cb, chunk, pos, lane) items; 3 x 16 bytes each
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per) return;
+    const int grp = blockIdx.y;
+    const int lane = (int)(idx & 63);
+    const int pos = (int)((idx >> 6) & 15);
+    const long long cc = idx >> 10;
+    const int chunk = (int)(cc % nchunk);
+    const int cb = (int)(cc / nchunk);
+    const int co = cb * 32 + (lane & 31);
+    const int i = pos >> 2, j = pos & 3;
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    unsigned short sl[3][8];
+    for (int e = 0; e < 8; ++e) {
+        const int ci = chunk * 16 + 8 * (lane >> 5) + e;
+        double a = 0.0;
+        if (ci < cin) {
+            const float* g = wgt + (long long)grp * w_gs + (long long)co * 9 * cin + ci;
+            for (int x = 0; x < 3; ++x)
+                for (int y = 0; y < 3; ++y) a += G[i][x] * (double)g[(x * 3 + y) * cin] * G[j][y];
+        }
+        const float u = (float)a;
+        const __bf16 u1 = (__bf16)u;
+        const float r1 = u - (float)u1;
+        const __bf16 u2 = (__bf16)r1;
+        const __bf16 u3 = (__bf16)(r1 - (float)u2);
+        sl[0][e] = __builtin_bit_cast(unsigned short, u1);
+        sl[1][e] = __builtin_bit_cast(unsigned short, u2);
+        sl[2][e] = __builtin_bit_cast(unsigned short, u3);
+    }
+    unsigned* dst = U3 + (long long)grp * u_gs + ((cc * 16 + pos) * 3) * 256 + lane * 4;       // dwords
+    for (int s3 = 0; s3 < 3; ++s3)
+        for (int q = 0; q < 4; ++q) dst[s3 * 256 + q] = (unsigned)sl[s3][2 * q] | ((unsigned)sl[s3][2 * q + 1] << 16);
+}
+
+extern "C" long long ss_wino_packed3_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || (cout & 31)) return 0;
+    return (long long)(cout / 32) * ss_cdiv(cin, 16) * 16 * 3 * 64 * 4;
+}
+
+extern "C" int ss_wino_pack3(const float* wgt, float* packed, int cout, int cin, int groups, void* stream) {
+    if (!wgt || !packed || cout <= 0 || cin <= 0 || (cout & 31) || (cin & 3) || groups <= 0) return SS_ERR_ARG;
+    const int nchunk = ss_cdiv(cin, 16);
+    const long long per = (long long)(cout / 32) * nchunk * 16 * 64;
+    hipLaunchKernelGGL(wino_pack3_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, (hipStream_t)stream, wgt,
+                       reinterpret_cast<unsigned*>(packed), cout, cin, nchunk, (long long)cout * 9 * cin, per * 12);
+    return ss_launch_status();
+}
+
 extern "C" long long ss_wino_packed_floats(int cout, int cin) {
     if (cout <= 0 || cin <= 0 || (cout & 31)) return 0;
     return (long long)(cout / 32) * ss_cdiv(cin, 16) * 16 * 2 * 64 * 4;
@@ -995,14 +1151,14 @@ extern "C" int ss_conv_uses_winograd(int kt, int kh, int kw, int stride, int cin
     return eff >= 0.70 && wgs >= 96;
 }
 
-extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
-                                    int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
-                                    long long in_gs, long long u_gs, long long out_gs, void* stream) {
+static int wino_launch(const float* in, const float* packed, const float* bias, const float* res, float* out,
+                       int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
+                       long long in_gs, long long u_gs, long long out_gs, void* stream, bool sliced) {
     if (!in || !packed || !out || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || (cin & 3) || cout <= 0 || (cout & 63) ||
         groups <= 0 || out_cs < cout)
         return SS_ERR_ARG;
     const long long in_elems = (long long)n * h * w * cin, out_elems = (long long)n * h * w * out_cs;
-    const long long u_floats = ss_wino_packed_floats(cout, cin);
+    const long long u_floats = sliced ? ss_wino_packed3_floats(cout, cin) : ss_wino_packed_floats(cout, cin);
     if (in_elems * 4 >= (1ll << 32) || out_elems * 4 >= (1ll << 32) || u_floats * 4 >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
     WinoP p;
     p.in = in; p.U = packed; p.bias = bias; p.res = res; p.out = out;
@@ -1016,7 +1172,7 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
     p.nby = (unsigned)ss_cdiv((h + 1) / 2, tbh);
     p.divBx = ss_div32_make(p.nbx);
     p.divBy = ss_div32_make(p.nby);
-    const int nb = cin <= g_wino_nb1_max_cin ? 1 : 2;         // 2 (64-channel blocks) in the product build
+    const int nb = (!sliced && cin <= g_wino_nb1_max_cin) ? 1 : 2;         // 2 (64-channel blocks) in the product build
     p.ncb = (unsigned)(cout / (32 * nb));
     p.divNcb = ss_div32_make(p.ncb);
     p.in_gs = in_gs; p.u_gs = u_gs; p.out_gs = out_gs;
@@ -1032,7 +1188,7 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
     hipStream_t st = (hipStream_t)stream;
 #ifdef SS_TUNING
     // pair kernel (one persistent workgroup per CU, two tile blocks per job): needs >= 2 chunks for its prefetch distance
-    if (g_wino_variant == 2 && nb == 2 && p.nchunk >= 2 && p.nchunk <= 512 && in_elems * 4 <= 0xFFFF0000ll) {
+    if (!sliced && g_wino_variant == 2 && nb == 2 && p.nchunk >= 2 && p.nchunk <= 512 && in_elems * 4 <= 0xFFFF0000ll) {
         p.nmb = (unsigned)((long long)n * p.nbx * p.nby);
         p.njobs = (unsigned)(((long long)p.nmb + 1) / 2 * p.ncb);
         long long cap = (long long)(256 / groups) & ~7ll;
@@ -1049,6 +1205,16 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
     }
 #endif
     dim3 g((unsigned)wgs, 1, groups);
+    if (sliced) {           // fp32 products from three bf16 slices per operand on the bf16 matrix pipe (opt-in entry point)
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, false, true>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, false, true>), g, dim3(256), 0, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, false, true>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, false, true>), g, dim3(256), 0, st, p);
+        }
+        return ss_launch_status();
+    }
 #ifdef SS_TUNING      // 32-channel blocks / three workgroups per CU: measured slower on every layer (tools/diag_wino.py); tools build only
     if (nb == 1) {
         if (tbh == 8) {
@@ -1081,4 +1247,16 @@ extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const 
         else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true>), g, dim3(256), 0, st, p);
     }
     return ss_launch_status();
+}
+
+extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
+                                    int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
+                                    long long in_gs, long long u_gs, long long out_gs, void* stream) {
+    return wino_launch(in, packed, bias, res, out, n, h, w, cin, cout, relu, out_cs, groups, in_gs, u_gs, out_gs, stream, false);
+}
+
+extern "C" int ss_conv3x3_wino3_nhwc(const float* in, const float* packed3, const float* bias, const float* res, float* out,
+                                     int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
+                                     long long in_gs, long long u_gs, long long out_gs, void* stream) {
+    return wino_launch(in, packed3, bias, res, out, n, h, w, cin, cout, relu, out_cs, groups, in_gs, u_gs, out_gs, stream, true);
 }

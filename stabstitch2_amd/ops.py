@@ -97,16 +97,24 @@ def conv_executed_flop_ratio(kt, kh, kw, stride, cin, cout, out_shape):
     return 16.0 / 36.0 if _uses_winograd(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, images) else 1.0
 
 
-def wino_packed(wgt, groups):
+# Arithmetic of the Winograd layers' GEMMs.  'f32' (default): v_mfma_f32_32x32x2_f32.  'bf16x9' (opt-in, SS_WINO_MATH):
+# every fp32 x fp32 product formed exactly from three bf16 slices per operand (nine slice products) on the bf16 matrix
+# pipe, fp32 accumulation -- agrees with 'f32' to fp32 rounding, not bit for bit (csrc/wino.hip, SLICED).
+WINO_MATH = os.environ.get('SS_WINO_MATH', 'f32')
+
+
+def wino_packed(wgt, groups, sliced=False):
     """Transformed + packed filters of a 3x3 weight tensor ([cout,1,3,3,cin] or [g,cout,1,3,3,cin]), built on first use
-    by ss_wino_pack and kept on the tensor (prepared weights are rebuilt, hence re-packed, whenever a net is reloaded)."""
-    pk = getattr(wgt, '_wino_packed', None)
+    by ss_wino_pack / ss_wino_pack3 and kept on the tensor (prepared weights are rebuilt, hence re-packed, whenever a net
+    is reloaded)."""
+    attr = '_wino_packed3' if sliced else '_wino_packed'
+    pk = getattr(wgt, attr, None)
     if pk is None:
         cout, cin = wgt.shape[-5], wgt.shape[-1]
-        per = int(H.lib().ss_wino_packed_floats(cout, cin))
+        per = int((H.lib().ss_wino_packed3_floats if sliced else H.lib().ss_wino_packed_floats)(cout, cin))
         pk = torch.empty((groups, per), device=wgt.device, dtype=torch.float32)
-        H.call('ss_wino_pack', H.dptr(wgt), H.dptr(pk), cout, cin, groups, H.stream())
-        wgt._wino_packed = pk
+        H.call('ss_wino_pack3' if sliced else 'ss_wino_pack', H.dptr(wgt), H.dptr(pk), cout, cin, groups, H.stream())
+        setattr(wgt, attr, pk)
     return pk
 
 
@@ -121,8 +129,9 @@ def conv_winograd(x, wgt, bias=None, res=None, relu=False, out=None):
     n, h, w = x.shape[-4], x.shape[-3], x.shape[-2]
     if out is None:
         out = torch.empty(((g, n, h, w, cout) if grouped else (n, h, w, cout)), device=x.device, dtype=torch.float32)
-    pk = wino_packed(wgt, g)
-    H.call('ss_conv3x3_wino_nhwc', H.dptr(x), H.dptr(pk), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
+    sliced = WINO_MATH == 'bf16x9'
+    pk = wino_packed(wgt, g, sliced)
+    H.call('ss_conv3x3_wino3_nhwc' if sliced else 'ss_conv3x3_wino_nhwc', H.dptr(x), H.dptr(pk), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, h, w, cin, cout, int(relu), out.shape[-1], g, 0 if (shared or not grouped) else x[0].numel(),
            pk.shape[1], out[0].numel() if grouped else 0, H.stream())
     return out

@@ -1034,6 +1034,44 @@ def test_conv_winograd_schedules_bit_identical(dev, request):
             assert torch.equal(prod, outs[0]), 'product and tuning builds differ'
 
 
+def test_conv_winograd_bf16x9_products(dev, golden, hip_nets, clip16, request):
+    """The opt-in arithmetic of the Winograd GEMMs (ops.WINO_MATH = 'bf16x9': every fp32 operand as three exact bf16
+    slices, all nine slice products on the bf16 matrix pipe, fp32 accumulation): against an fp64 convolution it must be
+    no worse than the fp32-MFMA kernel (it forms every product exactly; only the accumulation order differs), and the
+    reference's meshes (G9) must hold at the SAME gates as the default arithmetic."""
+    from stabstitch2_amd import ops, pipeline
+    old = ops.WINO_MATH
+    request.addfinalizer(lambda: setattr(ops, 'WINO_MATH', old))
+    rs = np.random.RandomState(41)
+    for (n, cin, cout, h, w, g) in ((4, 64, 64, 90, 120, 1), (3, 36, 64, 37, 53, 1), (2, 256, 256, 23, 30, 1), (5, 160, 64, 11, 15, 2),
+                                    (2, 16, 64, 9, 7, 1)):
+        shape = (g, n, h, w, cin) if g > 1 else (n, h, w, cin)
+        x = torch.from_numpy(np.maximum(rs.normal(0, 1, shape), 0).astype(np.float32)).to(dev)
+        wt = torch.from_numpy((rs.normal(0, 1, ((g,) if g > 1 else ()) + (cout, 1, 3, 3, cin)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rs.normal(0, 1, ((g,) if g > 1 else ()) + (cout,)).astype(np.float32)).to(dev)
+        r = torch.from_numpy(rs.normal(0, 1, shape[:-1] + (cout,)).astype(np.float32)).to(dev)
+        xs, ws, bs, rs_ = (x, wt, b, r) if g == 1 else (x[1], wt[1], b[1], r[1])
+        ref = F.conv2d(xs.permute(0, 3, 1, 2).double().cpu(), ws[:, 0].permute(0, 3, 1, 2).double().cpu(), bs.double().cpu(),
+                       padding=1).permute(0, 2, 3, 1) + rs_.double().cpu()
+        err = {}
+        for math in ('f32', 'bf16x9'):
+            ops.WINO_MATH = math
+            o = ops.conv_winograd(x, wt, b, r, relu=False)
+            o = o if g == 1 else o[1]
+            err[math] = float((o.double().cpu() - ref).abs().max())
+        ops.WINO_MATH = old
+        scale = max(1.0, float(ref.abs().max()))
+        assert err['bf16x9'] <= 1e-6 * scale, (err, scale)          # observed 2-3e-7 x scale for both
+        assert err['bf16x9'] <= 2.0 * err['f32'] + 1e-7 * scale, err
+    ops.WINO_MATH = 'bf16x9'
+    gg = golden('g9_pipeline')
+    hr, lr = clip16
+    acc = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+    close(acc['smooth_mesh1'], gg['smooth_mesh1'], 5e-3, 'smooth_mesh1 (bf16x9 products)')
+    close(acc['smooth_mesh2'], gg['smooth_mesh2'], 5e-3, 'smooth_mesh2 (bf16x9 products)')
+    close(acc['smooth_path2'], gg['smooth_path2'], 1e-2, 'smooth_path2 (bf16x9 products)')
+
+
 def test_ingest_u8_vs_handworked_cv2_vectors(dev):
     """The HIP front-end against the scalar hand derivation of OpenCV's uint8 INTER_LINEAR (tests/golden/
     cv2_resize_handworked.json, independent of oracle/frame_io.py): lr = resize / 127.5 - 1, bit for bit."""
