@@ -195,6 +195,12 @@ SS_API int ss_tps_warp_views(const float* const* imgs, const float* source, cons
  * (differs from the reference there by that residue, <~ 1e-2 grey levels of machine-dependent noise). */
 SS_API int ss_render_average(const float* const* imgs, const float* source, const float* T, const float* footprint,
                              float* out, int views, int h, int w, int hc, int wc, int mode, void* stream);
+/* the same render from decoded uint8 frames [h][w][3] (cv2.imread's layout, test_online_tra.py:252-258) straight to the
+ * uint8 video frame [hc][wc][3] (`.astype(np.uint8)` of the fused values, :413): bit-identical to ss_ingest_u8 ->
+ * ss_render_average -> ss_canvas_to_u8 without the fp32 frame planes and the fp32 canvas ever being written */
+SS_API int ss_render_average_u8(const unsigned char* const* frames, const float* source, const float* T,
+                         const float* footprint, unsigned char* out, int views, int h, int w, int hc, int wc, int mode,
+                         void* stream);
 /* footprints of frames x views splines (source [frames][views][63][2], T [frames][views][2][66]) on an hc x wc canvas, one
  * launch: per frame ss_render_footprint_floats(views, hc, wc) floats = exactly evaluated sampling coordinates on the
  * lattice of tile corners, the bounding box of each view's control points (its mesh hull) and the frame's tile order

@@ -59,6 +59,7 @@ SIGNATURES = {
     'ss_ingest_u8': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_canvas_to_u8': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_render_average': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_render_average_u8': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
     'ss_render_footprint_floats': (c_ll, [c_i, c_i, c_i]),
     'ss_render_footprints': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
     'ss_linear_blend_workspace_floats': (c_ll, [c_i, c_i]),
@@ -134,9 +135,9 @@ def dptr(t, allow_none=False, dtype=torch.float32):
     return p
 
 
-def ptr_array(tensors):
+def ptr_array(tensors, dtype=torch.float32):
     """`const float* const*` argument: array of device pointers (all tensors checked like `dptr`); carries the device."""
-    ps = [dptr(t) for t in tensors]
+    ps = [dptr(t, dtype=dtype) for t in tensors]
     arr = (ctypes.c_void_p * len(ps))(*[p.value for p in ps])
     arr.dev = ps[0].dev
     if any(p.dev != arr.dev for p in ps):

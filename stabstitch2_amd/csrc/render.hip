@@ -341,13 +341,53 @@ __device__ __forceinline__ void sample3(const float* __restrict__ in, float xn, 
     }
 }
 
+// the same samples from a decoded uint8 frame [h][w][3] (what cv2.imread hands the reference, test_online_tra.py:252-258):
+// uint8 -> fp32 is exact, so the values equal those of sample3 on the converted planes bit for bit
+__device__ __forceinline__ void sample3_u8(const unsigned char* __restrict__ in, float xn, float yn, int w, int h, int mode,
+                                           float (&v)[3]) {
+    if (mode == SS_WARP_NORMAL) {
+        SsTaps t = taps_normal(xn, yn, w, h);
+        const long long ia = ((long long)t.y0 * w + t.x0) * 3, ib = ((long long)t.y1 * w + t.x0) * 3;
+        const long long ic = ((long long)t.y0 * w + t.x1) * 3, id = ((long long)t.y1 * w + t.x1) * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            v[ch] = blend4(t, (float)in[ia + ch], (float)in[ib + ch], (float)in[ic + ch], (float)in[id + ch]);
+    } else {
+        float x = ((xn + 1.f) / 2.f) * (float)(w - 1);
+        float y = ((yn + 1.f) / 2.f) * (float)(h - 1);
+        float xf = fminf(fmaxf(floorf(x), -4.f), (float)w + 4.f);
+        float yf = fminf(fmaxf(floorf(y), -4.f), (float)h + 4.f);
+        int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
+        float w00 = (xf + 1.f - x) * (yf + 1.f - y), w01 = (x - xf) * (yf + 1.f - y);
+        float w10 = (xf + 1.f - x) * (y - yf), w11 = (x - xf) * (y - yf);
+        bool vx0 = (unsigned)x0 < (unsigned)w, vx1 = (unsigned)x1 < (unsigned)w;
+        bool vy0 = (unsigned)y0 < (unsigned)h, vy1 = (unsigned)y1 < (unsigned)h;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {            // sample_fast, term by term
+            float r = 0.f;
+            if (vx0 && vy0) r += (float)in[((long long)y0 * w + x0) * 3 + ch] * w00;
+            if (vx1 && vy0) r += (float)in[((long long)y0 * w + x1) * 3 + ch] * w01;
+            if (vx0 && vy1) r += (float)in[((long long)y1 * w + x0) * 3 + ch] * w10;
+            if (vx1 && vy1) r += (float)in[((long long)y1 * w + x1) * 3 + ch] * w11;
+            v[ch] = r;
+        }
+    }
+}
+__device__ __forceinline__ unsigned char render_to_u8(float v) {          // `.astype(np.uint8)` (frameio.hip to_u8)
+    if (!(fabsf(v) < 2147483648.f)) return 0;
+    return (unsigned char)((unsigned)((int)v) & 255u);
+}
+
 // fp == nullptr: every view is evaluated at every pixel (the reference's arithmetic everywhere, residues included);
 // otherwise tiles are classified by `tile_views` and a view that cannot reach a tile contributes exactly 0 there.
-template <int VIEWS>
+// U8: frames are decoded uint8 [h][w][3] and the canvas is written as the video frame uint8 [hc][wc][3] (`.astype(np.uint8)`
+// of the fused values, test_online_tra.py:413) -- the fp32 frame planes and the fp32 canvas never exist in memory.
+template <int VIEWS, bool U8>
 __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, const float* __restrict__ source,
                                                              const float* __restrict__ T, const float* __restrict__ fp,
                                                              float* __restrict__ out, int h, int w, int hc, int wc,
                                                              int mode) {
+    unsigned char* const out8 = reinterpret_cast<unsigned char*>(out);
     // workgroup = 64 x 8 canvas pixels; wave w owns rows w and w + 4 of the tile and evaluates, for every view that
     // reaches the tile, that view's spline at its 64 columns of both rows (packed over the rows)
     const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -377,8 +417,13 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
         if (xin) {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                out[ch * ohw + (long long)ya * wc + x] = 0.f;
-                if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = 0.f;
+                if (U8) {
+                    out8[((long long)ya * wc + x) * 3 + ch] = 0;
+                    if (yb < hc) out8[((long long)yb * wc + x) * 3 + ch] = 0;
+                } else {
+                    out[ch * ohw + (long long)ya * wc + x] = 0.f;
+                    if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = 0.f;
+                }
             }
         }
         return;
@@ -398,8 +443,14 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
         if (mask & (1u << k)) {
             ss_f2 px, py;
             tps_eval_rows(source + k * SS_NV * 2, T + k * 2 * SS_NT, dytab[wv][k], gx, gya, gyb, px, py);
-            sample3(rv.img[k], px.x, py.x, w, h, hw, mode, va[k]);
-            sample3(rv.img[k], px.y, py.y, w, h, hw, mode, vb[k]);
+            if (U8) {
+                const unsigned char* img8 = reinterpret_cast<const unsigned char*>(rv.img[k]);
+                sample3_u8(img8, px.x, py.x, w, h, mode, va[k]);
+                sample3_u8(img8, px.y, py.y, w, h, mode, vb[k]);
+            } else {
+                sample3(rv.img[k], px.x, py.x, w, h, hw, mode, va[k]);
+                sample3(rv.img[k], px.y, py.y, w, h, hw, mode, vb[k]);
+            }
         } else {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { va[k][ch] = 0.f; vb[k][ch] = 0.f; }
@@ -411,13 +462,18 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
         // the chained fusion in the reference's order ((1 (+) 2) (+) 3), zeros in the places of views that do not reach
         float fa = avg_fuse(va[0][ch], va[1][ch]), fb = avg_fuse(vb[0][ch], vb[1][ch]);
         if (VIEWS == 3) { fa = avg_fuse(fa, va[2][ch]); fb = avg_fuse(fb, vb[2][ch]); }
-        out[ch * ohw + (long long)ya * wc + x] = fa;
-        if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = fb;
+        if (U8) {
+            out8[((long long)ya * wc + x) * 3 + ch] = render_to_u8(fa);
+            if (yb < hc) out8[((long long)yb * wc + x) * 3 + ch] = render_to_u8(fb);
+        } else {
+            out[ch * ohw + (long long)ya * wc + x] = fa;
+            if (yb < hc) out[ch * ohw + (long long)yb * wc + x] = fb;
+        }
     }
 }
 
-extern "C" int ss_render_average(const float* const* imgs, const float* source, const float* T, const float* footprint,
-                                 float* out, int views, int h, int w, int hc, int wc, int mode, void* stream) {
+static int render_average_launch(const void* const* imgs, const float* source, const float* T, const float* footprint,
+                                 void* out, int views, int h, int w, int hc, int wc, int mode, void* stream, bool u8) {
     if (!imgs || !source || !T || !out || (views != 2 && views != 3) || h <= 1 || w <= 1 || hc <= 1 || wc <= 1 ||
         ((mode & 0xFF) != SS_WARP_NORMAL && (mode & 0xFF) != SS_WARP_FAST))
         return SS_ERR_ARG;
@@ -425,16 +481,33 @@ extern "C" int ss_render_average(const float* const* imgs, const float* source, 
     if (mode >> 8) return SS_ERR_ARG;
 #endif
     RenderViews rv;
-    for (int i = 0; i < 3; ++i) rv.img[i] = i < views ? imgs[i] : nullptr;
+    for (int i = 0; i < 3; ++i) rv.img[i] = i < views ? static_cast<const float*>(imgs[i]) : nullptr;
     for (int i = 0; i < views; ++i)
         if (!rv.img[i]) return SS_ERR_ARG;
     dim3 g(ss_cdiv(wc, 64) * ss_cdiv(hc, 8), 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (views == 2)
-        hipLaunchKernelGGL((render_average_kernel<2>), g, dim3(256), 0, st, rv, source, T, footprint, out, h, w, hc, wc, mode);
-    else
-        hipLaunchKernelGGL((render_average_kernel<3>), g, dim3(256), 0, st, rv, source, T, footprint, out, h, w, hc, wc, mode);
+    float* o = static_cast<float*>(out);
+    if (views == 2) {
+        if (u8) hipLaunchKernelGGL((render_average_kernel<2, true>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
+        else hipLaunchKernelGGL((render_average_kernel<2, false>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
+    } else {
+        if (u8) hipLaunchKernelGGL((render_average_kernel<3, true>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
+        else hipLaunchKernelGGL((render_average_kernel<3, false>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
+    }
     return ss_launch_status();
+}
+
+extern "C" int ss_render_average(const float* const* imgs, const float* source, const float* T, const float* footprint,
+                                 float* out, int views, int h, int w, int hc, int wc, int mode, void* stream) {
+    return render_average_launch(reinterpret_cast<const void* const*>(imgs), source, T, footprint, out, views, h, w, hc, wc,
+                                 mode, stream, false);
+}
+
+extern "C" int ss_render_average_u8(const unsigned char* const* frames, const float* source, const float* T,
+                                    const float* footprint, unsigned char* out, int views, int h, int w, int hc, int wc,
+                                    int mode, void* stream) {
+    return render_average_launch(reinterpret_cast<const void* const*>(frames), source, T, footprint, out, views, h, w, hc,
+                                 wc, mode, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------

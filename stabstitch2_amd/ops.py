@@ -368,6 +368,21 @@ def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None, footprint=N
     return out
 
 
+def render_average_u8(frames, source, T, hc, wc, mode='NORMAL', out=None, footprint=None):
+    """The fused AVERAGE render straight from decoded uint8 frames to the uint8 video frame: frames = list of 2|3 device
+    tensors [h,w,3] uint8 (cv2 channel order); -> uint8 [hc,wc,3] = `.astype(np.uint8)` of the fused values.  Equal,
+    bit for bit, to ingest (uint8 -> fp32 planes) + render_average + canvas_to_u8; the fp32 planes and canvas are never
+    written."""
+    v = len(frames)
+    h, w = frames[0].shape[0], frames[0].shape[1]
+    arr = H.ptr_array(frames, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((hc, wc, 3), device=frames[0].device, dtype=torch.uint8)
+    H.call('ss_render_average_u8', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(footprint, True), _u8ptr(out), v, h, w, hc, wc,
+           MODES[mode], H.stream())
+    return out
+
+
 def tps_warp_views(imgs, source, T, hc, wc, mode='NORMAL'):
     """imgs: list of V <= 3 device tensors [1,3,h,w] / [3,h,w] -> [V,4,hc,wc] (3 colour planes + ones-mask plane)."""
     v = len(imgs)

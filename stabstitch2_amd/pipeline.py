@@ -411,9 +411,46 @@ def to_video_frames(frames, to_host=False):
     return u8.cpu().numpy() if to_host else u8
 
 
+# uint8 end to end: the AVERAGE render samples the decoded uint8 frames and writes the uint8 video frame itself
+# (ss_render_average_u8) -- per 720p frame pair 22 MB of fp32 frame planes and 17 + 17 MB of fp32 canvas traffic less,
+# bit-identical output.  SS_U8_FUSED=0 (or fusion LINEAR) goes through fp32 planes / canvas + ss_canvas_to_u8.
+U8_FUSED = os.environ.get('SS_U8_FUSED', '1') == '1'
+
+
+@torch.no_grad()
+def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None):
+    """frame_lists: V device tensors [N,H,W,3] uint8; meshes: V tensors [1,N,7,9,2] -> (uint8 [N,Hc,Wc,3], Hc, Wc):
+    `render_frames(..., 'AVERAGE')` followed by `to_video_frames`, fused."""
+    v = len(frame_lists)
+    n = meshes[0].shape[1]
+    img_h, img_w = frame_lists[0].shape[1], frame_lists[0].shape[2]
+    hc, wc, src, T = render_plan(meshes, img_h, img_w)
+    if out is None:
+        out = torch.empty((n, hc, wc, 3), device=meshes[0].device, dtype=torch.uint8)
+    fp = ops.render_footprints(src, T, img_h, img_w, hc, wc) if SKIP_OUTSIDE else None
+    for i in range(n):
+        ops.render_average_u8([frame_lists[k][i] for k in range(v)], src[i], T[i], hc, wc, warp_mode, out=out[i],
+                              footprint=None if fp is None else fp[i])
+    return out, hc, wc
+
+
+def _as_device_u8(frames, device):
+    if not torch.is_tensor(frames):
+        frames = torch.from_numpy(frames)
+    return frames.to(device, non_blocking=True).contiguous()
+
+
 @torch.no_grad()
 def run_two_view_u8(frames1, frames2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', device='cuda', to_host=False):
     """uint8 in, uint8 out: ingest -> estimate -> render -> video frames.  -> (uint8 [N,Hc,Wc,3], Hc, Wc, m1, m2)."""
+    if U8_FUSED and fusion_mode == 'AVERAGE':
+        f1, f2 = _as_device_u8(frames1, device), _as_device_u8(frames2, device)
+        _, lr1 = ops.ingest_u8(f1, want_hr=False)
+        _, lr2 = ops.ingest_u8(f2, want_hr=False)
+        acc = estimate_meshes(nets, lr1, lr2)
+        m1, m2 = acc['smooth_mesh1'], acc['smooth_mesh2']
+        u8, hc, wc = render_frames_u8([f1, f2], [m1, m2], warp_mode)
+        return (u8.cpu().numpy() if to_host else u8), hc, wc, m1, m2
     hr1, lr1 = load_frames_u8(frames1, device=device)
     hr2, lr2 = load_frames_u8(frames2, device=device)
     frames, hc, wc, m1, m2 = run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode, fusion_mode)
@@ -451,10 +488,16 @@ class HostClipRunner:
             for t in d:
                 t.record_stream(self.comp)
             d = [t if t.is_contiguous() else t.contiguous() for t in d]
-            hr1, lr1 = ops.ingest_u8(d[0])
-            hr2, lr2 = ops.ingest_u8(d[1])
-            frames, hc, wc, _, _ = run_two_view(hr1, hr2, lr1, lr2, self.nets, self.warp_mode, self.fusion_mode)
-            u8 = ops.canvas_to_u8(frames)
+            if U8_FUSED and self.fusion_mode == 'AVERAGE':
+                _, lr1 = ops.ingest_u8(d[0], want_hr=False)
+                _, lr2 = ops.ingest_u8(d[1], want_hr=False)
+                acc = estimate_meshes(self.nets, lr1, lr2)
+                u8, hc, wc = render_frames_u8(d, [acc['smooth_mesh1'], acc['smooth_mesh2']], self.warp_mode)
+            else:
+                hr1, lr1 = ops.ingest_u8(d[0])
+                hr2, lr2 = ops.ingest_u8(d[1])
+                frames, hc, wc, _, _ = run_two_view(hr1, hr2, lr1, lr2, self.nets, self.warp_mode, self.fusion_mode)
+                u8 = ops.canvas_to_u8(frames)
             ev2 = torch.cuda.Event()
             ev2.record(self.comp)
         return u8, hc, wc, ev2

@@ -546,6 +546,30 @@ def test_u8_pipeline_matches_float_pipeline(dev, hip_nets):
     want = np.stack([FIO.to_video_frame(f) for f in ref.cpu().numpy()])
     assert out.dtype == torch.uint8 and tuple(out.shape) == (9, hc, wc, 3)
     assert np.array_equal(out.cpu().numpy(), want)
+    # the render that samples the uint8 frames and writes the uint8 video frame itself (default) against the three-step
+    # route ingest -> fp32 render -> ss_canvas_to_u8: equal bytes, both warp modes, with and without footprints
+    assert pipeline.U8_FUSED
+    for wm in ('NORMAL', 'FAST'):
+        for skip in (True, False):
+            old_skip, pipeline.SKIP_OUTSIDE = pipeline.SKIP_OUTSIDE, skip
+            try:
+                fused = pipeline.run_two_view_u8(u8[0], u8[1], hip_nets, warp_mode=wm, device=dev)[0]
+                pipeline.U8_FUSED = False
+                steps = pipeline.run_two_view_u8(u8[0], u8[1], hip_nets, warp_mode=wm, device=dev)[0]
+            finally:
+                pipeline.U8_FUSED = True
+                pipeline.SKIP_OUTSIDE = old_skip
+            assert torch.equal(fused, steps), (wm, skip)
+    # three views through the same kernel
+    from stabstitch2_amd import ops
+    f3 = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in u8] + [torch.from_numpy(np.ascontiguousarray(u8[0][:, :, ::-1])).to(dev)]
+    src = torch.stack([pipeline.get_norm_mesh(pipeline.get_rigid_mesh(1, 540, 720, device=dev) + 3.0 * k, 560, 760)[0] for k in range(3)])
+    tgt = pipeline.get_norm_mesh(pipeline.get_rigid_mesh(1, 540, 720, device=dev), 540, 720).expand(3, -1, -1).contiguous()
+    T = ops.tps_solve(src.contiguous(), tgt)
+    planes = [ops.ingest_u8(f[:1])[0][0] for f in f3]
+    want3 = ops.canvas_to_u8(ops.render_average(planes, src, T, 560, 760).unsqueeze(0))[0]
+    got3 = ops.render_average_u8([f[0] for f in f3], src, T, 560, 760)
+    assert torch.equal(got3, want3)
 
 
 def test_host_clip_runner_overlapped_copies(dev, hip_nets):
