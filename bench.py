@@ -527,7 +527,8 @@ def main():
         'config': {'workload': '%s: %dx%d %d-view, %d-frame clip per step per GPU, 7-frame SmoothWarp sliding '
                                'window, warp %s / fusion %s, %s' % (
                                    ('streaming (batch 1) ' if args.online else '') + ('' if args.io == 'f32' else '[io=%s] ' % args.io) +
-                                   ('configs[4]' if args.views == 3 else ('configs[2]' if args.height == 720 else 'configs[1]'))
+                                   ('configs[4]' if args.views == 3 else ('configs[2]' if (args.height, args.width) == (720, 1280) else
+                                    ('configs[1]' if (args.height, args.width) == (360, 480) else 'custom size')))
                                    + (' x %d GPUs = configs[3]' % world if world > 1 else ''),
                                    args.height, args.width, args.views, args.frames, args.warp_mode, args.fusion_mode,
                                    build_nets.weights),
