@@ -1058,6 +1058,29 @@ def test_conv_winograd_schedules_bit_identical(dev, request):
             assert torch.equal(prod, outs[0]), 'product and tuning builds differ'
 
 
+def test_wino_pack3_slices_sum_exactly(dev):
+    """ss_wino_pack3 against ss_wino_pack: the three bf16 slices of every transformed filter value add up to EXACTLY the
+    fp32 value the fp32 kernel multiplies with (fp32 adds of the slices are exact: 8 + 8 + 8 significand bits), for a
+    channel tail (cin = 36 -> 3 chunks, zero padding) and a grouped pack."""
+    from stabstitch2_amd import ops
+    rs = np.random.RandomState(9)
+    for (g, cout, cin) in ((1, 64, 36), (2, 128, 64), (1, 64, 256)):
+        wt = torch.from_numpy(rs.normal(0, 1, ((g,) if g > 1 else ()) + (cout, 1, 3, 3, cin)).astype(np.float32)).to(dev)
+        if g == 1:
+            wt_ = wt
+        else:
+            wt_ = wt
+        p1 = ops.wino_packed(wt_, g, sliced=False)
+        p3 = ops.wino_packed(wt_, g, sliced=True)
+        nchunk = (cin + 15) // 16
+        a = p1.view(g, cout // 32, nchunk, 16, 2, 64, 4).permute(0, 1, 2, 3, 5, 4, 6).reshape(g, cout // 32, nchunk, 16, 64, 8)
+        b = p3.view(torch.bfloat16).view(g, cout // 32, nchunk, 16, 3, 64, 8).float()
+        s12 = b[:, :, :, :, 0] + b[:, :, :, :, 1]
+        tot = s12 + b[:, :, :, :, 2]
+        assert torch.equal(tot, a), (g, cout, cin, float((tot - a).abs().max()))
+        assert float(b[:, :, :, :, 1].abs().max()) <= float(b[:, :, :, :, 0].abs().max()) * 2.0 ** -7      # the slices descend
+
+
 def test_conv_winograd_bf16x9_products(dev, golden, hip_nets, clip16, request):
     """The opt-in arithmetic of the Winograd GEMMs (ops.WINO_MATH = 'bf16x9': every fp32 operand as three exact bf16
     slices, all nine slice products on the bf16 matrix pipe, fp32 accumulation): against an fp64 convolution it must be
