@@ -126,6 +126,17 @@ class ConvProbe:
             print('%10d %5d %5d %5d %4d %9.3f %9.2f %7.1f' % (key + (a[0], a[1], a[2] / 1e9, a[2] / a[1] / 1e9)),
                   file=sys.stderr)
 
+    def by_kernel(self):
+        """-> {kernel family: (launches, ms, executed flop, direct-equivalent flop)}: 'conv_wino_kernel' = the launches the
+        engine's dispatch rule sends to the Winograd kernel, 'conv_igemm_kernel' = the rest."""
+        out = {}
+        for e0, e1, m, cout, taps, cin, nbytes, xr in self.records:
+            k = 'conv_wino_kernel' if xr < 1.0 else 'conv_igemm_kernel'
+            a = out.setdefault(k, [0, 0.0, 0.0, 0.0])
+            f = 2.0 * m * cout * taps * self._real_cin(cin, taps)
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f * xr; a[3] += f
+        return out
+
     def summary(self):
         """-> (ms, direct-conv-equivalent flop, launches, algorithmic bytes, executed MFMA flop)."""
         tot_ms, tot_flop, n, tot_bytes, tot_exec = 0.0, 0.0, 0, 0.0, 0.0
@@ -548,6 +559,14 @@ def main():
                      'algorithmic_bytes_per_launch': round(conv_bytes / max(conv_n, 1)),
                      'avg_launch_us': round(conv_ms * 1e3 / max(conv_n, 1), 2),
                      'kernel_ms_per_step': round(conv_ms, 3),
+                     # the two kernels of the engine separately (HIP events of the same step; avg_us agrees with the kernels'
+                     # average durations in profiles/r02_kernel_stats.txt)
+                     'per_kernel': {k: {'launches_per_step': v[0], 'avg_launch_us': round(v[1] * 1e3 / max(v[0], 1), 2),
+                                        'ms_per_step': round(v[1], 3),
+                                        'achieved_tflops_executed': round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0,
+                                        'frac': round(v[2] / (v[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if v[1] > 0 else 0.0,
+                                        'direct_conv_equivalent_tflops': round(v[3] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0}
+                                    for k, v in probe.by_kernel().items()},
                      'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5),
                      # whole path against the MFMA roof: 41.31 GFLOP of dense contraction per 2-view frame
                      'path_mfma_frac': round(fps / world * 41.31e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if args.views == 2 else None},
