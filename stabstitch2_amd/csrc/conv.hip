@@ -163,11 +163,16 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
             // table mode, <= 32 taps: bit (dt*kh + dh)*kw + dw SET where the tap falls outside the input
             unsigned valid = 0u;
             const unsigned mw = msk & 0xFFu;
-            for (int dt = 0; dt < p.kt; ++dt)
-                for (int dh = 0; dh < p.kh; ++dh) {
-                    const unsigned sel = 0u - ((msk >> (8 + dh)) & (msk >> (16 + dt)) & 1u);
-                    valid |= (mw << ((dt * p.kh + dh) * p.kw)) & sel;
-                }
+            if (p.kw == 1 && p.kt == 1) {
+                // one tap column (the row-packed stem, 1x1 convs): the tap bits are the valid-dh bits themselves
+                valid = (mw & (msk >> 16) & 1u) ? ((msk >> 8) & 0xFFu) : 0u;
+            } else {
+                for (int dt = 0; dt < p.kt; ++dt)
+                    for (int dh = 0; dh < p.kh; ++dh) {
+                        const unsigned sel = 0u - ((msk >> (8 + dh)) & (msk >> (16 + dt)) & 1u);
+                        valid |= (mw << ((dt * p.kh + dh) * p.kw)) & sel;
+                    }
+            }
             inv_lo = ~valid;
         } else if (AMODE == 2) {
             unsigned long long valid = 0ull;
