@@ -59,7 +59,7 @@ struct ConvP {
     unsigned in_bytes, w_bytes;      // per-group extents for the buffer descriptors
 #ifdef SS_TUNING                     // tools/ build only (csrc/build.sh tuning): never in the shipped library
     unsigned long long* dbg;         // ss_debug_ptr: per-workgroup phase timestamps, or nullptr
-    int ablate;                      // ss_debug_set key 1: 8 = row-major tile order instead of XCD-aware, 32 = no setprio
+    int ablate;                      // ss_debug_set key 1: 8 = row-major tile order instead of XCD-aware, 32 = no setprio, 64 = no epilogue
 #endif
 };
 
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
     // dropped), all residual loads are issued before the first use and all stores after the last.  (The first
     // version tested `m < M` per row and the compiler serialised load -> wait -> store 16 times: 44k cycles per
     // workgroup beside a 75k-cycle K loop.)
+    if (SS_ABLATE(p, 64)) return;                 // tuning build: no epilogue at all (wrong results; what would a free epilogue buy?)
     const bool direct = p.splits == 1;
     float* __restrict__ out = direct ? p.out + (long long)grp * p.out_gs
                                      : p.partial + (long long)blockIdx.z * p.M * p.Co;

@@ -10,7 +10,7 @@ dev = torch.device('cuda:0')
 xs = [torch.randn(16, 3, 360, 480, device=dev)]
 buf = ops.stem_input(xs); wt = torch.randn(128, 7, 24, device=dev) * 0.05; b = torch.randn(128, device=dev)
 ref = None
-for key in (0, 5, 7, 16) * 4:
+for key in (0, 16):
     lib.ss_debug_set(0, key)
     for _ in range(3): out = ops.conv_stem(buf, wt, b, relu=True)
     torch.cuda.synchronize()
@@ -22,3 +22,13 @@ for key in (0, 5, 7, 16) * 4:
     if ref is None: ref = out.clone()
     print('tile key %2d: %.1f us  (%.1f TF/s on 147 real products)  max|diff vs rule| %.3g' % (key, us, 2.0 * out.numel() * 147 / us / 1e6, (out - ref).abs().max().item()))
 lib.ss_debug_set(0, 0)
+for ab in (0, 64, 0, 64):
+    lib.ss_debug_set(1, ab)
+    for _ in range(3): out = ops.conv_stem(buf, wt, b, relu=True)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30): out = ops.conv_stem(buf, wt, b, relu=True)
+    e1.record(); torch.cuda.synchronize()
+    print('ablation %d: %.1f us' % (ab, e0.elapsed_time(e1) / 30 * 1e3))
+lib.ss_debug_set(1, 0)
