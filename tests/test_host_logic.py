@@ -203,3 +203,15 @@ def test_bench_self_launches_ranks_and_gathers():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub-step-ms', '1'],
                         capture_output=True, text=True, env=env2, timeout=120)
     assert r2.returncode != 0 and 'WORLD_SIZE=4' in (r2.stderr + r2.stdout)
+
+
+def test_default_switches_are_the_measured_configuration():
+    """The headline number is plain fp32 MFMA arithmetic with every default optimisation on; the opt-in bf16-slice
+    products must stay opt-in (a default flipped by accident would change what `dtype: f32` of the bench line means)."""
+    if any(k in os.environ for k in ('SS_WINO_MATH', 'SS_WINOGRAD', 'SS_SKIP_OUTSIDE', 'SS_U8_FUSED')):
+        pytest.skip('an A/B switch is set in the environment')
+    from stabstitch2_amd import ops, pipeline
+    assert ops.WINO_MATH == 'f32' and ops.WINOGRAD is True
+    assert pipeline.SKIP_OUTSIDE is True and pipeline.U8_FUSED is True
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert "'dtype': 'f32'" in src
