@@ -158,6 +158,9 @@ SS_API int ss_homo_warp_nchw(const float* in, const float* theta, float* out, in
  *      utils/torch_tps_transform_point.py:21-125) -------------------------------------------- */
 /* source, target [n][63][2] (normalised) -> T [n][2][66]; fp32 kernel matrix, fp64 solve. */
 SS_API int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream);
+/* n control-point sets source [n][63][2] against ONE shared target [63][2] (the render's splines: every frame's warped mesh
+ * maps onto the same rigid mesh, test_online_tra.py:129-137) -> T [n][2][66]; no broadcast copy of the target. */
+SS_API int ss_tps_solve_shared_target(const float* source, const float* target, float* T, int n, void* stream);
 /* point [n][q][2] evaluated through (source, T) -> out [n][q][2] */
 SS_API int ss_tps_points(const float* point, const float* source, const float* T, float* out, int n, int q,
                   void* stream);
@@ -192,20 +195,35 @@ SS_API int ss_tps_warp_views(const float* const* imgs, const float* source, cons
  * footprint: NULL = every view is evaluated at every canvas pixel (the reference's arithmetic everywhere, including the
  * rounding residue its clamped sampler returns outside a view's image); or this frame's block of ss_render_footprints:
  * 64 x 8-pixel tiles outside a view's mesh hull skip its 63-term spline and take its contribution as exactly 0
- * (differs from the reference there by that residue, <~ 1e-2 grey levels of machine-dependent noise). */
+ * (differs from the reference there by that residue, <~ 1e-2 grey levels of machine-dependent noise).
+ * footprint_floats: size of that block; must equal ss_render_footprint_floats(views, hc, wc) (a block built for another
+ * canvas or view count is SS_ERR_ARG, not an out-of-bounds read); ignored when footprint is NULL. */
 SS_API int ss_render_average(const float* const* imgs, const float* source, const float* T, const float* footprint,
-                             float* out, int views, int h, int w, int hc, int wc, int mode, void* stream);
+                             long long footprint_floats, float* out, int views, int h, int w, int hc, int wc, int mode,
+                             void* stream);
 /* the same render from decoded uint8 frames [h][w][3] (cv2.imread's layout, test_online_tra.py:252-258) straight to the
  * uint8 video frame [hc][wc][3] (`.astype(np.uint8)` of the fused values, :413): bit-identical to ss_ingest_u8 ->
  * ss_render_average -> ss_canvas_to_u8 without the fp32 frame planes and the fp32 canvas ever being written */
 SS_API int ss_render_average_u8(const unsigned char* const* frames, const float* source, const float* T,
-                         const float* footprint, unsigned char* out, int views, int h, int w, int hc, int wc, int mode,
-                         void* stream);
+                         const float* footprint, long long footprint_floats, unsigned char* out, int views, int h, int w,
+                         int hc, int wc, int mode, void* stream);
+/* a whole clip in ONE launch (the frame loop of get_stable_sqe, test_online_tra.py:127-152): views_base = host array of
+ * `views` device pointers to [frames][3][h][w] fp32; source [frames][views][63][2]; T [frames][views][2][66]; footprint
+ * [frames][footprint_floats] or NULL; out [frames][3][hc][wc].  Bit-identical to `frames` calls of ss_render_average. */
+SS_API int ss_render_average_clip(const float* const* views_base, const float* source, const float* T,
+                           const float* footprint, long long footprint_floats, float* out, int frames, int views, int h,
+                           int w, int hc, int wc, int mode, void* stream);
+/* the same from decoded uint8 clips [frames][h][w][3] per view to uint8 video frames [frames][hc][wc][3] */
+SS_API int ss_render_average_clip_u8(const unsigned char* const* views_base, const float* source, const float* T,
+                              const float* footprint, long long footprint_floats, unsigned char* out, int frames,
+                              int views, int h, int w, int hc, int wc, int mode, void* stream);
 /* footprints of frames x views splines (source [frames][views][63][2], T [frames][views][2][66]) on an hc x wc canvas, one
  * launch: per frame ss_render_footprint_floats(views, hc, wc) floats = exactly evaluated sampling coordinates on the
- * lattice of tile corners, the bounding box of each view's control points (its mesh hull) and the frame's tile order
- * (tiles sorted by the number of views that reach them, most expensive first); a tile is skipped for a view when it lies
- * outside the hull AND its four corners sample more than 8 pixels outside the (h x w) image (csrc/render.hip). */
+ * lattice of tile corners and long-edge midpoints, the bounding box of each view's control points (its mesh hull) and the
+ * frame's tile order (tiles sorted by the number of views that reach them, most expensive first); a tile is skipped for a
+ * view when it lies outside the hull AND its four corners and two long-edge midpoints all sample more than 8 pixels beyond
+ * the same side of the (h x w) image (csrc/render.hip; a test, not a proof -- pass footprint = NULL for the reference's
+ * arithmetic at every pixel). */
 SS_API long long ss_render_footprint_floats(int views, int hc, int wc);
 SS_API int ss_render_footprints(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
                                 int hc, int wc, void* stream);
@@ -225,6 +243,12 @@ SS_API int ss_mesh_bbox(const float* mesh, int n_points, float img_h, float img_
 /* out = norm(scale(mesh) - (wmin,hmin); Hc_f, Wc_f) with the float canvas size read from bbox on device */
 SS_API int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_points, float img_h,
                       float img_w, void* stream);
+/* the same for view `view` of `views` of a clip, mesh [frames][63][2], written into the render's source layout
+ * out [frames][views][63][2] (one call per view assembles it; test_online_tra.py:129-136) */
+SS_API int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,
+                            float img_h, float img_w, void* stream);
+/* p[0..n) = value (the zero motion of frame 0, temporal_network.py:31-33, written in place) */
+SS_API int ss_fill_f32(float* p, float value, long long n, void* stream);
 
 /* ---- K11: SmoothNet glue (smooth_network.py:64-157) ------------------------------------------
  * smesh1/2, tsmotion1/2 [frames][63][2] (LR px).  Window wi covers frames wi*wstride .. +t-1
@@ -242,6 +266,14 @@ SS_API int ss_smooth_finalize(const float* smesh1, const float* smesh2, const fl
                        const float* delta, float* ori_mesh1, float* ori_mesh2, float* ori_path1,
                        float* ori_path2, float* smooth_mesh1, float* smooth_mesh2, float* smooth_path1,
                        float* smooth_path2, int nw, int t, int wstride, int zero_first, void* stream);
+/* the clip's tensors straight from the sliding windows (wstride 1, first tsmotion of every window zeroed): window 0
+ * contributes its t frames, every later window its last frame (test_online_tra.py:377-392); the metric harness's paths
+ * are chained across windows sequentially as test_metric_ssd.py:427-436 does.  smesh*, ts* [n][63][2] with
+ * n = nw + t - 1; delta [nw][t][63][4] -> ori_mesh1/2, smooth_mesh1/2 [n][63][2]; ori_path2, smooth_path2 [n][63][2]
+ * (both or neither may be NULL). */
+SS_API int ss_smooth_stitch(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+                     const float* delta, float* ori_mesh1, float* ori_mesh2, float* smooth_mesh1, float* smooth_mesh2,
+                     float* ori_path2, float* smooth_path2, int nw, int t, void* stream);
 
 /* canvas-sized elementwise helpers of the harnesses: out = (in + add) * mul  ((img+1)*127.5,
  * test_metric_ssd.py:166);  out = a + b - a*b  (three-view mask union, test_online_tra_threeview.py:501) */

@@ -47,6 +47,7 @@ SIGNATURES = {
     'ss_homo_warp_nhwc': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_homo_warp_nchw': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_tps_solve': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
+    'ss_tps_solve_shared_target': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
     'ss_tps_points': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_st]),
     'ss_tsmotion_workspace_floats': (c_ll, [c_i]),
     'ss_tps_inverse': (c_i, [c_fp, c_fp, c_st]),
@@ -58,16 +59,21 @@ SIGNATURES = {
     'ss_mask_union': (c_i, [c_fp, c_fp, c_fp, c_ll, c_st]),
     'ss_ingest_u8': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_canvas_to_u8': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
-    'ss_render_average': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
-    'ss_render_average_u8': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_render_average': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_ll, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_render_average_u8': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_ll, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_render_average_clip': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_ll, c_fp] + [c_i] * 7 + [c_st]),
+    'ss_render_average_clip_u8': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_ll, c_fp] + [c_i] * 7 + [c_st]),
     'ss_render_footprint_floats': (c_ll, [c_i, c_i, c_i]),
     'ss_render_footprints': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
     'ss_linear_blend_workspace_floats': (c_ll, [c_i, c_i]),
     'ss_linear_blend': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_st]),
     'ss_mesh_bbox': (c_i, [c_fp, c_i, c_f, c_f, c_fp, c_i, c_st]),
     'ss_mesh_normalize': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
+    'ss_mesh_normalize_views': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_st]),
+    'ss_fill_f32': (c_i, [c_fp, c_f, c_ll, c_st]),
     'ss_smooth_embed': (c_i, [c_fp] * 9 + [c_i] * 4 + [c_st]),
     'ss_smooth_finalize': (c_i, [c_fp] * 13 + [c_i] * 4 + [c_st]),
+    'ss_smooth_stitch': (c_i, [c_fp] * 11 + [c_i] * 2 + [c_st]),
     'ss_alignment_psnr_ssim': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_stability_score': (c_i, [c_fp, c_fp, c_i, c_st]),
     'ss_distortion_score': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),

@@ -247,7 +247,7 @@ extern "C" int ss_homo_warp_nchw(const float* in, const float* theta, float* out
 // subtracts f * pivot_row with f fetched from its 4-lane row group by a shuffle.  All register indices are static
 // (steps unrolled per 17-column quarter); three barriers per step, 94 us per system vs 196 us LDS-resident.  src_stride = 0 shares one source mesh across the batch.
 __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
-                                                        const float* __restrict__ target,
+                                                        const float* __restrict__ target, long long tgt_stride,
                                                         float* __restrict__ T) {
     __shared__ float sx[SS_NV], sy[SS_NV];
     __shared__ double colabs[SS_NT], prow[TPS_LD], diag[SS_NT];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict_
     const int r = tid >> 2, q = tid & 3;
     const bool rowok = r < SS_NT;
     const float* src = source + (long long)b * src_stride;
-    const float* tgt = target + (long long)b * SS_NV * 2;
+    const float* tgt = target + (long long)b * tgt_stride;
     if (tid < SS_NV) { sx[tid] = src[tid * 2]; sy[tid] = src[tid * 2 + 1]; }
     __syncthreads();
     double a[TPS_TQ];
@@ -339,7 +339,16 @@ __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict_
 extern "C" int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream) {
     if (!source || !target || !T || n <= 0) return SS_ERR_ARG;
     hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
-                       target, T);
+                       target, (long long)SS_NV * 2, T);
+    return ss_launch_status();
+}
+
+// n systems with n control-point sets and ONE target shared by all of them (the render's splines: every frame's mesh maps
+// onto the same rigid mesh, test_online_tra.py:129-137) -- no [n,63,2] broadcast copy of the target
+extern "C" int ss_tps_solve_shared_target(const float* source, const float* target, float* T, int n, void* stream) {
+    if (!source || !target || !T || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
+                       target, 0ll, T);
     return ss_launch_status();
 }
 
@@ -536,7 +545,7 @@ extern "C" int ss_tsmotion(const float* smotion, const float* tmotion, float* sm
     float* ntgt = ws + 126;
     float* T = ntgt + (long long)n * 252;
     if (!rigid_winv)
-        hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, st, (const float*)ws, 0ll, (const float*)ntgt, T);
+        hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, st, (const float*)ws, 0ll, (const float*)ntgt, (long long)SS_NV * 2, T);
     hipLaunchKernelGGL(tsm_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)ws, (const float*)smesh, rigid_winv,
                        tsmotion, n, img_h, img_w);
     return ss_launch_status();
@@ -590,6 +599,41 @@ __global__ void mesh_normalize_kernel(const float* __restrict__ mesh, const floa
     float y = img_h > 0.f ? __fmul_rn(mesh[i * 2 + 1], img_h) / 360.0f : mesh[i * 2 + 1];
     out[i * 2] = norm1(__fsub_rn(x, wmin), ow);
     out[i * 2 + 1] = norm1(__fsub_rn(y, hmin), oh);
+}
+
+// the same for view `view` of `views`, written where the render wants it: frame f's 63 points at out[(f * views + view) * 126]
+// (source [frames][views][63][2] assembled by `views` launches, no torch.stack)
+__global__ void mesh_normalize_views_kernel(const float* __restrict__ mesh, const float* __restrict__ bbox,
+                                            float* __restrict__ out, int npts, int view, int views, float img_h, float img_w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    float wmin = bbox[0], wmax = bbox[1], hmin = bbox[2], hmax = bbox[3];
+    float ow = __fsub_rn(wmax, wmin), oh = __fsub_rn(hmax, hmin);
+    float x = img_w > 0.f ? __fmul_rn(mesh[i * 2], img_w) / 480.0f : mesh[i * 2];
+    float y = img_h > 0.f ? __fmul_rn(mesh[i * 2 + 1], img_h) / 360.0f : mesh[i * 2 + 1];
+    const int f = i / SS_NV, k = i - f * SS_NV;
+    float* o = out + (((long long)f * views + view) * SS_NV + k) * 2;
+    o[0] = norm1(__fsub_rn(x, wmin), ow);
+    o[1] = norm1(__fsub_rn(y, hmin), oh);
+}
+
+extern "C" int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,
+                                       float img_h, float img_w, void* stream) {
+    if (!mesh || !bbox || !out || frames <= 0 || views <= 0 || view < 0 || view >= views) return SS_ERR_ARG;
+    const int npts = frames * SS_NV;
+    hipLaunchKernelGGL(mesh_normalize_views_kernel, dim3(ss_cdiv(npts, 256)), dim3(256), 0, (hipStream_t)stream, mesh, bbox,
+                       out, npts, view, views, img_h, img_w);
+    return ss_launch_status();
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+extern "C" int ss_fill_f32(float* p, float value, long long n, void* stream) {
+    if (!p || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(fill_kernel, dim3(ss_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, value, n);
+    return ss_launch_status();
 }
 
 extern "C" int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_points, float img_h,

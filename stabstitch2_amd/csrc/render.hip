@@ -207,14 +207,17 @@ __device__ __forceinline__ float avg_fuse(float a, float b) {
 // of (P + Q) - P - Q (|r| <~ 1e-2 grey levels, different on every machine -- DESIGN.md 4); yet those pixels cost the full
 // 63-term spline evaluation, and on the benchmark canvas a third of all (pixel, view) pairs lie there.  With a footprint
 // block the fused render skips them and treats the view's contribution as exactly 0.
-//   lattice[v][i][j] = (xn, yn) = sampling coordinate of view v at canvas pixel (x = 64 j, y = 8 i), i <= ceil(hc / 8),
-//   j <= ceil(wc / 64) (the last row / column lies on or beyond the canvas edge: the spline is defined everywhere);
+//   lattice[v][i][j] = (xn, yn) = sampling coordinate of view v at canvas pixel (x = 32 j, y = 8 i), i <= ceil(hc / 8),
+//   j <= 2 ceil(wc / 64) (half-tile spacing along the long side of a tile: a tile is judged on its four corners AND the
+//   midpoints of its two long edges; the last row / column lies on or beyond the canvas edge: the spline is defined everywhere);
 //   hull[v] = (xmin, xmax, ymin, ymax): bounding box of the view's 63 control points in normalised canvas coordinates --
 //   the view's mesh on the canvas; its border vertices map exactly onto the image border (TPS interpolation).
 // A tile is OUTSIDE view v when BOTH hold:
 //   (a) it lies outside the mesh hull grown by 8 canvas pixels, and
-//   (b) the exactly evaluated sampling coordinates of its four corners all lie beyond the same image side by more than
-//       8 source pixels (a spline would have to bend by 8 px inside a 64 x 8-pixel tile, 0.4 mesh cells, to come back).
+//   (b) the exactly evaluated sampling coordinates of its four corners and two long-edge midpoints all lie beyond the same
+//       image side by more than 8 source pixels (to come back, the spline would have to bend by 8 px within 32 canvas
+//       pixels OUTSIDE its own mesh hull, where it has no control points and extrapolates smoothly).
+// This is a test, not a proof: callers who need the reference's arithmetic at every pixel pass footprint = NULL.
 // (A rigorous interpolation-error bound from sum |T_k| was tried instead of (b)'s fixed margin: the RBF weights of a
 // near-affine warp cancel, the bound does not -- it came out at 100-140 source pixels and kept a third of the skippable
 // tiles.)  tests/test_gpu_parity.py::test_render_footprint_skipping checks on pipeline meshes that every skipped pixel is
@@ -241,7 +244,7 @@ __global__ void render_lattice_kernel(const float* __restrict__ source, const fl
     }
     if (idx >= ny * nx) return;
     const int i = idx / nx, j = idx - i * nx;
-    const float gx = -1.f + 2.f * (float)(64 * j) / (float)(wc - 1), gy = -1.f + 2.f * (float)(8 * i) / (float)(hc - 1);
+    const float gx = -1.f + 2.f * (float)(32 * j) / (float)(wc - 1), gy = -1.f + 2.f * (float)(8 * i) / (float)(hc - 1);
     float xn, yn;
     tps_eval_fast(src, Tx, Tx + SS_NT, gx, gy, xn, yn);
     lattice[idx * 2] = xn;
@@ -259,12 +262,18 @@ __device__ __forceinline__ unsigned tile_views(const float* __restrict__ fp, int
     const float mx = 1.f + 16.f / (float)w, my = 1.f + 16.f / (float)h;       // 8 source pixels beyond the image
     unsigned mask = 0u;
     for (int v = 0; v < views; ++v) {
-        const float* L = fp + ((long long)v * ny * nx + (long long)by * nx + bx) * 2;
-        const float x00 = L[0], y00 = L[1], x01 = L[2], y01 = L[3];
-        const float x10 = L[2 * nx], y10 = L[2 * nx + 1], x11 = L[2 * nx + 2], y11 = L[2 * nx + 3];
+        const float* L = fp + ((long long)v * ny * nx + (long long)by * nx + 2 * bx) * 2;      // lattice column 2 bx = pixel 64 bx
+        float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {            // corners and long-edge midpoints
+                const float xs = L[(r * nx + c) * 2], ys = L[(r * nx + c) * 2 + 1];
+                xlo = fminf(xlo, xs); xhi = fmaxf(xhi, xs);
+                ylo = fminf(ylo, ys); yhi = fmaxf(yhi, ys);
+            }
         const bool off_hull = tx1 < hull[4 * v] || tx0 > hull[4 * v + 1] || ty1 < hull[4 * v + 2] || ty0 > hull[4 * v + 3];
-        const bool off_image = (fminf(fminf(x00, x01), fminf(x10, x11)) > mx) || (fmaxf(fmaxf(x00, x01), fmaxf(x10, x11)) < -mx) ||
-                               (fminf(fminf(y00, y01), fminf(y10, y11)) > my) || (fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) < -my);
+        const bool off_image = xlo > mx || xhi < -mx || ylo > my || yhi < -my;
         if (!(off_hull && off_image)) mask |= 1u << v;
     }
     return mask;
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void render_order_kernel(float* __restrict__ f
     __shared__ unsigned cnt[4], base[4];
     float* f = fp + (long long)blockIdx.x * frame_stride;
     unsigned* order = reinterpret_cast<unsigned*>(f + (long long)views * ny * nx * 2 + 4 * views);
-    const int nbx = nx - 1, nby = ny - 1, nt = nbx * nby;
+    const int nbx = (nx - 1) / 2, nby = ny - 1, nt = nbx * nby;
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0u;
     __syncthreads();
     for (int t = threadIdx.x; t < nt; t += 256) {
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(256) void render_order_kernel(float* __restrict__ f
 
 extern "C" long long ss_render_footprint_floats(int views, int hc, int wc) {
     if (views <= 0 || hc <= 1 || wc <= 1) return 0;
-    return (long long)views * ((long long)(ss_cdiv(hc, 8) + 1) * (ss_cdiv(wc, 64) + 1) * 2 + 4) +
+    return (long long)views * ((long long)(ss_cdiv(hc, 8) + 1) * (2 * ss_cdiv(wc, 64) + 1) * 2 + 4) +
            (long long)ss_cdiv(hc, 8) * ss_cdiv(wc, 64);       // + the tile order table
 }
 
@@ -313,12 +322,18 @@ extern "C" int ss_render_footprints(const float* source, const float* T, float* 
                                     int hc, int wc, void* stream) {
     if (!source || !T || !fp || frames <= 0 || views <= 0 || views > 3 || h <= 1 || w <= 1 || hc <= 1 || wc <= 1)
         return SS_ERR_ARG;
-    const int ny = ss_cdiv(hc, 8) + 1, nx = ss_cdiv(wc, 64) + 1;
+    const int ny = ss_cdiv(hc, 8) + 1, nx = 2 * ss_cdiv(wc, 64) + 1;
     // the footprint of frame f (lattice of every view, then the margins) lives at fp + f * ss_render_footprint_floats(...)
     const long long stride = ss_render_footprint_floats(views, hc, wc);
     if (ny > 4096 || nx > 4096) return SS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(render_lattice_kernel, dim3(ss_cdiv(ny * nx, 128), frames * views), dim3(128), 0, (hipStream_t)stream,
-                       source, T, fp, stride, views, hc, wc, ny, nx);
+    // grid.y = (frame, view), capped at 65535 by HIP: whole frames per launch
+    const int fmax = 65535 / views;
+    for (int f0 = 0; f0 < frames; f0 += fmax) {
+        const int nf = frames - f0 < fmax ? frames - f0 : fmax;
+        hipLaunchKernelGGL(render_lattice_kernel, dim3(ss_cdiv(ny * nx, 128), nf * views), dim3(128), 0, (hipStream_t)stream,
+                           source + (long long)f0 * views * SS_NV * 2, T + (long long)f0 * views * 2 * SS_NT,
+                           fp + (long long)f0 * stride, stride, views, hc, wc, ny, nx);
+    }
     hipLaunchKernelGGL(render_order_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, fp, stride, views, h, w, hc, wc,
                        ny, nx);
     return ss_launch_status();
@@ -382,17 +397,32 @@ __device__ __forceinline__ unsigned char render_to_u8(float v) {          // `.a
 // otherwise tiles are classified by `tile_views` and a view that cannot reach a tile contributes exactly 0 there.
 // U8: frames are decoded uint8 [h][w][3] and the canvas is written as the video frame uint8 [hc][wc][3] (`.astype(np.uint8)`
 // of the fused values, test_online_tra.py:413) -- the fp32 frame planes and the fp32 canvas never exist in memory.
+// One launch renders a whole clip: blockIdx.y = frame (the hardware hands out a frame's tiles, most expensive first,
+// then the next frame's: the light tail of one frame runs beside the heavy head of the next -- 32 launch boundaries and
+// 32 partially filled last rounds per clip less than one launch per frame).  Per-frame strides: `img_fs` / `out_fs` in
+// BYTES (frames of a view / canvases are equally spaced), `fp_fs` in floats; source [frame][VIEWS][63][2], T [frame][VIEWS][2][66].
 template <int VIEWS, bool U8>
 __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, const float* __restrict__ source,
                                                              const float* __restrict__ T, const float* __restrict__ fp,
                                                              float* __restrict__ out, int h, int w, int hc, int wc,
-                                                             int mode) {
+                                                             int mode, long long img_fs, long long out_fs,
+                                                             long long fp_fs) {
+    {
+        const long long frame = blockIdx.y;
+        source += frame * (VIEWS * SS_NV * 2);
+        T += frame * (VIEWS * 2 * SS_NT);
+        if (fp) fp += frame * fp_fs;
+        out = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + frame * out_fs);
+#pragma unroll
+        for (int k = 0; k < VIEWS; ++k)
+            rv.img[k] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(rv.img[k]) + frame * img_fs);
+    }
     unsigned char* const out8 = reinterpret_cast<unsigned char*>(out);
     // workgroup = 64 x 8 canvas pixels; wave w owns rows w and w + 4 of the tile and evaluates, for every view that
     // reaches the tile, that view's spline at its 64 columns of both rows (packed over the rows)
     const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long hw = (long long)h * w, ohw = (long long)hc * wc;
-    const int ny = (hc + 7) / 8 + 1, nx = (wc + 63) / 64 + 1;
+    const int ny = (hc + 7) / 8 + 1, nx = 2 * ((wc + 63) / 64) + 1, nbx = (nx - 1) / 2;
     int tbx, tby;
     unsigned mask;
     if (fp) {                                       // tile and its view set from the frame's order table (longest first)
@@ -400,12 +430,12 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
         const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);
         tbx = (int)(e & 0xFFFu); tby = (int)((e >> 12) & 0xFFFu); mask = e >> 24;
     } else {
-        tby = blockIdx.x / (nx - 1); tbx = blockIdx.x - tby * (nx - 1); mask = (1u << VIEWS) - 1u;
+        tby = blockIdx.x / nbx; tbx = blockIdx.x - tby * nbx; mask = (1u << VIEWS) - 1u;
     }
     const int x = tbx * 64 + lx;
 #ifdef SS_TUNING
     if ((mode >> 8) == 9) mask = ((tbx + tby) & 1) ? 3u : 1u;          // checkerboard of single / both
-    else if ((mode >> 8) == 10) mask = (tbx < (nx - 1) / 2) ? 1u : 3u;        // left half single, right half both
+    else if ((mode >> 8) == 10) mask = (tbx < nbx / 2) ? 1u : 3u;        // left half single, right half both
     else if (mode >> 8) mask = (unsigned)(mode >> 8) - 1u;          // forced tile class (timing experiments)
     mode &= 0xFF;
 #endif
@@ -473,41 +503,74 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
 }
 
 static int render_average_launch(const void* const* imgs, const float* source, const float* T, const float* footprint,
-                                 void* out, int views, int h, int w, int hc, int wc, int mode, void* stream, bool u8) {
-    if (!imgs || !source || !T || !out || (views != 2 && views != 3) || h <= 1 || w <= 1 || hc <= 1 || wc <= 1 ||
-        ((mode & 0xFF) != SS_WARP_NORMAL && (mode & 0xFF) != SS_WARP_FAST))
+                                 long long footprint_floats, void* out, int frames, long long img_fs, long long out_fs,
+                                 int views, int h, int w, int hc, int wc, int mode, void* stream, bool u8) {
+    if (!imgs || !source || !T || !out || frames <= 0 || (views != 2 && views != 3) || h <= 1 || w <= 1 || hc <= 1 ||
+        wc <= 1 || ((mode & 0xFF) != SS_WARP_NORMAL && (mode & 0xFF) != SS_WARP_FAST))
         return SS_ERR_ARG;
 #ifndef SS_TUNING
     if (mode >> 8) return SS_ERR_ARG;
 #endif
+    // a footprint row is only meaningful for the (views, canvas) it was built for: the kernel indexes its lattice and tile
+    // order with this geometry, so a row of another size is an argument error, not an out-of-bounds read
+    const long long fp_fs = ss_render_footprint_floats(views, hc, wc);
+    if (footprint && footprint_floats != fp_fs) return SS_ERR_ARG;
     RenderViews rv;
     for (int i = 0; i < 3; ++i) rv.img[i] = i < views ? static_cast<const float*>(imgs[i]) : nullptr;
     for (int i = 0; i < views; ++i)
         if (!rv.img[i]) return SS_ERR_ARG;
-    dim3 g(ss_cdiv(wc, 64) * ss_cdiv(hc, 8), 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    float* o = static_cast<float*>(out);
-    if (views == 2) {
-        if (u8) hipLaunchKernelGGL((render_average_kernel<2, true>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
-        else hipLaunchKernelGGL((render_average_kernel<2, false>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
-    } else {
-        if (u8) hipLaunchKernelGGL((render_average_kernel<3, true>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
-        else hipLaunchKernelGGL((render_average_kernel<3, false>), g, dim3(256), 0, st, rv, source, T, footprint, o, h, w, hc, wc, mode);
+    // grid.y = frame; HIP caps grid.y at 65535: longer clips go in several launches
+    for (int f0 = 0; f0 < frames; f0 += 65535) {
+        const int nf = frames - f0 < 65535 ? frames - f0 : 65535;
+        dim3 g(ss_cdiv(wc, 64) * ss_cdiv(hc, 8), nf, 1);
+        RenderViews r = rv;
+        for (int i = 0; i < views; ++i)
+            r.img[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(rv.img[i]) + (long long)f0 * img_fs);
+        const float* s_ = source + (long long)f0 * views * SS_NV * 2;
+        const float* t_ = T + (long long)f0 * views * 2 * SS_NT;
+        const float* p_ = footprint ? footprint + (long long)f0 * fp_fs : nullptr;
+        float* o = reinterpret_cast<float*>(static_cast<char*>(out) + (long long)f0 * out_fs);
+        if (views == 2) {
+            if (u8) hipLaunchKernelGGL((render_average_kernel<2, true>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+            else hipLaunchKernelGGL((render_average_kernel<2, false>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+        } else {
+            if (u8) hipLaunchKernelGGL((render_average_kernel<3, true>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+            else hipLaunchKernelGGL((render_average_kernel<3, false>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+        }
     }
     return ss_launch_status();
 }
 
 extern "C" int ss_render_average(const float* const* imgs, const float* source, const float* T, const float* footprint,
-                                 float* out, int views, int h, int w, int hc, int wc, int mode, void* stream) {
-    return render_average_launch(reinterpret_cast<const void* const*>(imgs), source, T, footprint, out, views, h, w, hc, wc,
-                                 mode, stream, false);
+                                 long long footprint_floats, float* out, int views, int h, int w, int hc, int wc, int mode,
+                                 void* stream) {
+    return render_average_launch(reinterpret_cast<const void* const*>(imgs), source, T, footprint, footprint_floats, out, 1,
+                                 0, 0, views, h, w, hc, wc, mode, stream, false);
 }
 
 extern "C" int ss_render_average_u8(const unsigned char* const* frames, const float* source, const float* T,
-                                    const float* footprint, unsigned char* out, int views, int h, int w, int hc, int wc,
-                                    int mode, void* stream) {
-    return render_average_launch(reinterpret_cast<const void* const*>(frames), source, T, footprint, out, views, h, w, hc,
-                                 wc, mode, stream, true);
+                                    const float* footprint, long long footprint_floats, unsigned char* out, int views, int h,
+                                    int w, int hc, int wc, int mode, void* stream) {
+    return render_average_launch(reinterpret_cast<const void* const*>(frames), source, T, footprint, footprint_floats, out, 1,
+                                 0, 0, views, h, w, hc, wc, mode, stream, true);
+}
+
+// whole clip, one launch: view k's frame f at views[k] + f * 3 h w floats (planar fp32 [n,3,h,w]), canvas f at
+// out + f * 3 hc wc floats, source [n,V,63,2], T [n,V,2,66], footprint [n][ss_render_footprint_floats] or NULL
+extern "C" int ss_render_average_clip(const float* const* views_base, const float* source, const float* T,
+                                      const float* footprint, long long footprint_floats, float* out, int frames, int views,
+                                      int h, int w, int hc, int wc, int mode, void* stream) {
+    return render_average_launch(reinterpret_cast<const void* const*>(views_base), source, T, footprint, footprint_floats,
+                                 out, frames, 12ll * h * w, 12ll * hc * wc, views, h, w, hc, wc, mode, stream, false);
+}
+
+// the same from decoded uint8 frames [n,h,w,3] per view to uint8 video frames [n,hc,wc,3]
+extern "C" int ss_render_average_clip_u8(const unsigned char* const* views_base, const float* source, const float* T,
+                                         const float* footprint, long long footprint_floats, unsigned char* out, int frames,
+                                         int views, int h, int w, int hc, int wc, int mode, void* stream) {
+    return render_average_launch(reinterpret_cast<const void* const*>(views_base), source, T, footprint, footprint_floats,
+                                 out, frames, 3ll * h * w, 3ll * hc * wc, views, h, w, hc, wc, mode, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------

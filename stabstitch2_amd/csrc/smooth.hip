@@ -103,3 +103,72 @@ extern "C" int ss_smooth_finalize(const float* smesh1, const float* smesh2, cons
                        smooth_path1, smooth_path2, nw, t, wstride, zero_first);
     return ss_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// The clip's tensors straight from the sliding windows (test_online_tra.py:377-392, test_metric_ssd.py:415-436):
+// window 0 contributes its t frames, window k >= 1 its last frame -- frame f comes from window w = max(f - (t-1), 0) at
+// position tt = f - w.  Meshes are written directly ([n][63][2], n = nw + t - 1); the metric harness's paths are chained
+// across windows SEQUENTIALLY like the reference's frame loop:
+//     ori_path[f]    = ori_path[f-1] + (op_w[t-1] - op_w[t-2])
+//     smooth_path[f] = ori_path[f]   + (sp_w[t-1] - op_w[t-1])            (f >= t, w = f - t + 1)
+// pass 1 (parallel over frames) leaves the two bracketed increments in place, pass 2 (one thread per coordinate) runs
+// the chain over them.  Replaces smooth_finalize + a dozen torch cat / cumsum calls of mesh-sized tensors.
+__global__ void smooth_stitch_kernel(const float* __restrict__ sm1, const float* __restrict__ sm2,
+                                     const float* __restrict__ ts1, const float* __restrict__ ts2,
+                                     const float* __restrict__ delta, float* __restrict__ om1, float* __restrict__ om2,
+                                     float* __restrict__ smm1, float* __restrict__ smm2, float* __restrict__ op2,
+                                     float* __restrict__ sp2, int nw, int t) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)nw + t - 1;
+    if (idx >= n * SS_NV) return;
+    const int v = (int)(idx % SS_NV);
+    const long long f = idx / SS_NV;
+    const long long w = f >= t - 1 ? f - (t - 1) : 0;
+    const int tt = (int)(f - w);
+    const float4 d = *reinterpret_cast<const float4*>(delta + ((w * t + tt) * SS_NV + v) * 4);
+    const float m1x = sm1[idx * 2], m1y = sm1[idx * 2 + 1], m2x = sm2[idx * 2], m2y = sm2[idx * 2 + 1];
+    om1[idx * 2] = m1x; om1[idx * 2 + 1] = m1y;
+    om2[idx * 2] = m2x; om2[idx * 2 + 1] = m2y;
+    smm1[idx * 2] = __fsub_rn(m1x, d.x); smm1[idx * 2 + 1] = __fsub_rn(m1y, d.y);
+    smm2[idx * 2] = __fsub_rn(m2x, d.z); smm2[idx * 2 + 1] = __fsub_rn(m2y, d.w);
+    if (!op2) return;
+    float fx, fy;
+    window_flow(ts2, w, tt, v, 1, fx, fy);                // op_w[tt]
+    if (f < t) {                                          // window 0: the paths themselves
+        op2[idx * 2] = fx; op2[idx * 2 + 1] = fy;
+        sp2[idx * 2] = __fadd_rn(fx, d.z); sp2[idx * 2 + 1] = __fadd_rn(fy, d.w);
+    } else {                                              // increments; chained by smooth_path_chain_kernel
+        float gx, gy;
+        window_flow(ts2, w, tt - 1, v, 1, gx, gy);        // op_w[t-2]
+        op2[idx * 2] = __fsub_rn(fx, gx); op2[idx * 2 + 1] = __fsub_rn(fy, gy);
+        sp2[idx * 2] = __fsub_rn(__fadd_rn(fx, d.z), fx); sp2[idx * 2 + 1] = __fsub_rn(__fadd_rn(fy, d.w), fy);
+    }
+}
+
+__global__ void smooth_path_chain_kernel(float* __restrict__ op2, float* __restrict__ sp2, long long n, int t) {
+    const int c = threadIdx.x;                            // one of the 126 coordinates
+    if (c >= SS_NV * 2) return;
+    float acc = op2[(long long)(t - 1) * SS_NV * 2 + c];
+    for (long long f = t; f < n; ++f) {
+        acc = __fadd_rn(acc, op2[f * SS_NV * 2 + c]);
+        op2[f * SS_NV * 2 + c] = acc;
+        sp2[f * SS_NV * 2 + c] = __fadd_rn(acc, sp2[f * SS_NV * 2 + c]);
+    }
+}
+
+// smesh*/ts* [n,7,9,2] (n = nw + t - 1 frames, window stride 1, first tsmotion of every window zeroed), delta [nw,t,7,9,4]
+// -> ori_mesh1/2, smooth_mesh1/2 [n,7,9,2]; ori_path2 / smooth_path2 [n,7,9,2] (both or neither)
+extern "C" int ss_smooth_stitch(const float* smesh1, const float* smesh2, const float* ts1, const float* ts2,
+                                const float* delta, float* ori_mesh1, float* ori_mesh2, float* smooth_mesh1,
+                                float* smooth_mesh2, float* ori_path2, float* smooth_path2, int nw, int t, void* stream) {
+    if (!smesh1 || !smesh2 || !ts1 || !ts2 || !delta || !ori_mesh1 || !ori_mesh2 || !smooth_mesh1 || !smooth_mesh2 ||
+        nw <= 0 || t < 2 || (!ori_path2) != (!smooth_path2))
+        return SS_ERR_ARG;
+    const long long n = (long long)nw + t - 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(smooth_stitch_kernel, dim3(ss_cdiv(n * SS_NV, 256)), dim3(256), 0, st, smesh1, smesh2, ts1, ts2, delta,
+                       ori_mesh1, ori_mesh2, smooth_mesh1, smooth_mesh2, ori_path2, smooth_path2, nw, t);
+    if (ori_path2 && n > t)
+        hipLaunchKernelGGL(smooth_path_chain_kernel, dim3(1), dim3(128), 0, st, ori_path2, smooth_path2, n, t);
+    return ss_launch_status();
+}

@@ -56,16 +56,23 @@ struct WinoP {
 #ifdef SS_TUNING
     unsigned long long* dbg;            // per-workgroup phase stamps (tools/diag_wino.py)
     int ablate;                         // 1: no filter loads, 2: no raw loads / LDS / transform, 4: no epilogue (wrong results)
+    int knob[4];                        // round-3 experiments (ss_debug_set keys 16..19): [0] first-round stagger of the second
+                                        // workgroup of a CU in units of 1024 clocks, [1] epilogue priority + 1 (0 = default 3),
+                                        // [2] prologue priority + 1 (0 = default 3), [3] K-loop priority + 1 (0 = default 0)
 #endif
 };
 
 #ifdef SS_TUNING
 #define W_STAMP(i) do { if (p.dbg) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define W_ABLATE(bit) (p.ablate & (bit))
+#define W_SETPRIO_KNOB(k, dflt) do { const int v_ = p.knob[k]; if (v_ == 1) __builtin_amdgcn_s_setprio(0); else if (v_ == 2) __builtin_amdgcn_s_setprio(1); \
+        else if (v_ == 3) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(dflt); } while (0)
 extern int g_wino_ablate;
+extern int g_wino_knob[4];
 #else
 #define W_STAMP(i) do { } while (0)
 #define W_ABLATE(bit) 0
+#define W_SETPRIO_KNOB(k, dflt) __builtin_amdgcn_s_setprio(dflt)
 #endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float* base, unsigned bytes) {
@@ -116,7 +123,15 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
 #endif
     // Setup and epilogue are VALU / LDS work that shares its SIMD with the OTHER resident workgroup's MFMAs; at equal
     // priority every such instruction waits for an MFMA boundary.  Raised priority lets it through (as in conv.hip).
-    __builtin_amdgcn_s_setprio(3);
+#ifdef SS_TUNING
+    // experiment: the second workgroup of a CU (LDS base != 0) of the FIRST round sleeps, so that the two resident workgroups
+    // run in anti-phase (one's prologue / epilogue under the other's K loop) instead of in lock-step
+    if (p.knob[0] > 0 && blockIdx.x < 512u && (__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0x1FFu) != 0u) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.knob[0] * 1024ull) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+    W_SETPRIO_KNOB(2, 3);
     W_STAMP(0);
 
     // XCD-aware block order (as conv.hip): consecutive workgroups go round-robin to the 8 XCDs; give every XCD one
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         rd(smem, 4);
         W_STAMP(6);
         W_STAMP(1);
-        __builtin_amdgcn_s_setprio(0);
+        W_SETPRIO_KNOB(3, 0);
         // ---- the stream: 8 blocks of 8 MFMAs per chunk.  First half: channels 0..3 of the chunk multiply while channels 4..7
         // are transformed; second half: channels 4..7 multiply while channels 0..3 of the NEXT chunk are transformed (its raw
         // patch goes registers -> LDS inside block (0, 2), one barrier per chunk after that block).  Every accumulator sees its
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             mma(3, 3, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_setprio(3);
+        W_SETPRIO_KNOB(1, 3);
 #undef W_SGB_BLOCK
     } else {
         acc_clear();
@@ -1125,6 +1140,7 @@ extern "C" int ss_wino_pack(const float* wgt, float* packed, int cout, int cin, 
 int g_wino_ablate = 0;                   // ss_debug_set key 6
 int g_wino_nb1_max_cin = 0;              // ss_debug_set key 5
 int g_wino_variant = 0;                  // ss_debug_set key 7: 0 stream kernel (dispatched), 1 phase-alternating kernel, 2 pair kernel
+int g_wino_knob[4] = {0, 0, 0, 0};       // ss_debug_set keys 16..19
 #else
 constexpr int g_wino_nb1_max_cin = 0;
 #endif
@@ -1182,6 +1198,7 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
 #ifdef SS_TUNING
     p.dbg = ss_tuning_dbg;
     p.ablate = g_wino_ablate;
+    for (int i = 0; i < 4; ++i) p.knob[i] = g_wino_knob[i];
 #endif
     const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
     if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;

@@ -12,16 +12,27 @@ def shard_streams(n_streams, rank, world_size):
     return list(range(rank, n_streams, world_size))
 
 
-def gather_records(record, dist=None, device=None):
-    """record: 1-D float64 tensor of fixed length -> [world, len] tensor on the host (identity without dist)."""
+def gather_records(record, dist=None, device=None, force_collective=False):
+    """record: 1-D float64 tensor of fixed length -> [world, len] tensor on the host (identity without dist).
+    A world of one rank skips the collective unless `force_collective` (the one-rank RCCL smoke test: init `nccl` with
+    world size 1 and push the record through a real device-side all_gather)."""
     record = record.to(torch.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return record.detach().cpu().unsqueeze(0)
     if device is not None:
         record = record.to(device)
     out = [torch.zeros_like(record) for _ in range(dist.get_world_size())]
     dist.all_gather(out, record)
     return torch.stack(out).cpu()
+
+
+def collective_backend_version():
+    """'rccl x.y.z' of the library behind torch.distributed's "nccl" backend on ROCm (None when unavailable)."""
+    try:
+        v = torch.cuda.nccl.version()
+        return 'rccl ' + '.'.join(str(x) for x in v)
+    except Exception:
+        return None
 
 
 def aggregate_fps(records):

@@ -189,7 +189,7 @@ def run_stage1(x_nchw, p, chunk=None):
     chunk = chunk or STAGE1_CHUNK
     buf = ops.stem_input(x_nchw)                     # [total, h, w + 8, 3]
     total, h, w = buf.shape[0], buf.shape[1], buf.shape[2] - 8
-    outs = []
+    whole = None
     for s in range(0, total, chunk):
         m = min(chunk, total - s)
         if CONV1_CHUNK > 0 and m > CONV1_CHUNK and h % 2 == 0 and w % 2 == 0:
@@ -204,8 +204,12 @@ def run_stage1(x_nchw, p, chunk=None):
             x = run_block(x, b)
         for b in p['layer2']:
             x = run_block(x, b)
-        outs.append(x)
-    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        if total <= chunk:
+            return x
+        if whole is None:                # several trunk passes: their features land in one preallocated tensor (no torch.cat)
+            whole = torch.empty((total,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+        whole[s:s + x.shape[0]].copy_(x)
+    return whole
 
 
 def run_stage2(x, p):
@@ -226,22 +230,42 @@ def prep_regressor(convs, fcs, last_c, last_hw):
 REG_CHUNK = int(os.environ.get('SS_REG_CHUNK', '512'))
 
 
-def run_regressor(x, p, chunk=None):
-    """x nhwc; pairs of 3x3 conv+ReLU then 2x2 max-pool; NHWC flatten; 3 FC."""
+def _fc_tail(flat, fc, out=None, out_slices=None, row0=0):
+    """The three FC layers of a regressor on flattened NHWC features.  out: [rows, nout] destination of the last layer;
+    out_slices: list of (r0, r1, dst) -- rows [r0, r1) of the WHOLE batch (this call covers rows row0 .. row0 + rows) go to
+    dst[r - r0] (dst [r1 - r0, nout] contiguous): the last layer then runs once per overlapping slice and writes in place
+    (e.g. every view's motions behind a zero first frame, no torch.cat)."""
+    if flat.shape[1] != fc[0][0].shape[1]:
+        raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
+                         % (fc[0][0].shape[1], flat.shape[1]))
+    y = ops.linear(flat, fc[0][0], fc[0][1], relu=True)
+    y = ops.linear(y, fc[1][0], fc[1][1], relu=True)
+    if out_slices is None:
+        return ops.linear(y, fc[2][0], fc[2][1], relu=False, out=out)
+    rows = flat.shape[0]
+    for r0, r1, dst in out_slices:
+        a, b = max(r0, row0), min(r1, row0 + rows)
+        if a < b:
+            ops.linear(y[a - row0:b - row0], fc[2][0], fc[2][1], relu=False, out=dst[a - r0:b - r0])
+    return None
+
+
+def run_regressor(x, p, chunk=None, out=None, out_slices=None, row0=0):
+    """x nhwc; pairs of 3x3 conv+ReLU then 2x2 max-pool; NHWC flatten; 3 FC.  out / out_slices: see _fc_tail."""
     chunk = chunk or REG_CHUNK
     if x.shape[0] > chunk:
-        return torch.cat([run_regressor(x[s:s + chunk], p, chunk) for s in range(0, x.shape[0], chunk)], 0)
+        nout = p['fc'][2][0].shape[0]
+        if out is None and out_slices is None:
+            out = torch.empty((x.shape[0], nout), device=x.device, dtype=torch.float32)
+        for s in range(0, x.shape[0], chunk):
+            e = min(s + chunk, x.shape[0])
+            run_regressor(x[s:e], p, chunk, None if out is None else out[s:e], out_slices, row0 + s)
+        return out
     for i, w in enumerate(p['convs']):
         x = ops.conv(x, w, None, stride=1, pad=(0, 1, 1), relu=True)
         if i & 1:
             x = ops.maxpool(x, 2, 2, 0)
-    flat = x.reshape(x.shape[0], -1)
-    if flat.shape[1] != p['fc'][0][0].shape[1]:
-        raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
-                         % (p['fc'][0][0].shape[1], flat.shape[1]))
-    y = ops.linear(flat, p['fc'][0][0], p['fc'][0][1], relu=True)
-    y = ops.linear(y, p['fc'][1][0], p['fc'][1][1], relu=True)
-    return ops.linear(y, p['fc'][2][0], p['fc'][2][1], relu=False)
+    return _fc_tail(x.reshape(x.shape[0], -1), p['fc'], out, out_slices, row0)
 
 
 def pair_regressors(pa, pb):
@@ -250,30 +274,24 @@ def pair_regressors(pa, pb):
             'fc': (pa['fc'], pb['fc'])}
 
 
-def run_regressor_pair(x, pp, chunk=None):
+def run_regressor_pair(x, pp, chunk=None, outs=None):
     """x [2,n,h,w,c] nhwc (one input per regressor) -> (out_a, out_b): the eight convs of both regressors run as
     eight grouped launches instead of sixteen, the pools on the joint batch; the FC stacks stay per regressor."""
     g, n = x.shape[0], x.shape[1]
     chunk = chunk or REG_CHUNK
     if n > chunk:
-        parts = [run_regressor_pair(x[:, s:s + chunk].contiguous(), pp, chunk) for s in range(0, n, chunk)]
-        return [torch.cat([pt[k] for pt in parts], 0) for k in range(g)]
+        if outs is None:
+            outs = [torch.empty((n, pp['fc'][k][2][0].shape[0]), device=x.device, dtype=torch.float32) for k in range(g)]
+        for s in range(0, n, chunk):
+            e = min(s + chunk, n)
+            run_regressor_pair(x[:, s:e].contiguous(), pp, chunk, [o[s:e] for o in outs])
+        return outs
     for i, w in enumerate(pp['convs']):
         x = ops.conv_grouped(x, w, None, None, stride=1, pad=(0, 1, 1), relu=True)
         if i & 1:
             x = ops.maxpool(x.view(g * n, *x.shape[2:]), 2, 2, 0)
             x = x.view(g, n, *x.shape[1:])
-    outs = []
-    for k in range(g):
-        fc = pp['fc'][k]
-        flat = x[k].reshape(n, -1)
-        if flat.shape[1] != fc[0][0].shape[1]:
-            raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
-                             % (fc[0][0].shape[1], flat.shape[1]))
-        y = ops.linear(flat, fc[0][0], fc[0][1], relu=True)
-        y = ops.linear(y, fc[1][0], fc[1][1], relu=True)
-        outs.append(ops.linear(y, fc[2][0], fc[2][1], relu=False))
-    return outs
+    return [_fc_tail(x[k].reshape(n, -1), pp['fc'][k], None if outs is None else outs[k]) for k in range(g)]
 
 
 # --------------------------------------------------------------------------- twin trunks (streaming mode)

@@ -64,9 +64,8 @@ class OnlineStitcher:
     @torch.no_grad()
     def _render(self, hr1, hr2, mesh1, mesh2):
         """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc]."""
-        src = torch.cat((ops.mesh_normalize(mesh1, self.bbox, self.h, self.w),
-                         ops.mesh_normalize(mesh2, self.bbox, self.h, self.w)), 0)
-        T = ops.tps_solve(src, self.nrigid.expand(2, -1, -1).contiguous())
+        src = ops.mesh_normalize_views([mesh1, mesh2], self.bbox, self.h, self.w)[0]          # [2,63,2]
+        T = ops.tps_solve_shared(src, self.nrigid)
         if self.fusion_mode == 'AVERAGE':
             fp = None
             if pipeline.SKIP_OUTSIDE:        # same footprint skipping as the offline render (pipeline.render_frames)

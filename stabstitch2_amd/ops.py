@@ -12,6 +12,37 @@ def _f(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
 
 
+class _Built:
+    """A device buffer built once by kernels on some stream (packed filters, cached inverses, constant meshes) and then
+    read by launches on any stream: remembers the stream it was built on and an event behind the build, so that a first
+    use from ANOTHER stream waits for it.  Building inside a HIP-graph capture is refused (the buffer would come from the
+    graph's private pool and be replayed over by later eager launches): warm the path up eagerly before capturing."""
+    __slots__ = ('value', 'stream', 'event', 'tag')
+
+    def __init__(self, build, device, what, tag=None):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('stabstitch2_amd: %s would be built inside a HIP-graph capture; run the path once eagerly '
+                               '(warm-up) before capturing' % what)
+        self.value = build()
+        self.stream = torch.cuda.current_stream(device)
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+        self.tag = tag
+
+    def get(self, device):
+        if self.event is None or torch.cuda.is_current_stream_capturing():
+            # (inside a capture no event may be queried; the eager warm-up that built the buffer was submitted before the
+            # capture began, and torch.cuda.graph synchronises the device on entry)
+            return self.value
+        cur = torch.cuda.current_stream(device)
+        if cur != self.stream:
+            if self.event.query():
+                self.event = None               # finished long ago: nothing to wait for any more
+            else:
+                cur.wait_event(self.event)
+        return self.value
+
+
 # ------------------------------------------------------------------ layout
 def nchw_to_nhwc(x, c_pad=None, out=None):
     n, c, h, w = x.shape
@@ -86,6 +117,11 @@ def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
                                               int(wo), int(images)))
 
 
+# which kernel the most recent ops.conv / ops.conv_grouped / ops.conv_winograd call launched ('wino' | 'igemm'): read by
+# bench.ConvProbe for its executed-flop accounting (the dispatch is not re-derived there)
+last_conv_path = None
+
+
 def conv_executed_flop_ratio(kt, kh, kw, stride, cin, cout, out_shape):
     """Executed MFMA flop / direct-convolution flop of the launch the engine picks for this geometry: 16/36 where the
     Winograd F(2x2,3x3) kernel runs (the library's own dispatch rule, ss_conv_uses_winograd), else 1."""
@@ -106,16 +142,21 @@ WINO_MATH = os.environ.get('SS_WINO_MATH', 'f32')
 def wino_packed(wgt, groups, sliced=False):
     """Transformed + packed filters of a 3x3 weight tensor ([cout,1,3,3,cin] or [g,cout,1,3,3,cin]), built on first use
     by ss_wino_pack / ss_wino_pack3 and kept on the tensor (prepared weights are rebuilt, hence re-packed, whenever a net
-    is reloaded)."""
+    is reloaded; an in-place edit of the tensor bumps its version counter and re-packs too)."""
     attr = '_wino_packed3' if sliced else '_wino_packed'
-    pk = getattr(wgt, attr, None)
-    if pk is None:
+    ent = getattr(wgt, attr, None)
+    tag = (wgt._version, wgt.data_ptr())
+    if ent is None or ent.tag != tag:
         cout, cin = wgt.shape[-5], wgt.shape[-1]
         per = int((H.lib().ss_wino_packed3_floats if sliced else H.lib().ss_wino_packed_floats)(cout, cin))
-        pk = torch.empty((groups, per), device=wgt.device, dtype=torch.float32)
-        H.call('ss_wino_pack3' if sliced else 'ss_wino_pack', H.dptr(wgt), H.dptr(pk), cout, cin, groups, H.stream())
-        setattr(wgt, attr, pk)
-    return pk
+
+        def build():
+            pk = torch.empty((groups, per), device=wgt.device, dtype=torch.float32)
+            H.call('ss_wino_pack3' if sliced else 'ss_wino_pack', H.dptr(wgt), H.dptr(pk), cout, cin, groups, H.stream())
+            return pk
+        ent = _Built(build, wgt.device, 'the Winograd filter pack', tag)
+        setattr(wgt, attr, ent)
+    return ent.get(wgt.device)
 
 
 def conv_winograd(x, wgt, bias=None, res=None, relu=False, out=None):
@@ -131,6 +172,8 @@ def conv_winograd(x, wgt, bias=None, res=None, relu=False, out=None):
         out = torch.empty(((g, n, h, w, cout) if grouped else (n, h, w, cout)), device=x.device, dtype=torch.float32)
     sliced = WINO_MATH == 'bf16x9'
     pk = wino_packed(wgt, g, sliced)
+    global last_conv_path
+    last_conv_path = 'wino'
     H.call('ss_conv3x3_wino3_nhwc' if sliced else 'ss_conv3x3_wino_nhwc', H.dptr(x), H.dptr(pk), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, h, w, cin, cout, int(relu), out.shape[-1], g, 0 if (shared or not grouped) else x[0].numel(),
            pk.shape[1], out[0].numel() if grouped else 0, H.stream())
@@ -156,6 +199,8 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
     if not five and _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n):
         return conv_winograd(x, wgt, bias, res, relu, out)
+    global last_conv_path
+    last_conv_path = 'igemm'
     ws = conv_workspace(x.device, _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, 1))
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), out.shape[-1],
@@ -181,6 +226,8 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
     out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
     if _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n * g):
         return conv_winograd(x, wgt, bias, res, relu, out)
+    global last_conv_path
+    last_conv_path = 'igemm'
     ws = conv_workspace(x.device, _conv_ws_need(n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, g))
     H.call('ss_conv_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
            n, 1, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, int(relu), cout,
@@ -206,11 +253,13 @@ def maxpool_split(x, k, stride, pad, out0, out1):
     return out0, out1
 
 
-def linear(x, w, b=None, relu=False):
+def linear(x, w, b=None, relu=False, out=None):
     m, k = x.shape
     nout = w.shape[0]
     assert w.shape[1] == k
-    out = torch.empty((m, nout), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((m, nout), device=x.device, dtype=torch.float32)
+    assert out.numel() == m * nout
     H.call('ss_linear', H.dptr(x), H.dptr(w), H.dptr(b, True), H.dptr(out), m, k, nout, int(relu), H.stream())
     return out
 
@@ -262,10 +311,14 @@ def spatial_decompose(offset8, img_h, img_w):
     return a, b
 
 
-def spatial_meshes(offset8, off_ref, off_tgt, img_h, img_w):
+def spatial_meshes(offset8, off_ref, off_tgt, img_h, img_w, out=None):
     n = offset8.shape[0]
-    m1 = torch.empty((n, 7, 9, 2), device=offset8.device, dtype=torch.float32)
-    m2 = torch.empty((n, 7, 9, 2), device=offset8.device, dtype=torch.float32)
+    if out is not None:
+        m1, m2 = out
+        assert m1.numel() == n * 126 and m2.numel() == n * 126
+    else:
+        m1 = torch.empty((n, 7, 9, 2), device=offset8.device, dtype=torch.float32)
+        m2 = torch.empty((n, 7, 9, 2), device=offset8.device, dtype=torch.float32)
     H.call('ss_spatial_meshes', H.dptr(offset8), H.dptr(off_ref), H.dptr(off_tgt), H.dptr(m1), H.dptr(m2), n,
            float(img_h), float(img_w), H.stream())
     return m1, m2
@@ -292,6 +345,15 @@ def tps_solve(source, target):
     return T
 
 
+def tps_solve_shared(source, target):
+    """n control-point sets [n,63,2] against ONE target [63,2] / [1,63,2] -> T [n,2,66] (no broadcast copy)."""
+    n = source.shape[0]
+    assert target.numel() == 126
+    T = torch.empty((n, 2, 66), device=source.device, dtype=torch.float32)
+    H.call('ss_tps_solve_shared_target', H.dptr(_f(source)), H.dptr(_f(target)), H.dptr(T), n, H.stream())
+    return T
+
+
 def tps_points(point, source, T):
     n, q, _ = point.shape
     out = torch.empty((n, q, 2), device=point.device, dtype=torch.float32)
@@ -306,17 +368,21 @@ RIGID_INVERSE_CACHE = True      # host switch for A/B runs and the equivalence t
 def rigid_winv(img_h, img_w, device):
     """fp64 W^-1 of the TPS system whose control points are the normalised RIGID mesh of an (img_h, img_w) image: a
     constant of the tsmotion composition, computed once per (size, device) by ss_tps_inverse."""
+    device = torch.device(device)
     key = (int(img_h), int(img_w), str(device))
-    w = _rigid_winv.get(key)
-    if w is None:
-        xs = torch.linspace(0.0, float(img_w), 9)
-        ys = torch.linspace(0.0, float(img_h), 7)
-        m = torch.stack((xs.view(1, -1).expand(7, -1), ys.view(-1, 1).expand(-1, 9)), 2).reshape(63, 2)
-        src = torch.stack((m[:, 0] * 2. / float(img_w) - 1., m[:, 1] * 2. / float(img_h) - 1.), 1).contiguous().to(device)
-        w = torch.empty((66, 66), device=device, dtype=torch.float64)
-        H.call('ss_tps_inverse', H.dptr(src), H.dptr(w, dtype=torch.float64), H.stream())
-        _rigid_winv[key] = w
-    return w
+    ent = _rigid_winv.get(key)
+    if ent is None:
+        def build():
+            xs = torch.linspace(0.0, float(img_w), 9)
+            ys = torch.linspace(0.0, float(img_h), 7)
+            m = torch.stack((xs.view(1, -1).expand(7, -1), ys.view(-1, 1).expand(-1, 9)), 2).reshape(63, 2)
+            src = torch.stack((m[:, 0] * 2. / float(img_w) - 1., m[:, 1] * 2. / float(img_h) - 1.), 1).contiguous().to(device)
+            w = torch.empty((66, 66), device=device, dtype=torch.float64)
+            H.call('ss_tps_inverse', H.dptr(src), H.dptr(w, dtype=torch.float64), H.stream())
+            return w
+        ent = _Built(build, device, 'the cached rigid-mesh TPS inverse')
+        _rigid_winv[key] = ent
+    return ent.get(device)
 
 
 def tsmotion(smotion, tmotion, img_h=360, img_w=480):
@@ -353,17 +419,24 @@ def render_footprints(source, T, h, w, hc, wc):
     return fp
 
 
+def _fp_args(footprint):
+    return H.dptr(footprint, True), (0 if footprint is None else footprint.numel())
+
+
 def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None, footprint=None):
     """imgs: list of 2|3 device tensors [1,3,h,w] / [3,h,w]; source [V,63,2]; T [V,2,66] -> [3,hc,wc].
     footprint: this frame's row of `render_footprints` (views that cannot reach a tile are skipped there and count as
-    exactly 0), or None (every view evaluated everywhere)."""
+    exactly 0 -- a deliberate deviation from the reference, whose clamped sampler returns a rounding residue of up to
+    ~1e-2 grey levels outside a view's image; the skip test samples each 64 x 8 tile at six points and is not a proof),
+    or None (every view evaluated everywhere: the reference's arithmetic at every pixel)."""
     v = len(imgs)
     imgs = [_f(i) for i in imgs]
     h, w = imgs[0].shape[-2:]
     arr = H.ptr_array(imgs)
     if out is None:
         out = torch.empty((3, hc, wc), device=imgs[0].device, dtype=torch.float32)
-    H.call('ss_render_average', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(footprint, True), H.dptr(out), v, h, w, hc, wc,
+    fp, fpn = _fp_args(footprint)
+    H.call('ss_render_average', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, H.dptr(out), v, h, w, hc, wc,
            MODES[mode], H.stream())
     return out
 
@@ -378,7 +451,39 @@ def render_average_u8(frames, source, T, hc, wc, mode='NORMAL', out=None, footpr
     arr = H.ptr_array(frames, dtype=torch.uint8)
     if out is None:
         out = torch.empty((hc, wc, 3), device=frames[0].device, dtype=torch.uint8)
-    H.call('ss_render_average_u8', arr, H.dptr(_f(source)), H.dptr(T), H.dptr(footprint, True), _u8ptr(out), v, h, w, hc, wc,
+    fp, fpn = _fp_args(footprint)
+    H.call('ss_render_average_u8', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, _u8ptr(out), v, h, w, hc, wc,
+           MODES[mode], H.stream())
+    return out
+
+
+def render_average_clip(views, source, T, hc, wc, mode='NORMAL', out=None, footprint=None):
+    """A whole clip in one launch: views = list of 2|3 contiguous device tensors [n,3,h,w]; source [n,V,63,2];
+    T [n,V,2,66]; footprint [n, ss_render_footprint_floats] | None -> [n,3,hc,wc].  Bit-identical to n render_average calls."""
+    v = len(views)
+    n, _, h, w = views[0].shape
+    assert all(tuple(t.shape) == (n, 3, h, w) for t in views) and source.shape[0] == n and T.shape[0] == n
+    arr = H.ptr_array(views)
+    if out is None:
+        out = torch.empty((n, 3, hc, wc), device=views[0].device, dtype=torch.float32)
+    assert tuple(out.shape) == (n, 3, hc, wc)
+    fp, fpn = H.dptr(footprint, True), (0 if footprint is None else footprint.shape[-1])
+    H.call('ss_render_average_clip', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, H.dptr(out), n, v, h, w, hc, wc,
+           MODES[mode], H.stream())
+    return out
+
+
+def render_average_clip_u8(views, source, T, hc, wc, mode='NORMAL', out=None, footprint=None):
+    """The same from decoded uint8 clips: views = list of 2|3 contiguous device tensors [n,h,w,3] uint8 -> uint8 [n,hc,wc,3]."""
+    v = len(views)
+    n, h, w, _ = views[0].shape
+    assert all(tuple(t.shape) == (n, h, w, 3) for t in views) and source.shape[0] == n and T.shape[0] == n
+    arr = H.ptr_array(views, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((n, hc, wc, 3), device=views[0].device, dtype=torch.uint8)
+    assert tuple(out.shape) == (n, hc, wc, 3)
+    fp, fpn = H.dptr(footprint, True), (0 if footprint is None else footprint.shape[-1])
+    H.call('ss_render_average_clip_u8', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, _u8ptr(out), n, v, h, w, hc, wc,
            MODES[mode], H.stream())
     return out
 
@@ -451,12 +556,15 @@ def linear_blend(ref, tgt, ref_m, tgt_m, want_mask=False, out=None):
     return mk if want_mask else out
 
 
-def mesh_bbox(meshes, img_h, img_w):
-    """meshes: list of LR-scale tensors [...,2] -> device tensor [4] = wmin, wmax, hmin, hmax (HR px)."""
-    bbox = torch.empty(4, device=meshes[0].device, dtype=torch.float32)
+def mesh_bbox(meshes, img_h, img_w, bbox=None):
+    """meshes: list of LR-scale tensors [...,2] -> device tensor [4] = wmin, wmax, hmin, hmax (HR px).
+    bbox: an existing box to fold these meshes into (in place)."""
+    acc = bbox is not None
+    if bbox is None:
+        bbox = torch.empty(4, device=meshes[0].device, dtype=torch.float32)
     for i, m in enumerate(meshes):
         m = _f(m)
-        H.call('ss_mesh_bbox', H.dptr(m), m.numel() // 2, float(img_h), float(img_w), H.dptr(bbox), int(i > 0),
+        H.call('ss_mesh_bbox', H.dptr(m), m.numel() // 2, float(img_h), float(img_w), H.dptr(bbox), int(acc or i > 0),
                H.stream())
     return bbox
 
@@ -468,6 +576,24 @@ def mesh_normalize(mesh, bbox, img_h, img_w):
     H.call('ss_mesh_normalize', H.dptr(m), H.dptr(bbox), H.dptr(out), m.numel() // 2, float(img_h), float(img_w),
            H.stream())
     return out
+
+
+def mesh_normalize_views(meshes, bbox, img_h, img_w):
+    """meshes: V tensors [..., N,7,9,2] (N frames each) -> the render's control points [N,V,63,2] on the canvas `bbox`."""
+    v = len(meshes)
+    n = meshes[0].numel() // 126
+    out = torch.empty((n, v, 63, 2), device=meshes[0].device, dtype=torch.float32)
+    for k, m in enumerate(meshes):
+        m = _f(m)
+        assert m.numel() == n * 126
+        H.call('ss_mesh_normalize_views', H.dptr(m), H.dptr(bbox), H.dptr(out), n, k, v, float(img_h), float(img_w), H.stream())
+    return out
+
+
+def fill(t, value=0.0):
+    """t[...] = value in place (t contiguous fp32)."""
+    H.call('ss_fill_f32', H.dptr(t), float(value), t.numel(), H.stream())
+    return t
 
 
 # ------------------------------------------------------------------ smooth glue
@@ -484,4 +610,18 @@ def smooth_finalize(sm1, sm2, ts1, ts2, delta, nw, t, wstride, zero_first):
     outs = {k: torch.empty((nw, t, 7, 9, 2), device=sm1.device, dtype=torch.float32) for k in names}
     H.call('ss_smooth_finalize', H.dptr(sm1), H.dptr(sm2), H.dptr(ts1), H.dptr(ts2), H.dptr(delta),
            *[H.dptr(outs[k]) for k in names], nw, t, wstride, int(zero_first), H.stream())
+    return outs
+
+
+
+def smooth_stitch(sm1, sm2, ts1, ts2, delta, nw, t, want_paths=True):
+    """The clip's tensors straight from the sliding windows (ss_smooth_stitch): sm*/ts* [n,7,9,2] with n = nw + t - 1,
+    delta [nw,t,7,9,4] -> dict(ori_mesh1/2, smooth_mesh1/2 [1,n,7,9,2] (+ ori_path2, smooth_path2))."""
+    n = nw + t - 1
+    assert sm1.shape[0] == n and delta.numel() == nw * t * 63 * 4
+    names = ['ori_mesh1', 'ori_mesh2', 'smooth_mesh1', 'smooth_mesh2'] + (['ori_path2', 'smooth_path2'] if want_paths else [])
+    outs = {k: torch.empty((1, n, 7, 9, 2), device=sm1.device, dtype=torch.float32) for k in names}
+    H.call('ss_smooth_stitch', H.dptr(sm1), H.dptr(sm2), H.dptr(ts1), H.dptr(ts2), H.dptr(delta),
+           H.dptr(outs['ori_mesh1']), H.dptr(outs['ori_mesh2']), H.dptr(outs['smooth_mesh1']), H.dptr(outs['smooth_mesh2']),
+           H.dptr(outs.get('ori_path2'), True), H.dptr(outs.get('smooth_path2'), True), nw, t, H.stream())
     return outs

@@ -10,10 +10,15 @@ over all frames of a view, one batched tsmotion composition per view, all slidin
 as one batch, one batched TPS solve for every (frame, view), then one fused warp+blend launch per
 stitched frame.  The only host round trip is the data-dependent canvas size (test_online_tra.py:122-123).
 
-Everything tensor-sized (frames, feature maps, cost volumes, canvases) is computed by the HIP kernels.  What stays as
-torch expressions here is mesh-sized bookkeeping on [N,7,9,2] tensors (a few KB): assembling the clip's meshes from the
-sliding windows and the metric harness's stitched paths (`_stitch_windows`), and the three-view mesh alignment
-(`three_view_compose`: scale, mean offset, middle mesh, bbox, normalise) -- torch device ops, no host sync.
+Everything tensor-sized (frames, feature maps, cost volumes, canvases) is computed by the HIP kernels, and in the 2-view
+path so is the mesh-sized bookkeeping (the clip's meshes and the metric harness's stitched paths straight from the sliding
+windows: `ops.smooth_stitch`; the render's control points: `ops.mesh_normalize_views`): a steady-state 2-view clip issues
+no torch (aten) kernel at all (tools/trace_torch_ops.py).  What stays as torch expressions is the three-view mesh alignment
+(`three_view_compose`: scale, mean offset, middle mesh, bbox, normalise on [1,N,7,9,2] tensors) -- device ops, no host sync.
+
+Long videos: `run_two_view_long` keeps the reference's ONE global canvas (test_online_tra.py:106-120) in bounded device
+memory -- pass 1 estimates the meshes chunk by chunk from the LR frames only, pass 2 renders chunk by chunk onto the
+shared canvas.
 """
 import glob
 import os
@@ -65,92 +70,148 @@ def _side_stream(dev):
 SPATIAL_CHUNK = int(os.environ.get('SS_SPATIAL_CHUNK', '32'))     # frame pairs per SpatialNet pass
 
 
+def _mesh_pair(n, dev):
+    return (torch.empty((n, grid_h + 1, grid_w + 1, 2), device=dev, dtype=torch.float32),
+            torch.empty((n, grid_h + 1, grid_w + 1, 2), device=dev, dtype=torch.float32))
+
+
 @torch.no_grad()
 def spatial_stage(spatial_net, lr1, lr2, chunk=None, cache1=None):
     """lr1, lr2 [N,3,360,480] device -> smotion1, smotion2 [N,7,9,2].
     cache1: per chunk the (f64, f32) trunk features of view 1 kept by an earlier pass (then only view 2 goes through
     the trunk)."""
     chunk = chunk or SPATIAL_CHUNK
-    m1, m2 = [], []
-    for i, s in enumerate(range(0, lr1.shape[0], chunk)):
+    n = lr1.shape[0]
+    m1, m2 = _mesh_pair(n, lr1.device)                   # every chunk writes its rows in place (no torch.cat)
+    for i, s in enumerate(range(0, n, chunk)):
+        e = min(s + chunk, n)
         if cache1 is None:
-            o = build_SpatialNet(spatial_net, lr1[s:s + chunk], lr2[s:s + chunk])
-            a1, a2 = o['motion1'], o['motion2']
+            off = spatial_net(lr1[s:e], lr2[s:e])
         else:
-            f64_2, f32_2 = spatial_net.trunk_features([lr2[s:s + chunk]])
+            f64_2, f32_2 = spatial_net.trunk_features([lr2[s:e]])
             off = spatial_net.forward_pair(cache1[i][0], f64_2, cache1[i][1], f32_2, LR_H, LR_W)
-            a1, a2 = ops.spatial_meshes(off[0], off[1], off[2], LR_H, LR_W)
-        m1.append(a1)
-        m2.append(a2)
-    return torch.cat(m1, 0), torch.cat(m2, 0)
+        ops.spatial_meshes(off[0], off[1], off[2], LR_H, LR_W, out=(m1[s:e], m2[s:e]))
+    return m1, m2
 
 
 @torch.no_grad()
 def temporal_stage(temporal_net, lr):
     """lr [N,3,360,480] device -> tmotion [N,7,9,2] (frame 0 = 0)."""
-    m = temporal_net.motions(lr.unsqueeze(1))[:, 0]
-    return torch.cat((torch.zeros_like(m[:1]), m), 0)
+    return temporal_stage_views(temporal_net, [lr])[0]
 
 
 @torch.no_grad()
 def temporal_stage_views(temporal_net, lrs):
     """Both (all) views of a clip in ONE batched pass: lrs = list of V tensors [N,3,360,480]
-    -> list of V tmotion tensors [N,7,9,2] (frame 0 = 0)."""
-    ms = temporal_net.motions_views(lrs)                          # V x [N-1,7,9,2]
-    z = torch.zeros_like(ms[0][:1])
-    return [torch.cat((z, m), 0) for m in ms]
+    -> list of V tmotion tensors [N,7,9,2] (frame 0 = 0, written in place)."""
+    n = lrs[0].shape[0]
+    f = temporal_net.features(lrs)                                   # [V*N,45,60,128], view-major
+    return temporal_net.motions_from_view_features([f[i * n:(i + 1) * n] for i in range(len(lrs))], zero_first=True)
 
 
 SHARED_STEM = os.environ.get('SS_SHARED_STEM', '1') == '1'
 
 
-@torch.no_grad()
-def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None, cache2=None):
-    """SpatialNet and TemporalNet of a 2-view clip in one sweep: both nets start with the same 7x7/2 conv + pool on the
-    same LR frames (spatial_network.py:127-130 and temporal_network.py:47-50 build identical stems), so the stem runs
-    ONCE with 2 x 64 filters and each net continues from its half of the channels.
-    -> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0).
-    tmotion1: view 1's temporal motions when a previous pass already produced them (three-view: the middle view is
-    view 2 of pair (1,2) and view 1 of pair (2,3)); its TemporalNet trunk is then skipped."""
-    from . import layers as L
-    chunk = chunk or SPATIAL_CHUNK
-    sp, tp = spatial_net._prepared(), temporal_net._prepared()
-    # shared-stem filters derive from BOTH nets' weights: keyed on both versions, one live entry (replaced on a miss)
-    key = 'stem_pair'
-    ver = (spatial_net.weights_version, temporal_net.weights_version)
-    if sp.get('stem_pair_version') != ver:
-        sp[key] = L.pair_stems(sp['s1'], tp['s1'])
-        sp['stem_pair_version'] = ver
-    n = lr1.shape[0]
-    m1, m2 = [], []
-    ft = None
-    for s in range(0, n, chunk):
-        e = min(s + chunk, n)
-        b = e - s
-        xa, xb = L.run_stem_shared([lr1[s:e], lr2[s:e]], sp[key])
+class JointEstimator:
+    """SpatialNet and TemporalNet of a 2-view stream, chunk by chunk, in memory that does not grow with the stream (beyond
+    the [N,7,9,2] motions themselves).  Both nets start with the same 7x7/2 conv + pool on the same LR frames
+    (spatial_network.py:127-130 and temporal_network.py:47-50 build identical stems), so the stem runs ONCE with 2 x 64
+    filters and each net continues from its half of the channels.  TemporalNet's cost volumes pair every frame with its
+    predecessor; across a chunk boundary the predecessor's stage-1 features are carried over (one [1,45,60,128] map per
+    view), so feeding a video in chunks launches exactly the kernels a resident clip of the same chunking launches:
+    the motions are bit-identical however the frames arrive.
+        est = JointEstimator(spatial_net, temporal_net, n_frames, device); est.push(lr1[s:e], lr2[s:e]) ...; est.result()
+    tmotion1: view 1's temporal motions when a previous pass already produced them (three-view: the middle view is view 2
+    of pair (1,2) and view 1 of pair (2,3)); its TemporalNet trunk is then skipped.  cache2: list that receives view 2's
+    SpatialNet trunk features per chunk (for a later pair that starts with this view; resident clips only)."""
+
+    def __init__(self, spatial_net, temporal_net, n_frames, device, tmotion1=None, cache2=None):
+        from . import layers as L
+        self.L = L
+        self.spatial_net, self.temporal_net = spatial_net, temporal_net
+        self.sp, self.tp = spatial_net._prepared(), temporal_net._prepared()
+        # shared-stem filters derive from BOTH nets' weights: keyed on both versions, one live entry (replaced on a miss)
+        ver = (spatial_net.weights_version, temporal_net.weights_version)
+        if self.sp.get('stem_pair_version') != ver:
+            self.sp['stem_pair'] = L.pair_stems(self.sp['s1'], self.tp['s1'])
+            self.sp['stem_pair_version'] = ver
+        self.n, self.pos = n_frames, 0
+        self.m1, self.m2 = _mesh_pair(n_frames, device)
+        self.tmotion1, self.cache2 = tmotion1, cache2
+        self.views = (1,) if tmotion1 is not None else (0, 1)
+        self.tm = torch.empty((len(self.views), n_frames, grid_h + 1, grid_w + 1, 2), device=device, dtype=torch.float32)
+        for i in range(len(self.views)):
+            ops.fill(self.tm[i, 0])                      # the zero motion of frame 0 (temporal_network.py:31-33)
+        self.carry = None
+
+    @torch.no_grad()
+    def push(self, lr1, lr2):
+        """The next b frames of both views, [b,3,360,480] device tensors."""
+        L, sp, tp = self.L, self.sp, self.tp
+        b = lr1.shape[0]
+        s, e = self.pos, self.pos + b
+        if e > self.n:
+            raise ValueError('more frames pushed (%d) than announced (%d)' % (e, self.n))
+        xa, xb = L.run_stem_shared([lr1, lr2], sp['stem_pair'])
         f64 = L.run_trunk_body(xa, sp['s1'])
         f32 = L.run_stage2(f64, sp['s2'])
-        off1, off_ref, off_tgt = spatial_net.forward_pair(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
-        if cache2 is not None:                    # view 2's trunk features, for a later pair that starts with this view
-            cache2.append((f64[b:], f32[b:]))
-        a1, a2 = ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W)
-        m1.append(a1)
-        m2.append(a2)
-        views = (1,) if tmotion1 is not None else (0, 1)
-        f = L.run_trunk_body(xb if tmotion1 is None else xb[b:], tp['s1'])  # [len(views)*b,45,60,128], view-major
-        if n <= chunk:
-            ft = [f[i * b:(i + 1) * b] for i in range(len(views))]
-        else:
-            if ft is None:
-                ft = [torch.empty((n,) + tuple(f.shape[1:]), device=f.device, dtype=torch.float32) for _ in views]
-            for i in range(len(views)):
-                ft[i][s:e].copy_(f[i * b:(i + 1) * b])
-    ms = temporal_net.motions_from_view_features(ft)
-    z = torch.zeros_like(ms[0][:1])
-    tm = [torch.cat((z, m), 0) for m in ms]
-    if tmotion1 is not None:
-        tm = [tmotion1, tm[0]]
-    return torch.cat(m1, 0), torch.cat(m2, 0), tm[0], tm[1]
+        off1, off_ref, off_tgt = self.spatial_net.forward_pair(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
+        if self.cache2 is not None:
+            self.cache2.append((f64[b:], f32[b:]))
+        ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W, out=(self.m1[s:e], self.m2[s:e]))
+        nv = len(self.views)
+        f = L.run_trunk_body(xb if self.tmotion1 is None else xb[b:], tp['s1'])      # [nv*b,45,60,128], view-major
+        lead = 0 if s == 0 else 1                       # the pair (last frame of the previous chunk, first of this one)
+        rows = b - 1 + lead
+        if rows > 0:
+            cv = torch.empty((nv * rows, f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
+            slices = []
+            for i in range(nv):
+                fi = f[i * b:(i + 1) * b]
+                if lead:
+                    ops.cost_volume(self.carry[i], fi[0:1], 3, out=cv[i * rows:i * rows + 1])
+                if b > 1:
+                    ops.cost_volume(fi[:b - 1], fi[1:], 3, out=cv[i * rows + lead:(i + 1) * rows])
+                slices.append((i * rows, (i + 1) * rows, self.tm[i, e - rows:e].view(rows, -1)))
+            L.run_regressor(cv, tp['r2'], out_slices=slices)
+        self.carry = [f[i * b + b - 1:(i + 1) * b] for i in range(nv)]
+        self.pos = e
+
+    def result(self):
+        """-> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""
+        if self.pos != self.n:
+            raise ValueError('%d of %d frames pushed' % (self.pos, self.n))
+        self.carry = None
+        if self.tmotion1 is not None:
+            return self.m1, self.m2, self.tmotion1, self.tm[0]
+        return self.m1, self.m2, self.tm[0], self.tm[1]
+
+
+@torch.no_grad()
+def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None, cache2=None):
+    """SpatialNet and TemporalNet of a resident 2-view clip in one sweep (JointEstimator fed in chunks of `chunk` frames).
+    -> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""
+    chunk = chunk or SPATIAL_CHUNK
+    n = lr1.shape[0]
+    est = JointEstimator(spatial_net, temporal_net, n, lr1.device, tmotion1, cache2)
+    for s in range(0, n, chunk):
+        est.push(lr1[s:s + chunk], lr2[s:s + chunk])
+    return est.result()
+
+
+@torch.no_grad()
+def smooth_stage(smooth_net, s1, s2, t1, t2):
+    """Stage 3 of test() (test_online_tra.py:309-392) on the whole stream's motions [N,7,9,2]: tsmotion composition, all
+    sliding SmoothNet windows, the clip's tensors (mesh-sized; the windows run in chunks of smooth_network.WINDOW_CHUNK)."""
+    n = s1.shape[0]
+    smesh1, tsm1 = ops.tsmotion(s1, t1, LR_H, LR_W)
+    smesh2, tsm2 = ops.tsmotion(s2, t2, LR_H, LR_W)
+    nw = n - (WINDOW - 1)
+    delta = smooth_net.window_deltas(smesh1, smesh2, tsm1, tsm2, nw, WINDOW, 1, 1)
+    out = ops.smooth_stitch(smesh1, smesh2, tsm1, tsm2, delta, nw, WINDOW)
+    out['smotion1'], out['smotion2'], out['tmotion1'], out['tmotion2'] = s1, s2, t1, t2
+    out['tsmotion1'], out['tsmotion2'] = tsm1, tsm2
+    return out
 
 
 @torch.no_grad()
@@ -188,22 +249,16 @@ def estimate_meshes(nets, lr1, lr2, tmotion1=None, spatial_cache1=None, keep_spa
             t1, t2 = temporal_stage_views(temporal_net, [lr1, lr2])
         else:
             t1, t2 = tmotion1, temporal_stage_views(temporal_net, [lr2])[0]
-    smesh1, tsm1 = ops.tsmotion(s1, t1, LR_H, LR_W)
-    smesh2, tsm2 = ops.tsmotion(s2, t2, LR_H, LR_W)
-    nw = n - (WINDOW - 1)
-    o, _ = smooth_net.run_windows(smesh1, smesh2, tsm1, tsm2, nw, WINDOW, 1, 1)
-    out = _stitch_windows(o)
-    out['smotion1'], out['smotion2'], out['tmotion1'], out['tmotion2'] = s1, s2, t1, t2
-    out['tsmotion1'], out['tsmotion2'] = tsm1, tsm2
+    out = smooth_stage(smooth_net, s1, s2, t1, t2)
     if cache2:
         out['spatial_cache2'] = cache2
     return out
 
 
 def _stitch_windows(o):
-    """Per-window SmoothNet outputs [nw,7,7,9,2] -> the clip's tensors [1,N,7,9,2] (mesh-sized torch glue).
-    Window 0 contributes its 7 frames, every later window its last frame (test_online_tra.py:377-392); the metric
-    harness's paths are chained across windows as test_metric_ssd.py:427-436 does."""
+    """torch restatement of ops.smooth_stitch on per-window SmoothNet outputs [nw,7,7,9,2] (kept for the tests: the
+    kernel is checked against it).  Window 0 contributes its 7 frames, every later window its last frame
+    (test_online_tra.py:377-392); the metric harness's paths are chained across windows as test_metric_ssd.py:427-436 does."""
     out = {}
     for k in ('ori_mesh1', 'ori_mesh2', 'smooth_mesh1', 'smooth_mesh2'):
         out[k] = torch.cat((o[k][0], o[k][1:, -1]), 0).unsqueeze(0)
@@ -254,12 +309,14 @@ _nrigid_cache = {}
 def norm_rigid_mesh(img_h, img_w, device):
     """get_norm_mesh(get_rigid_mesh(1, h, w)) as a cached device constant ([1,63,2]; built once per (size, device)
     instead of on the host for every render)."""
+    device = torch.device(device)
     key = (int(img_h), int(img_w), str(device))
-    t = _nrigid_cache.get(key)
-    if t is None:
-        t = get_norm_mesh(get_rigid_mesh(1, img_h, img_w, device=device), img_h, img_w).contiguous()
-        _nrigid_cache[key] = t
-    return t
+    ent = _nrigid_cache.get(key)
+    if ent is None:
+        ent = ops._Built(lambda: get_norm_mesh(get_rigid_mesh(1, img_h, img_w, device=device), img_h, img_w).contiguous(),
+                         device, 'the cached normalised rigid mesh')
+        _nrigid_cache[key] = ent
+    return ent.get(device)
 
 
 # AVERAGE render: skip a view's 63-term spline on canvas tiles it provably cannot reach (ops.render_footprints) and take
@@ -270,37 +327,68 @@ SKIP_OUTSIDE = os.environ.get('SS_SKIP_OUTSIDE', '1') == '1'
 
 # ------------------------------------------------------------------ render
 @torch.no_grad()
-def render_plan(meshes, img_h, img_w, prescaled=False):
+def canvas_bbox(meshes, img_h, img_w, prescaled=False, bbox=None):
+    """(wmin, wmax, hmin, hmax) over `meshes` in HR pixels as a device tensor [4] (test_online_tra.py:103-120); `bbox`:
+    an existing box to fold in (more chunks of the same video)."""
+    sh, sw = (0.0, 0.0) if prescaled else (img_h, img_w)
+    return ops.mesh_bbox(list(meshes), sh, sw, bbox)
+
+
+def canvas_size(bbox):
+    """bbox device tensor [4] -> (Hc, Wc): the path's one host sync (the data-dependent canvas size,
+    test_online_tra.py:122-123: fp32 extents `wmax - wmin`, `hmax - hmin`, truncated by `.int()`)."""
+    import numpy as np
+    bb = bbox.cpu().numpy()                        # one 16-byte device -> host copy
+    return int(np.float32(bb[3]) - np.float32(bb[2])), int(np.float32(bb[1]) - np.float32(bb[0]))
+
+
+@torch.no_grad()
+def render_plan(meshes, img_h, img_w, prescaled=False, bbox=None, size=None):
     """Canvas + TPS coefficients for every (frame, view).
     meshes: list of V tensors [1,N,7,9,2] (LR scale, or HR canvas pixels with prescaled=True).
+    bbox: the canvas box to render onto (device [4]; default: the box of these meshes); size: its (Hc, Wc) when the
+    caller already read it back (no host sync then).
     -> (Hc, Wc, source [N,V,63,2], T [N,V,2,66])."""
     dev = meshes[0].device
     v = len(meshes)
     n = meshes[0].shape[1]
     sh, sw = (0.0, 0.0) if prescaled else (img_h, img_w)
-    bbox = ops.mesh_bbox([m for m in meshes], sh, sw)
-    bb = bbox.cpu()                                       # the one host sync: data-dependent canvas size
-    wc_f, hc_f = bb[1] - bb[0], bb[3] - bb[2]
-    hc, wc = int(hc_f.int()), int(wc_f.int())
-    src = torch.stack([ops.mesh_normalize(m[0], bbox, sh, sw) for m in meshes], 1).contiguous()   # [N,V,63,2]
-    tgt = norm_rigid_mesh(img_h, img_w, dev).expand(n * v, -1, -1).contiguous()
-    T = ops.tps_solve(src.view(n * v, 63, 2), tgt).view(n, v, 2, 66)
+    if bbox is None:
+        bbox = canvas_bbox(meshes, img_h, img_w, prescaled)
+    hc, wc = size if size is not None else canvas_size(bbox)
+    src = ops.mesh_normalize_views(meshes, bbox, sh, sw)                          # [N,V,63,2]
+    T = ops.tps_solve_shared(src.view(n * v, 63, 2), norm_rigid_mesh(img_h, img_w, dev)).view(n, v, 2, 66)
     return hc, wc, src, T
 
 
+def _as_clip(x, n):
+    """A view's frames as ONE contiguous device tensor [n,3,h,w] when they already are one (no copy), else None."""
+    if torch.is_tensor(x) and x.dim() == 4 and x.shape[0] == n and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32:
+        return x
+    return None
+
+
 @torch.no_grad()
-def render_frames(img_lists, meshes, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None, prescaled=False):
+def render_frames(img_lists, meshes, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None, prescaled=False, bbox=None,
+                  size=None):
     """img_lists: V lists (or tensors [N,3,H,W]) of HR frames (0..255); meshes: V tensors [1,N,7,9,2].
-    -> (frames [N,3,Hc,Wc] device tensor, Hc, Wc)."""
+    -> (frames [N,3,Hc,Wc] device tensor, Hc, Wc).  AVERAGE fusion of clips held as tensors is ONE launch for the whole
+    clip (ops.render_average_clip); lists of separate frames and LINEAR fusion go frame by frame.
+    With SKIP_OUTSIDE (default) a view contributes exactly 0 on canvas tiles it cannot reach, where the reference's
+    clamped sampler leaves a rounding residue of <~ 1e-2 grey levels (ops.render_average)."""
     v = len(img_lists)
     dev = meshes[0].device
     n = meshes[0].shape[1]
     first = img_lists[0][0]
     img_h, img_w = first.shape[-2:]
-    hc, wc, src, T = render_plan(meshes, img_h, img_w, prescaled)
-    if out is None:
-        out = torch.empty((n, 3, hc, wc), device=dev, dtype=torch.float32)
+    hc, wc, src, T = render_plan(meshes, img_h, img_w, prescaled, bbox, size)
+    if out is None or tuple(out.shape) != (n, 3, hc, wc) or not out.is_contiguous():
+        out = torch.empty((n, 3, hc, wc), device=dev, dtype=torch.float32)      # (a buffer of another canvas is not reused)
     fp = ops.render_footprints(src, T, img_h, img_w, hc, wc) if (SKIP_OUTSIDE and fusion_mode == 'AVERAGE') else None
+    clips = [_as_clip(x, n) for x in img_lists]
+    if fusion_mode == 'AVERAGE' and all(c is not None for c in clips):
+        ops.render_average_clip(clips, src, T, hc, wc, warp_mode, out=out, footprint=fp)
+        return out, hc, wc
     for i in range(n):
         imgs = [img_lists[k][i].to(dev, non_blocking=True) for k in range(v)]
         if fusion_mode == 'AVERAGE':
@@ -324,11 +412,12 @@ def get_stable_sqe(img1_list, img2_list, smooth_mesh1, smooth_mesh2, warp_mode, 
 
 
 @torch.no_grad()
-def run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', to_host=False):
+def run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', to_host=False, out=None):
     """-> (frames, Hc, Wc, smooth_mesh1, smooth_mesh2); frames = device tensor [N,3,Hc,Wc]
-    (or list of HWC ndarrays with to_host=True)."""
+    (or list of HWC ndarrays with to_host=True).  out: the frames tensor of a previous call to render into; it is reused
+    when the canvas still has that size (same-size clips of one stream), else a new one is allocated."""
     acc = estimate_meshes(nets, lr1, lr2)
-    frames, hc, wc = render_frames([hr1, hr2], [acc['smooth_mesh1'], acc['smooth_mesh2']], warp_mode, fusion_mode)
+    frames, hc, wc = render_frames([hr1, hr2], [acc['smooth_mesh1'], acc['smooth_mesh2']], warp_mode, fusion_mode, out=out)
     if to_host:
         host = frames.permute(0, 2, 3, 1).cpu().numpy()
         frames = [host[i] for i in range(host.shape[0])]
@@ -373,20 +462,20 @@ def three_view_compose(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w):
 
 
 @torch.no_grad()
-def three_view_render(img1, img2, img3, mesh1, middle, mesh3, warp_mode='NORMAL', fusion_mode='AVERAGE'):
+def three_view_render(img1, img2, img3, mesh1, middle, mesh3, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None):
     """Meshes are HR-scale canvas pixels here (output of three_view_compose)."""
-    return render_frames([img1, img2, img3], [mesh1, middle, mesh3], warp_mode, fusion_mode, prescaled=True)
+    return render_frames([img1, img2, img3], [mesh1, middle, mesh3], warp_mode, fusion_mode, out=out, prescaled=True)
 
 
 @torch.no_grad()
-def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE'):
+def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None):
     # the middle view's TemporalNet motions and SpatialNet trunk features are computed once and reused by pair (2,3)
     a12 = estimate_meshes(nets, lr1, lr2, keep_spatial_cache2=True)
     a23 = estimate_meshes(nets, lr2, lr3, tmotion1=a12['tmotion2'], spatial_cache1=a12.get('spatial_cache2'))
     img_h, img_w = hr1[0].shape[-2:]
     m1, mid, m3 = three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'],
                                      a23['smooth_mesh2'], img_h, img_w)
-    frames, hc, wc = three_view_render(hr1, hr2, hr3, m1, mid, m3, warp_mode, fusion_mode)
+    frames, hc, wc = three_view_render(hr1, hr2, hr3, m1, mid, m3, warp_mode, fusion_mode, out=out)
     return frames, hc, wc, m1, mid, m3
 
 
@@ -418,19 +507,17 @@ U8_FUSED = os.environ.get('SS_U8_FUSED', '1') == '1'
 
 
 @torch.no_grad()
-def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None):
+def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None, bbox=None, size=None):
     """frame_lists: V device tensors [N,H,W,3] uint8; meshes: V tensors [1,N,7,9,2] -> (uint8 [N,Hc,Wc,3], Hc, Wc):
-    `render_frames(..., 'AVERAGE')` followed by `to_video_frames`, fused."""
-    v = len(frame_lists)
+    `render_frames(..., 'AVERAGE')` followed by `to_video_frames`, fused, one launch for the clip."""
     n = meshes[0].shape[1]
     img_h, img_w = frame_lists[0].shape[1], frame_lists[0].shape[2]
-    hc, wc, src, T = render_plan(meshes, img_h, img_w)
-    if out is None:
+    hc, wc, src, T = render_plan(meshes, img_h, img_w, bbox=bbox, size=size)
+    if out is None or tuple(out.shape) != (n, hc, wc, 3) or not out.is_contiguous():
         out = torch.empty((n, hc, wc, 3), device=meshes[0].device, dtype=torch.uint8)
     fp = ops.render_footprints(src, T, img_h, img_w, hc, wc) if SKIP_OUTSIDE else None
-    for i in range(n):
-        ops.render_average_u8([frame_lists[k][i] for k in range(v)], src[i], T[i], hc, wc, warp_mode, out=out[i],
-                              footprint=None if fp is None else fp[i])
+    ops.render_average_clip_u8([f if f.is_contiguous() else f.contiguous() for f in frame_lists], src, T, hc, wc, warp_mode,
+                               out=out, footprint=fp)
     return out, hc, wc
 
 
@@ -541,3 +628,132 @@ class HostClipRunner:
             k += 1
         pending[3].synchronize()
         yield pending[0], pending[1], pending[2]
+
+
+# ------------------------------------------------------------------ long videos, one global canvas, bounded device memory
+class LongVideoStitcher:
+    """The reference's whole-video behaviour for videos of any length: it keeps every frame in host lists
+    (test_online_tra.py:250-278), smooths over the whole sequence (:359-392) and renders every frame onto ONE canvas, the
+    bounding box of all frames' meshes (:106-120) -- cutting a video into independent clips (HostClipRunner) does not
+    reproduce that output.  Here the frames stay on the host (uint8 [N,H,W,3] arrays, memory-mapped files, ...) and go
+    through the device twice, `chunk` frames at a time:
+      pass 1  `estimate`: uint8 upload -> cv2-exact LR resize -> SpatialNet / TemporalNet (JointEstimator; a chunk boundary
+              carries one feature map per view) -> the stream's motions [N,7,9,2]; then tsmotion, all sliding SmoothNet
+              windows and the global canvas box on those mesh-sized tensors;
+      pass 2  `render`: uint8 upload -> fused TPS warp + fusion onto the shared canvas -> uint8 video frames -> host.
+    Device memory is that of one chunk plus O(N) mesh-sized tensors (504 bytes per frame, view and motion kind); uploads,
+    compute and downloads of neighbouring chunks overlap on three HIP streams.  The meshes equal those of the resident
+    path bit for bit (same launches), hence so do the canvas and the frames."""
+
+    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', chunk=None):
+        self.nets, self.dev = nets, torch.device(device)
+        self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
+        self.chunk = chunk or SPATIAL_CHUNK
+        self.io = HostClipRunner(nets, device, warp_mode, fusion_mode)
+        self.acc = self.bbox = self.hc = self.wc = None
+
+    def _chunks(self, frames1, frames2):
+        n = len(frames1)
+        if len(frames2) != n:
+            raise ValueError('views differ in length: %d vs %d frames' % (n, len(frames2)))
+        for s in range(0, n, self.chunk):
+            e = min(s + self.chunk, n)
+            yield s, e, (frames1[s:e], frames2[s:e])
+
+    def _uploads(self, frames1, frames2):
+        """(s, e, device uint8 tensors, ready event), the next chunk's upload always enqueued before this one is consumed."""
+        it = self._chunks(frames1, frames2)
+        nxt = next(it, None)
+        up = None if nxt is None else self.io._upload(nxt[2])
+        while nxt is not None:
+            cur, cur_up = nxt, up
+            nxt = next(it, None)
+            up = None if nxt is None else self.io._upload(nxt[2])
+            yield cur[0], cur[1], cur_up[0], cur_up[1]
+
+    @torch.no_grad()
+    def estimate(self, frames1, frames2):
+        """Pass 1 -> the dict of `estimate_meshes` for the WHOLE video (+ the global canvas: self.bbox, self.hc, self.wc)."""
+        n = len(frames1)
+        if n < WINDOW:
+            raise ValueError('need at least %d frames for the sliding smooth window, got %d' % (WINDOW, n))
+        spatial_net, temporal_net, smooth_net = self.nets
+        comp = self.io.comp
+        est = None
+        img_h = img_w = None
+        for s, e, d, ev in self._uploads(frames1, frames2):
+            comp.wait_event(ev)
+            with torch.cuda.stream(comp):
+                for t in d:
+                    t.record_stream(comp)
+                d = [t if t.is_contiguous() else t.contiguous() for t in d]
+                img_h, img_w = d[0].shape[1], d[0].shape[2]
+                if est is None:
+                    est = JointEstimator(spatial_net, temporal_net, n, self.dev)
+                _, lr1 = ops.ingest_u8(d[0], want_hr=False)
+                _, lr2 = ops.ingest_u8(d[1], want_hr=False)
+                est.push(lr1, lr2)
+        with torch.cuda.stream(comp):
+            self.acc = smooth_stage(smooth_net, *est.result())
+            self.bbox = canvas_bbox([self.acc['smooth_mesh1'], self.acc['smooth_mesh2']], img_h, img_w)
+            self.hc, self.wc = canvas_size(self.bbox)
+        return self.acc
+
+    @torch.no_grad()
+    def render(self, frames1, frames2):
+        """Pass 2: yields (uint8 [m,Hc,Wc,3] pinned host tensor, s, e) per chunk of frames [s, e), one chunk late at most;
+        a yielded tensor stays valid until two more chunks have been yielded."""
+        if self.acc is None:
+            raise RuntimeError('estimate() first')
+        io = self.io
+        m1, m2 = self.acc['smooth_mesh1'], self.acc['smooth_mesh2']
+        pending = None
+        k = 0
+        for s, e, d, ev in self._uploads(frames1, frames2):
+            io.comp.wait_event(ev)
+            with torch.cuda.stream(io.comp):
+                for t in d:
+                    t.record_stream(io.comp)
+                d = [t if t.is_contiguous() else t.contiguous() for t in d]
+                ms = [m1[:, s:e].contiguous(), m2[:, s:e].contiguous()]
+                if U8_FUSED and self.fusion_mode == 'AVERAGE':
+                    u8, _, _ = render_frames_u8(d, ms, self.warp_mode, bbox=self.bbox, size=(self.hc, self.wc))
+                else:
+                    hr1, _ = ops.ingest_u8(d[0])
+                    hr2, _ = ops.ingest_u8(d[1])
+                    fr, _, _ = render_frames([hr1, hr2], ms, self.warp_mode, self.fusion_mode, bbox=self.bbox,
+                                             size=(self.hc, self.wc))
+                    u8 = ops.canvas_to_u8(fr)
+                ev2 = torch.cuda.Event()
+                ev2.record(io.comp)
+            host, done = io._download(k, u8, ev2)
+            if pending is not None:
+                pending[0].synchronize()
+                yield pending[1], pending[2], pending[3]
+            pending = (done, host, s, e)
+            k += 1
+        if pending is not None:
+            pending[0].synchronize()
+            yield pending[1], pending[2], pending[3]
+
+
+@torch.no_grad()
+def run_two_view_long(frames1, frames2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', device='cuda', chunk=None,
+                      sink=None):
+    """`run_two_view_u8` for videos that do not fit the device: frames1, frames2 = uint8 [N,H,W,3] host arrays (anything
+    sliceable along frames: ndarray, pinned tensor, np.memmap), rendered onto the reference's single global canvas
+    (LongVideoStitcher).  sink(video_chunk [m,Hc,Wc,3] uint8 host tensor, s, e) receives the stitched frames in order
+    (e.g. cv2.VideoWriter.write per frame, test_online_tra.py:409-417); without a sink they are collected into one
+    ndarray.  -> (video | None, Hc, Wc, smooth_mesh1, smooth_mesh2)."""
+    st = LongVideoStitcher(nets, device, warp_mode, fusion_mode, chunk)
+    acc = st.estimate(frames1, frames2)
+    video = None
+    if sink is None:
+        import numpy as np
+        video = np.empty((len(frames1), st.hc, st.wc, 3), dtype=np.uint8)
+    for host, s, e in st.render(frames1, frames2):
+        if sink is None:
+            video[s:e] = host.numpy()
+        else:
+            sink(host, s, e)
+    return video, st.hc, st.wc, acc['smooth_mesh1'], acc['smooth_mesh2']

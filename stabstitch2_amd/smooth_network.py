@@ -39,28 +39,33 @@ class SmoothNet(L.PreparedMixin, nn.Module):
                 'dec': L.pack_fc(mp.decoding[0])}
 
     @torch.no_grad()
-    def run_windows(self, smesh1, smesh2, ts1, ts2, nw, t, wstride, zero_first):
-        """smesh*/ts* [frames,7,9,2] device tensors; see ss_smooth_embed for the window addressing.
-        -> (dict of the 8 build_SmoothNet tensors, each [nw,t,7,9,2]; decoder output [nw,t,7,9,4])."""
+    def window_deltas(self, smesh1, smesh2, ts1, ts2, nw, t, wstride, zero_first, out=None):
+        """The decoder output of `nw` windows: smesh*/ts* [frames,7,9,2] device tensors (see ss_smooth_embed for the window
+        addressing) -> delta [nw,t,7,9,4].  Long clips run in chunks of WINDOW_CHUNK windows (one Conv3d launch addresses
+        < 2 GiB of input) that write into one preallocated tensor."""
         p = self._prepared()
+        if out is None:
+            out = torch.empty((nw, t, grid_h + 1, grid_w + 1, 4), device=smesh1.device, dtype=torch.float32)
         if nw > WINDOW_CHUNK and wstride <= t:
-            # long clips: windows in chunks (one Conv3d launch addresses < 2 GiB of input); window wi starts at frame
-            # wi * wstride, so a chunk is the same call on the frame range it covers
-            outs, deltas = [], []
+            # window wi starts at frame wi * wstride, so a chunk is the same call on the frame range it covers
             for s in range(0, nw, WINDOW_CHUNK):
                 m = min(WINDOW_CHUNK, nw - s)
                 f0, f1 = s * wstride, (s + m - 1) * wstride + t
-                o, d = self.run_windows(smesh1[f0:f1], smesh2[f0:f1], ts1[f0:f1], ts2[f0:f1], m, t, wstride, zero_first)
-                outs.append(o)
-                deltas.append(d)
-            return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}, torch.cat(deltas, 0)
+                self.window_deltas(smesh1[f0:f1], smesh2[f0:f1], ts1[f0:f1], ts2[f0:f1], m, t, wstride, zero_first, out[s:s + m])
+            return out
         hid = ops.smooth_embed(smesh1, smesh2, ts1, ts2, p['e1'][0], p['e1'][1], p['e3'][0], p['e3'][1], nw, t,
                                wstride, zero_first)
         for w, b in p['conv']:
             hid = ops.conv(hid, w, b, stride=1, pad=(p['pad'], 1, 1), relu=True)
-        delta = ops.linear(hid.view(-1, 128), p['dec'][0], p['dec'][1])
-        out = ops.smooth_finalize(smesh1, smesh2, ts1, ts2, delta, nw, t, wstride, zero_first)
-        return out, delta.view(nw, t, grid_h + 1, grid_w + 1, 4)
+        ops.linear(hid.view(-1, 128), p['dec'][0], p['dec'][1], out=out.view(-1, 4))
+        return out
+
+    @torch.no_grad()
+    def run_windows(self, smesh1, smesh2, ts1, ts2, nw, t, wstride, zero_first):
+        """-> (dict of the 8 build_SmoothNet tensors, each [nw,t,7,9,2]; decoder output [nw,t,7,9,4])."""
+        delta = self.window_deltas(smesh1, smesh2, ts1, ts2, nw, t, wstride, zero_first)
+        out = ops.smooth_finalize(smesh1, smesh2, ts1, ts2, delta.view(-1, 4), nw, t, wstride, zero_first)
+        return out, delta
 
     def forward(self, smesh_list1, smesh_list2, tsmotion_list1, tsmotion_list2):
         """smooth_network.py:64-101 -> (smesh1, smesh2, tsflow1, tsflow2, delta1, delta2), each [B,T,7,9,2]."""

@@ -49,24 +49,28 @@ class TemporalNet(L.PreparedMixin, nn.Module):
         n = views[0].shape[0]
         v = len(views)
         f = L.run_stage1(list(views), p['s1'])                      # [V*N,45,60,128], view-major
-        cv = torch.empty((v * (n - 1), f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
-        for i in range(v):
-            ops.cost_volume(f[i * n:i * n + n - 1], f[i * n + 1:i * n + n], 3, out=cv[i * (n - 1):(i + 1) * (n - 1)])
-        off = L.run_regressor(cv, p['r2']).view(v, n - 1, grid_h + 1, grid_w + 1, 2)
-        return [off[i] for i in range(v)]
+        return self.motions_from_view_features([f[i * n:(i + 1) * n] for i in range(v)])
 
     @torch.no_grad()
-    def motions_from_view_features(self, feats):
+    def motions_from_view_features(self, feats, zero_first=False):
         """feats: list of V nhwc tensors [N,45,60,128] (stage-1 features of every frame of a view)
-        -> list of V tensors [N-1,7,9,2]; one regressor pass for all views."""
+        -> list of V tensors [N-1,7,9,2]; one regressor pass for all views.
+        zero_first=True: -> V tensors [N,7,9,2] whose frame 0 is the zero motion (temporal_network.py:31-33), written in
+        place (the last FC layer stores every view's motions behind its zero frame; no torch.cat)."""
         p = self._prepared()
         v, n = len(feats), feats[0].shape[0]
         cv = torch.empty((v * (n - 1), feats[0].shape[1], feats[0].shape[2], 52), device=feats[0].device,
                          dtype=torch.float32)
         for i in range(v):
             ops.cost_volume(feats[i][:n - 1], feats[i][1:], 3, out=cv[i * (n - 1):(i + 1) * (n - 1)])
-        off = L.run_regressor(cv, p['r2']).view(v, n - 1, grid_h + 1, grid_w + 1, 2)
-        return [off[i] for i in range(v)]
+        if not zero_first:
+            off = L.run_regressor(cv, p['r2']).view(v, n - 1, grid_h + 1, grid_w + 1, 2)
+            return [off[i] for i in range(v)]
+        tm = torch.empty((v, n, grid_h + 1, grid_w + 1, 2), device=cv.device, dtype=torch.float32)
+        for i in range(v):
+            ops.fill(tm[i, 0])
+        L.run_regressor(cv, p['r2'], out_slices=[(i * (n - 1), (i + 1) * (n - 1), tm[i, 1:].view(n - 1, -1)) for i in range(v)])
+        return [tm[i] for i in range(v)]
 
     @torch.no_grad()
     def features(self, frames):

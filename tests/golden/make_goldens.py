@@ -324,6 +324,23 @@ def g12(nets):
 
 
 # ------------------------------------------------------------------ G11 PSNR / SSIM
+def g13(nets):
+    """uint8 in, uint8 out, as the reference's script runs on decoded video frames (test_online_tra.py:252-278, 409-417):
+    the G9 clip quantised to uint8 (what cv2.imread hands over), HR = those bytes as fp32, LR = cv2.resize(frame,
+    (480, 360)) / 127.5 - 1 -- at 360x480 the resize is the identity, so no resize arithmetic enters -- through the
+    reference's networks and get_stable_sqe (NORMAL / AVERAGE), then `stable_list[k].astype(np.uint8)` (:413).
+    Also the fp32 values of frame 0 on canvas columns where ONE view lies outside its image (tiles the product's
+    footprint skipping drops): the reference's clamped-sampler residue fused with the other view's content."""
+    hr, _ = synth.make_clip(16, 360, 480, seed=0)
+    hr = [[f.round().clamp(0, 255) for f in v] for v in hr]               # uint8-valued fp32 frames
+    lr = [[f / 127.5 - 1.0 for f in v] for v in hr]
+    acc = run_motion_stages(nets, lr[0], lr[1])['acc']
+    frames, ow, oh = RP.get_stable_sqe(hr[0], hr[1], acc['smooth_mesh1'], acc['smooth_mesh2'], 'NORMAL', 'AVERAGE')
+    save('g13_frames_u8', canvas=np.array([int(oh), int(ow)]), smooth_mesh1=acc['smooth_mesh1'], smooth_mesh2=acc['smooth_mesh2'],
+         frames_u8=np.stack([frames[0].astype(np.uint8), frames[-1].astype(np.uint8)]), frame_idx=np.array([0, len(frames) - 1]),
+         left_f32=frames[0][:, 96:160].copy(), right_f32=frames[0][:, 544:608].copy())
+
+
 def g11():
     a, b = cases.g11_images()
     (p, s), = skimage_metrics([(a, b)])
@@ -350,6 +367,8 @@ if __name__ == '__main__':
         g6_g7()
     if want('g8') or want('g9'):
         g8_g9(nets)
+    if want('g13'):
+        g13(nets)
     if want('g10'):
         g10()
     if want('g11'):

@@ -833,7 +833,7 @@ def test_two_view_720p_vs_oracle(dev, hip_nets):
     close(m1, om1, 5e-3, '720p smooth_mesh1 vs oracle')
     close(m2, om2, 5e-3, '720p smooth_mesh2 vs oracle')
     assert (hc, wc) == (ohc, owc)
-    for i in (0, n - 1):
+    for i in range(n):                 # every frame of the clip
         d = np.abs(fr[i].permute(1, 2, 0).cpu().numpy() - ofr[i])
         assert np.median(d) < 5e-3 and np.quantile(d, 0.999) < 0.1, (i, float(np.median(d)), float(np.quantile(d, 0.999)))
     k = 3
@@ -1210,8 +1210,10 @@ def test_render_footprint_skipping(dev, hip_nets, views):
         pres = True
     hc, wc, src, T = pipeline.render_plan(meshes, h, w, pres)
     fp = ops.render_footprints(src, T, h, w, hc, wc)
-    ny, nx = (hc + 7) // 8 + 1, (wc + 63) // 64 + 1
-    assert fp.shape == (n, views * ny * nx * 2 + views * 4 + (ny - 1) * (nx - 1))
+    # lattice: rows every 8 px, columns every 32 px (tile corners + long-edge midpoints); nbx tiles per row
+    nbx = (wc + 63) // 64
+    ny, nx = (hc + 7) // 8 + 1, 2 * nbx + 1
+    assert fp.shape == (n, views * ny * nx * 2 + views * 4 + (ny - 1) * nbx)
     assert bool(torch.isfinite(fp[:, :views * ny * nx * 2 + views * 4]).all())
     skipped_frac = []
     for i in (0, n - 1):
@@ -1222,8 +1224,8 @@ def test_render_footprint_skipping(dev, hip_nets, views):
         # re-derive the tile classification on the host from the footprint block
         lat = fp[i, :views * ny * nx * 2].view(views, ny, nx, 2)
         hull = fp[i, views * ny * nx * 2:views * ny * nx * 2 + 4 * views].view(views, 4)
-        need = torch.ones((views, ny - 1, nx - 1), dtype=torch.bool, device=dev)
-        bxs = torch.arange(nx - 1, device=dev, dtype=torch.float32)
+        need = torch.ones((views, ny - 1, nbx), dtype=torch.bool, device=dev)
+        bxs = torch.arange(nbx, device=dev, dtype=torch.float32)
         bys = torch.arange(ny - 1, device=dev, dtype=torch.float32)
         tx0 = -1 + 2.0 / (wc - 1) * (64 * bxs - 8); tx1 = -1 + 2.0 / (wc - 1) * (64 * bxs + 71)
         ty0 = -1 + 2.0 / (hc - 1) * (8 * bys - 8); ty1 = -1 + 2.0 / (hc - 1) * (8 * bys + 15)
@@ -1231,7 +1233,7 @@ def test_render_footprint_skipping(dev, hip_nets, views):
             off_hull = ((tx1 < hull[v, 0]) | (tx0 > hull[v, 1]))[None, :] | ((ty1 < hull[v, 2]) | (ty0 > hull[v, 3]))[:, None]
             off_img = torch.zeros_like(off_hull)
             for c, m in ((0, 1.0 + 16.0 / w), (1, 1.0 + 16.0 / h)):
-                q = torch.stack((lat[v, :-1, :-1, c], lat[v, :-1, 1:, c], lat[v, 1:, :-1, c], lat[v, 1:, 1:, c]), 0)
+                q = torch.stack([lat[v, r:ny - 1 + r, k:k + 2 * nbx:2, c] for r in (0, 1) for k in (0, 1, 2)], 0)
                 off_img |= (q.min(0).values > m) | (q.max(0).values < -m)
             need[v] = ~(off_hull & off_img)
         tile = need.repeat_interleave(8, 1).repeat_interleave(64, 2)[:, :hc, :wc]                           # per pixel

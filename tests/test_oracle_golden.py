@@ -213,6 +213,26 @@ def test_g9_pipeline(golden, clip16, stages):
     assert abs(M.distortion_score(m2) - float(g['distortion'])) < 1e-5
 
 
+def test_g13_uint8_frames(golden):
+    """The oracle on the uint8-quantised clip against what the reference's writer stores (`.astype(np.uint8)`,
+    test_online_tra.py:413) and against the reference's fp32 pixels where one view lies outside its image: rendered with
+    the golden meshes, the oracle IS the reference's arithmetic there -- identical bytes, identical residue."""
+    g = golden('g13_frames_u8')
+    hr, _ = synth.make_clip(16, 360, 480, seed=0)
+    hr = [[f.round().clamp(0, 255) for f in v] for v in hr]
+    m1 = torch.from_numpy(g['smooth_mesh1'])
+    m2 = torch.from_numpy(g['smooth_mesh2'])
+    idx = [int(i) for i in g['frame_idx']]
+    frames, ow, oh = P.get_stable_sqe(hr[0], hr[1], m1, m2, 'NORMAL', 'AVERAGE')          # the canvas is the box of ALL frames
+    frames = [frames[i] for i in idx]
+    assert [int(oh), int(ow)] == list(g['canvas'])
+    for j in range(len(idx)):
+        d = np.abs(frames[j].astype(np.uint8).astype(np.int16) - g['frames_u8'][j].astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3, (j, int(d.max()), float((d != 0).mean()))
+    close(frames[0][:, 96:160], g['left_f32'], 2e-2, 'left strip (view 2 outside)')
+    close(frames[0][:, 544:608], g['right_f32'], 2e-2, 'right strip (view 1 outside)')
+
+
 def test_g10_three_view(golden):
     g = golden('g10_threeview')
     m12_1, m12_2, m23_1, m23_2 = cases.g10_meshes()
