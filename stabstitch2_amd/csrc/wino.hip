@@ -1141,6 +1141,7 @@ int g_wino_ablate = 0;                   // ss_debug_set key 6
 int g_wino_nb1_max_cin = 0;              // ss_debug_set key 5
 int g_wino_variant = 0;                  // ss_debug_set key 7: 0 stream kernel (dispatched), 1 phase-alternating kernel, 2 pair kernel
 int g_wino_knob[4] = {0, 0, 0, 0};       // ss_debug_set keys 16..19
+int g_wino_lds_pad = 0;                  // ss_debug_set key 20: extra dynamic LDS bytes per workgroup (1 workgroup per CU from 32 KB up)
 #else
 constexpr int g_wino_nb1_max_cin = 0;
 #endif
@@ -1256,12 +1257,17 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
         return ss_launch_status();
     }
 #endif
+#ifdef SS_TUNING
+    const unsigned dyn = (unsigned)g_wino_lds_pad;
+#else
+    const unsigned dyn = 0u;
+#endif
     if (tbh == 8) {
-        if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true>), g, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true>), g, dim3(256), 0, st, p);
+        if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true>), g, dim3(256), dyn, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true>), g, dim3(256), dyn, st, p);
     } else {
-        if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, true>), g, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true>), g, dim3(256), 0, st, p);
+        if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, true>), g, dim3(256), dyn, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true>), g, dim3(256), dyn, st, p);
     }
     return ss_launch_status();
 }

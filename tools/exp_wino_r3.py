@@ -9,9 +9,13 @@ lib = _tuning.lib()
 dev = torch.device('cuda:0')
 SHAPES = {'layer1': (64, 90, 120, 64, 64), 'layer2': (64, 45, 60, 128, 128), 'layer3': (64, 23, 30, 256, 256),
           'reg': (64, 45, 60, 124, 64)}
-CONFIGS = [('base', {})] + [('stagger%d' % k, {0: k}) for k in (8, 16, 32, 64)] + \
-          [('eprio%d' % (v - 1), {1: v}) for v in (1, 2, 3)] + [('pprio%d' % (v - 1), {2: v}) for v in (1, 2, 3)] + \
-          [('kprio1', {3: 2}), ('kprio1+eprio2', {3: 2, 1: 3}), ('stagger16+eprio1', {0: 16, 1: 2})]
+CONFIGS = [('base', {})] + [('stagger%d' % k, {0: k}) for k in (8, 16)] + \
+          [('eprio1', {1: 2}), ('pprio1', {2: 2}), ('e1p1', {1: 2, 2: 2}), ('e1p1s8', {1: 2, 2: 2, 0: 8}), ('e1p1s16', {1: 2, 2: 2, 0: 16}),
+           ('e0p1', {1: 1, 2: 2}), ('e1p0', {1: 2, 2: 1}), ('e2p2', {1: 3, 2: 3}), ('base2', {})]
+if os.environ.get('WINO_CONFIGS') == 'first':
+    CONFIGS = [('base', {})] + [('stagger%d' % k, {0: k}) for k in (8, 16, 32, 64)] + \
+              [('eprio%d' % (v - 1), {1: v}) for v in (1, 2, 3)] + [('pprio%d' % (v - 1), {2: v}) for v in (1, 2, 3)] + \
+              [('kprio1', {3: 2}), ('kprio1+eprio2', {3: 2, 1: 3}), ('stagger16+eprio1', {0: 16, 1: 2})]
 names = sys.argv[1].split(',') if len(sys.argv) > 1 else list(SHAPES)
 for name in names:
     n, h, w, cin, cout = SHAPES[name]
