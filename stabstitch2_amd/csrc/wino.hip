@@ -98,7 +98,10 @@ typedef float w_f32x2 __attribute__((ext_vector_type(2)));
 // NB = 32-channel output blocks per workgroup: 2 (64 channels, 128 accumulator registers, two workgroups per CU) or
 // 1 (32 channels, 64 accumulator registers, THREE workgroups per CU: the epilogue / prologue of one workgroup hides
 // behind the MFMAs of two others -- the short-K layers (cin = 64: 4 chunks) spend a quarter of a workgroup's life there)
-template <int TBH, int TBW, int NB, bool RES, bool STREAM, bool SLICED = false>
+// VAR (stream schedule only): 0 = round-2 placement of the loads; 1 = the filter loads of block (1, 2) are issued at the END of
+// block (0, 2), i.e. BEFORE the next chunk's raw-patch loads (buffer loads return in order: a wait for a filter load also waits
+// for every older load, and the raw patch mostly comes from HBM)
+template <int TBH, int TBW, int NB, bool RES, bool STREAM, bool SLICED = false, int VAR = 0>
 __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p) {
     static_assert(TBH * TBW == 32, "32 tiles per workgroup");
     static_assert(!STREAM || NB == 2, "the stream schedule is written for 64-channel blocks");
@@ -328,8 +331,12 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         }
     } else
     if constexpr (STREAM) {
+        // compile-time ablations of the stream (tuning build, timing only -- results are wrong): VAR = 16 + mask,
+        // 1 no filter loads, 2 no raw-patch loads, 4 no LDS staging writes, 8 no LDS reads / transform, 16 no barrier
+        constexpr int ABL = VAR >= 16 ? VAR - 16 : 0;
         w_f32x4 rr[NE];
         auto raw_issue = [&](int c) {
+            if constexpr (ABL & 2) return;
             const unsigned coff = (unsigned)c * 64u;
             const unsigned cinv = ((c * 16 + 4 * myq) < p.C) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
                 rr[e] = __builtin_bit_cast(w_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase[e] + coff) | rinv[e] | cinv, 0, 0));
         };
         auto raw_store = [&](float* buf) {
+            if constexpr (ABL & 4) return;
 #pragma unroll
             for (int e = 0; e < NE; ++e)
 #pragma unroll
@@ -344,8 +352,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         };
         // filters of one BLOCK = (chunk c, position 4 wave + j, half h): u[blk] = 4 floats = MFMA steps 4 h .. 4 h + 3.
         // Four register sets: block k multiplies with set k & 3 while the loads of block k + 3 go to the set block k - 1 used.
-        w_f32x4 u[4][NB];
+        w_f32x4 u[4][NB] = {};
         auto u_issue = [&](int set, int c, int j, int h) {
+            if constexpr (ABL & 1) return;
             const unsigned base = u_wave + (unsigned)c * 32768u + (unsigned)j * 2048u;
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
@@ -354,11 +363,18 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             }
         };
         float av[4][8];              // A operands: av[j][s] = V[position 4 wave + j][tile][channel 8 kh + s]
+        if constexpr (ABL & 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) av[j][q] = (float)(lane + j + q);
+        }
         const w_f32x2 t_sg = wave == 1 ? (w_f32x2){1.f, 1.f} : (w_f32x2){-1.f, -1.f};     // row stage: d[ra] + sg * d[rb] (exact)
         // the input transform, one channel at a time: rd() requests the two patch rows, xf() (one block later) turns them
         // into the four A operands of that channel
-        w_f32x2 tq[4];
+        w_f32x2 tq[4] = {};
         auto rd = [&](const float* buf, int ch) {
+            if constexpr (ABL & 8) return;
             const float* pa = buf + t_src + ch * PLANE + t_ra * RWP;
             const float* pb = buf + t_src + ch * PLANE + t_rb * RWP;
             tq[0] = *reinterpret_cast<const w_f32x2*>(pa);
@@ -367,6 +383,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             tq[3] = *reinterpret_cast<const w_f32x2*>(pb + 2);
         };
         auto xf = [&](int ch) {
+            if constexpr (ABL & 8) return;
             const w_f32x2 r0 = __builtin_elementwise_fma(tq[2], t_sg, tq[0]);      // (r0, r1)
             const w_f32x2 r1 = __builtin_elementwise_fma(tq[3], t_sg, tq[1]);      // (r2, r3)
             const w_f32x2 d = r0 - r1;                                             // (r0 - r2, r1 - r3) = positions 0 and 3
@@ -378,10 +395,14 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
         // 8 MFMAs: position j, channels 4 h .. 4 h + 3 of the chunk, both 32-channel blocks alternating
         auto mma = [&](int set, int j, int h) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk)
                     acc[j][blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][4 * h + s], u[set][blk][s], acc[j][blk], 0, 0, 0);
+                // VAR 2 (experiment): keep the two accumulators of a position ALTERNATING (left alone the scheduler issues four
+                // MFMAs on one accumulator, then four on the other: back-to-back dependent MFMAs with fillers in between)
+                if (VAR == 2) __builtin_amdgcn_sched_barrier(0);
+            }
         };
         // interleave pattern of one block: the block's 2 LDS reads behind the first MFMAs, its 2 filter loads behind the next
         // two, `DSW` LDS writes per MFMA where the block stages a raw patch, VALU work everywhere
@@ -400,6 +421,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             }                                                                               \
         } while (0)
         auto lds_barrier = [&]() {       // __syncthreads() minus its global-memory fence (it would drain every prefetch in flight)
+            if constexpr (ABL & 16) return;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -441,10 +463,12 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             __builtin_amdgcn_sched_barrier(0);
             xf(6); rd(bc, 7); raw_store(bn); mma(2, 2, 0); u_issue(1, c, 1, 1); W_SGB_BLOCK(1, 1);
             __builtin_amdgcn_sched_barrier(0);
+            if (VAR == 1) { u_issue(2, c, 2, 1); __builtin_amdgcn_sched_barrier(0); }
             lds_barrier();
             __builtin_amdgcn_sched_barrier(0);
             raw_issue(cnn);
-            xf(7); rd(bn, 0); mma(3, 3, 0); u_issue(2, c, 2, 1); W_SGB_BLOCK(0, 1);
+            if (VAR == 1) { xf(7); rd(bn, 0); mma(3, 3, 0); W_SGB_BLOCK(0, 1); }
+            else { xf(7); rd(bn, 0); mma(3, 3, 0); u_issue(2, c, 2, 1); W_SGB_BLOCK(0, 1); }
             __builtin_amdgcn_sched_barrier(0);
             xf(0); rd(bn, 1); mma(0, 0, 1); u_issue(3, c, 3, 1); W_SGB_BLOCK(0, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1259,6 +1283,34 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
 #endif
 #ifdef SS_TUNING
     const unsigned dyn = (unsigned)g_wino_lds_pad;
+    if (g_wino_variant >= 100 && tbh == 8 && res) {       // stream ablations (timing only): variant = 100 + mask
+        switch (g_wino_variant - 100) {
+#define W_ABL_CASE(m) case m: hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true, false, 16 + m>), g, dim3(256), dyn, st, p); return ss_launch_status();
+            W_ABL_CASE(1) W_ABL_CASE(2) W_ABL_CASE(4) W_ABL_CASE(8) W_ABL_CASE(16) W_ABL_CASE(3) W_ABL_CASE(12) W_ABL_CASE(15) W_ABL_CASE(31)
+#undef W_ABL_CASE
+            default: break;
+        }
+    }
+    if (g_wino_variant == 4) {      // accumulator-alternation experiment (VAR = 2)
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true, false, 2>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true, false, 2>), g, dim3(256), dyn, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, true, false, 2>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true, false, 2>), g, dim3(256), dyn, st, p);
+        }
+        return ss_launch_status();
+    }
+    if (g_wino_variant == 3) {      // load-order experiment (VAR = 1)
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true, false, 1>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true, false, 1>), g, dim3(256), dyn, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, true, false, 1>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true, false, 1>), g, dim3(256), dyn, st, p);
+        }
+        return ss_launch_status();
+    }
 #else
     const unsigned dyn = 0u;
 #endif

@@ -13,15 +13,18 @@ for name, (n, h, w, cin, cout) in SHAPES.items():
     x = torch.randn(n, h, w, cin, device=dev); wt = torch.randn(cout, 1, 3, 3, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     out = ops.conv_winograd(x, wt, b, None, relu=True)
     res = torch.randn_like(out)
-    for pad, what in ((0, 'two workgroups per CU'), (40960, 'ONE workgroup per CU')):
-        lib.ss_debug_set(20, pad)
+    for var, pad, what in ((0, 0, 'two workgroups per CU'), (0, 40960, 'ONE workgroup per CU'), (4, 0, 'VAR2 two per CU'), (4, 40960, 'VAR2 ONE per CU')):
+        lib.ss_debug_set(20, pad); lib.ss_debug_set(7, var)
+        ref = None if var == 0 else keep
         for _ in range(3): ops.conv_winograd(x, wt, b, res, relu=True, out=out)
         torch.cuda.synchronize()
+        if var == 0: keep = out.clone()
+        else: assert torch.equal(out, keep), 'variant differs'
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): ops.conv_winograd(x, wt, b, res, relu=True, out=out)
+        for _ in range(20): ops.conv_winograd(x, wt, b, res, relu=True, out=out)
         e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 5 * 1e3
+        us = e0.elapsed_time(e1) / 20 * 1e3
         dbg = torch.zeros((1 << 16, 10), dtype=torch.int64, device=dev)
         lib.ss_debug_ptr(ctypes.c_void_p(dbg.data_ptr()))
         ops.conv_winograd(x, wt, b, res, relu=True, out=out)
@@ -33,4 +36,4 @@ for name, (n, h, w, cin, cout) in SHAPES.items():
         print('%s [%s]: %.1f us; per workgroup median ticks: prologue %d | K loop %d = %d per chunk (pipe pace 4096: %.0f %%) | '
               'epilogue %d | total %d' % (name, what, us, med(d[:, 1] - d[:, 0]), med(d[:, 2] - d[:, 1]), med(d[:, 2] - d[:, 1]) // nch,
                                          100.0 * 4096 * nch / med(d[:, 2] - d[:, 1]), med(d[:, 8] - d[:, 2]), med(d[:, 8] - d[:, 0])))
-    lib.ss_debug_set(20, 0)
+    lib.ss_debug_set(20, 0); lib.ss_debug_set(7, 0)
