@@ -249,7 +249,7 @@ def test_u8_pipeline_bytes_vs_reference(dev, golden, hip_nets):
         frac = max(frac, float((d != 0).mean()))
     if os.environ.get('SS_VERBOSE'):
         print('  u8 vs reference inside both footprints: max |diff| %d, differing bytes %.2e' % (worst, frac))
-    assert worst <= 1 and frac <= 5e-3, (worst, frac)
+    assert worst <= 1 and frac <= 2e-3, (worst, frac)            # observed: max 1, 6.0e-4 of the bytes
 
 
 def test_skip_outside_region_vs_reference_pixels(dev, golden, hip_nets):
@@ -281,7 +281,7 @@ def test_skip_outside_region_vs_reference_pixels(dev, golden, hip_nets):
             d = np.abs(got - ref)[valid[sl]]
             if os.environ.get('SS_VERBOSE'):
                 print('  %s strip, %s evaluation vs reference: max %.2e median %.2e' % (name, what, d.max(), np.median(d)))
-            assert float(d.max()) <= (8e-3 if what == 'skip' else 8e-3) + 5e-2 * 0, (name, what, float(d.max()))
+            assert float(d.max()) <= 8e-3, (name, what, float(d.max()))      # observed: skip 2.2e-3, full 3.9e-3
     # and the skipped view really is skipped on part of those strips (else this test shows nothing)
     assert bool((skip[0] != full[0]).any())
 
