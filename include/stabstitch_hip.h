@@ -77,6 +77,16 @@ SS_API int ss_nchw_to_nhwc3_padded(const float* in, float* out, int n, int h, in
 SS_API int ss_conv_stem3(const float* in_padded, const float* wgt, const float* bias, float* out, int n, int h, int w,
                          int cout, int relu, int out_cs, int groups, long long in_gs, long long w_gs, long long out_gs,
                          void* stream);
+/* the whole stem in ONE kernel: Conv2d(3, 64, 7, 2, 3) + folded BN + ReLU + MaxPool2d(3, 2, 1) (spatial_network.py:127-130,
+ * temporal_network.py:47-50) for `groups` 64-filter banks reading the same frames; the un-pooled 64-channel map is never
+ * written (csrc/stem.hip).
+ *   ss_stem_pool_pack    wgt [groups][64][7][24] (the ss_conv_stem3 layout) -> packed, ss_stem_pool_packed_floats(groups) floats
+ *   ss_stem_pool         in_padded [n][h][w + 8][3] (ss_nchw_to_nhwc3_padded); bias [groups][64] or NULL;
+ *                        out [groups][n][hp][wp][64], group stride out_gs floats, hp = ((h-1)/2)/2 + 1, wp likewise */
+SS_API long long ss_stem_pool_packed_floats(int groups);
+SS_API int ss_stem_pool_pack(const float* wgt, float* packed, int groups, void* stream);
+SS_API int ss_stem_pool(const float* in_padded, const float* packed, const float* bias, float* out, int n, int h, int w,
+                 int groups, long long out_gs, void* stream);
 
 /* ---- the same convolution for 3x3 / stride 1 / pad 1 layers as fused Winograd F(2x2,3x3) on the fp32 matrix cores
  * (2.25x fewer MFMA flops; input and output transforms inside the GEMM kernel, nothing extra through HBM).  Replaces

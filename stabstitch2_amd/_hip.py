@@ -27,6 +27,9 @@ SIGNATURES = {
     'ss_conv_nhwc': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 15 + [c_i, c_ll, c_ll, c_ll, c_fp, c_ll, c_st]),
     'ss_nchw_to_nhwc3_padded': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_conv_stem3': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_ll] * 3 + [c_st]),
+    'ss_stem_pool_packed_floats': (c_ll, [c_i]),
+    'ss_stem_pool_pack': (c_i, [c_fp, c_fp, c_i, c_st]),
+    'ss_stem_pool': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_ll, c_st]),
     'ss_wino_packed_floats': (c_ll, [c_i, c_i]),
     'ss_wino_packed3_floats': (c_ll, [c_i, c_i]),
     'ss_wino_pack': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),

@@ -1,0 +1,334 @@
+// The trunk's stem in ONE kernel: Conv2d(3, 64, 7, stride 2, pad 3) + folded BatchNorm + ReLU + MaxPool2d(3, 2, 1)
+// (spatial_network.py:127-130, temporal_network.py:47-50), for `groups` filter banks that read the same frames (the
+// SpatialNet and TemporalNet stems of the shared-stem path) -- fp32 MFMA, gfx950.
+//
+// Why: as two kernels (ss_conv_stem3 + ss_maxpool_nhwc) the conv writes its 180 x 240 x 128-channel output (1.4 GB per 64
+// images) and the pool reads it back: 19 % of all HBM bytes of a clip for 0.47 ms of pool launches, on top of a conv whose
+// implicit-GEMM workgroups walk only six K tiles each (prologue + epilogue = 35 % of a workgroup's life, MFMA pipe 57 % busy).
+// Here a workgroup owns a 2-D tile of POOLED pixels, computes the conv outputs that feed it (one ring of halo) and pools them
+// in its epilogue: the un-pooled map never exists in memory.
+//
+//   workgroup = 256 threads = 4 waves; tile = 9 x 12 pooled pixels x 64 channels of ONE image and ONE filter bank;
+//   conv region = 19 x 25 pixels (rows 2 py0 - 1 .. 2 py0 + 17, columns 2 px0 - 1 .. 2 px0 + 23) = 475 GEMM rows, padded to
+//   16 row tiles of 32 (the map 90 x 120 is 10 x 10 tiles exactly; 512 computed rows per 432 conv pixels a non-overlapping
+//   tiling would need: 1.185x the MFMA work, the price of never writing the un-pooled map);
+//   K = 7 filter rows x 24 (21 = 7 taps x 3 channels, + 3 zero weights) = 168 = 21 groups of 8, on the row-packed 3-channel
+//   frames of ss_nchw_to_nhwc3_padded (a filter row is 24 contiguous floats of an image row);
+//   wave w owns row tiles 4 w .. 4 w + 3 x both 32-channel halves: 8 accumulator tiles of v_mfma_f32_32x32x2_f32 = 128 registers.
+//   * the 43 x 168-float input patch is staged once into LDS (coalesced 16-byte buffer loads; rows outside the image and the
+//     one column left of it come back as zeros / harmless neighbours through the descriptor's bounds check -- they only feed conv
+//     pixels outside the map, which the pool skips);
+//   * K loop: per group of 8 k a lane reads its 4 A values per row tile straight from the patch (k is permuted so that lane half
+//     h takes k = 8 g + 4 h + s: one 16-byte LDS read per row tile feeds 8 MFMAs; pixels are 24 bytes apart: conflict free) and
+//     its 4 B values per channel half from filters PRE-PACKED in that register layout (ss_stem_pool_pack; 1 KB coalesced loads,
+//     L2 resident): 10 loads and no VALU instruction per 32 MFMAs;
+//   * epilogue, per 32-channel half: accumulators -> LDS [conv pixel][32] (aliases the patch), then every thread pools 3 x 3
+//     windows of (pixel, 4 channels) with 16-byte LDS reads, adds the folded-BN bias, applies ReLU and stores 16 bytes.
+//     max(relu(x + b)) == relu(max(x) + b) bit for bit (rounding is monotone), so bias / ReLU run on the pooled values.
+// Results equal conv + ReLU + pool of the two-kernel path up to the summation order of the K axis (fp32 rounding).
+#include "common.h"
+#include <type_traits>
+
+typedef float sp_f32x16 __attribute__((ext_vector_type(16)));
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
+
+#define SP_PR 9                          // pooled rows / columns of a workgroup tile
+#define SP_PC 12
+#define SP_CR (2 * SP_PR + 1)            // conv rows / columns feeding it
+#define SP_CC (2 * SP_PC + 1)
+#define SP_M (SP_CR * SP_CC)             // 475 GEMM rows
+#define SP_PROWS (2 * SP_CR + 5)         // 43 input rows
+#define SP_PFLOATS (6 * (SP_CC - 1) + 24)    // 168 floats of an input row
+#define SP_PITCH 172                     // LDS pitch of a patch row (floats; 16-byte multiple)
+#define SP_NG 21                         // K groups of 8
+
+struct StemP {
+    const float* in;             // [n][h][w + 8][3]
+    const float* packed;         // [groups][2][21][64][4]
+    const float* bias;           // [groups][64] or nullptr
+    float* out;                  // [groups][n][hp][wp][64]
+    int n, h, w, ho, wo, hp, wp, groups;
+    unsigned ntx, nty;
+    SsDiv32 divTx, divTy, divG;
+    long long out_gs;
+    unsigned in_bytes, pk_bytes;
+#ifdef SS_TUNING
+    unsigned long long* dbg;     // per-workgroup phase stamps (tools/diag_stem.py)
+    int stagger;
+#endif
+};
+
+#ifdef SS_TUNING
+extern int g_wino_lds_pad;
+extern int g_wino_knob[4];
+#define SP_STAMP(i) do { if (p.dbg) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SP_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(const float* base, unsigned bytes) {
+    unsigned long long a = (unsigned long long)base;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* ub = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
+    // the input patch [43][172] during the K loop; the staged accumulators [512][32] in the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[512 * 32];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h2 = lane >> 5, ln = lane & 31;
+#ifdef SS_TUNING
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    SP_STAMP(0);
+    // prologue and epilogue are VALU / LDS work that shares its SIMD with the OTHER resident workgroup's dense MFMA stream: at
+    // equal priority each of their instructions waits for an MFMA boundary (64 clocks).  Raised priority lets them through.
+    __builtin_amdgcn_s_setprio(3);
+#ifdef SS_TUNING
+    // experiment (ss_debug_set key 16, units of 1024 clocks): the second resident workgroup of a CU (LDS base != 0) sleeps in the
+    // FIRST round so that the two run in anti-phase (all workgroups have the same length: left alone they stay in lock-step)
+    if (p.stagger > 0 && blockIdx.x < 512u && (__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0x1FFu) != 0u) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger * 1024ull) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+
+    // consecutive workgroups = the filter banks of one tile (they read the same patch), then the next tile of the image
+    const unsigned lin = blockIdx.x;
+    const unsigned tile = ss_div32(lin, p.divG);
+    const unsigned grp = lin - tile * (unsigned)p.groups;
+    const unsigned t1 = ss_div32(tile, p.divTx);
+    const int tx = (int)(tile - t1 * p.ntx);
+    const unsigned img = ss_div32(t1, p.divTy);
+    const int ty = (int)(t1 - img * p.nty);
+    const int py0 = ty * SP_PR, px0 = tx * SP_PC;
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;
+
+    const __amdgpu_buffer_rsrc_t rin = sp_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rpk = sp_rsrc(p.packed, p.pk_bytes);
+
+    // ---- stage the input patch: rows 2 cy0 - 3 .. + 42 of the image, floats 6 cx0 .. + 167 of the padded 3-channel row.
+    // Thread = (row slot, float4 of the row): 6 rows x 42 float4 per pass (252 threads), 8 passes; one division per thread, the
+    // rest is adds (prologue / epilogue instructions are paid for at the neighbouring workgroup's MFMA cadence: few of them).
+    {
+        constexpr int Q = SP_PFLOATS / 4;                   // 42 float4 per row
+        const int slot = tid / Q, q = tid - slot * Q;       // slot 0..5 (6: idle threads 252..255)
+        const long long rowf = (long long)(p.w + 8) * 3;
+        const int iy0 = 2 * cy0 - 3 + slot;
+        long long off = ((long long)img * p.h + iy0) * rowf + 6 * cx0 + 4 * q;      // floats; < 0 left of the very first row
+        float* dst = smem + slot * SP_PITCH + 4 * q;
+#pragma unroll
+        for (int i = 0; i < (SP_PROWS + 5) / 6; ++i) {
+            const int pr = slot + 6 * i, iy = iy0 + 6 * i;
+            const bool ok = slot < 6 && pr < SP_PROWS && (unsigned)iy < (unsigned)p.h && off >= 0;
+            const sp_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (unsigned)(off * 4) : 0xFFFFFFFFu, 0, 0);
+            if (slot < 6 && pr < SP_PROWS) *reinterpret_cast<sp_u32x4*>(dst) = v;
+            off += 6 * rowf;
+            dst += 6 * SP_PITCH;
+        }
+    }
+
+    // this lane's GEMM rows: row tile mt of the wave -> conv pixel (r, c) of the region -> first float of its window in the patch
+    int abase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int m = 32 * (4 * wave + mt) + ln;
+        m = m < SP_M ? m : SP_M - 1;                        // rows 475 .. 511: idle copies of the last pixel
+        const int r = m / SP_CC, c = m - r * SP_CC;
+        abase[mt] = (2 * r) * SP_PITCH + 6 * c + 4 * h2;
+    }
+    const unsigned pk_lane = (unsigned)lane * 16u;
+    const unsigned pk_grp = grp * (2u * SP_NG * 1024u);
+
+    sp_f32x16 acc[4][2];
+    const sp_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+    SP_STAMP(1);
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- K loop: 21 groups of 8 k; group g = filter row g / 3, floats 8 (g % 3) .. + 7 of its 24
+    sp_f32x4 a_cur[4], b_cur[2], a_nxt[4], b_nxt[2];
+    auto load = [&](int g, sp_f32x4 (&a)[4], sp_f32x4 (&b)[2]) {
+        const int koff = (g / 3) * SP_PITCH + (g % 3) * 8;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float* ap = smem + abase[mt] + koff;
+            const sp_f32x2 lo = *reinterpret_cast<const sp_f32x2*>(ap);
+            const sp_f32x2 hi = *reinterpret_cast<const sp_f32x2*>(ap + 2);
+            a[mt] = (sp_f32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int so = (int)__builtin_amdgcn_readfirstlane(pk_grp + (unsigned)(nt * SP_NG + g) * 1024u);
+            b[nt] = __builtin_bit_cast(sp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpk, pk_lane, so, 0));
+        }
+    };
+    load(0, a_cur, b_cur);
+#pragma unroll
+    for (int g = 0; g < SP_NG; ++g) {
+        // the next group's operands are requested BEFORE this group's 32 MFMAs (pinned: left alone, hipcc sinks the loads to
+        // the end of the group, right in front of their first use, and every group pays an L2 round trip)
+        if (g + 1 < SP_NG) load(g + 1, a_nxt, b_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    // the very first product of a tile starts from the instruction's inline 0 (no 128 v_mov to clear the tiles)
+                    const sp_f32x16 c0 = (g == 0 && s == 0) ? zero16 : acc[mt][nt];
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][s], b_cur[nt][s], c0, 0, 0, 0);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a_cur[mt] = a_nxt[mt];
+        b_cur[0] = b_nxt[0];
+        b_cur[1] = b_nxt[1];
+    }
+
+    SP_STAMP(2);
+    __builtin_amdgcn_s_setprio(3);
+    // ---- epilogue: per 32-channel half stage the accumulators as [conv pixel][32], pool 3 x 3 / stride 2, bias, ReLU, store
+    __syncthreads();                                        // every wave is done with the patch (the stage aliases it)
+    SP_STAMP(3);
+    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    // a tile is INTERIOR when every tap of every pooled pixel lies inside the conv map (81 of the 100 tiles of a 90 x 120 map):
+    // no padding logic at all.  Border tiles replace the taps outside the map (row / column -1 of the image, or beyond a partial
+    // last tile) by -inf, MaxPool2d's padding.  Either way branch free per tap: all nine taps lie inside the staged region, the
+    // nine 16-byte LDS reads of an item go out back to back (with a branch per tap they went one at a time: 59k clocks of epilogue
+    // beside 45k of K loop), and the 3 x 3 maximum is four v_max3_f32 per channel.
+    const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + SP_CR <= p.ho && cx0 + SP_CC <= p.wo;
+    // a thread's items all have the same channel quad (item & 7 = tid & 7): its two bias quads are loaded once
+    sp_f32x4 bias4[2] = {(sp_f32x4){0.f, 0.f, 0.f, 0.f}, (sp_f32x4){0.f, 0.f, 0.f, 0.f}};
+    if (p.bias) {
+        bias4[0] = *reinterpret_cast<const sp_f32x4*>(p.bias + grp * 64 + 4 * (tid & 7));
+        bias4[1] = *reinterpret_cast<const sp_f32x4*>(p.bias + grp * 64 + 32 + 4 * (tid & 7));
+    }
+    auto pool = [&](int nt, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+#pragma unroll
+        for (int it = 0; it < (SP_PR * SP_PC * 8 + 255) / 256; ++it) {
+            const int item = tid + 256 * it;
+            const int q = item & 7;
+            int pp = item >> 3;
+            pp = pp < SP_PR * SP_PC ? pp : SP_PR * SP_PC - 1;
+            const int a = pp / SP_PC, b = pp - a * SP_PC;
+            const int py = py0 + a, px = px0 + b;
+            const float* sp = smem + ((2 * a) * SP_CC + 2 * b) * 32 + 4 * q;
+            sp_f32x4 v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const sp_f32x4*>(sp + ((t / 3) * SP_CC + (t % 3)) * 32);
+            if constexpr (MASKED) {
+                bool rok[3], cok[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    rok[d] = (unsigned)(cy0 + 2 * a + d) < (unsigned)p.ho;
+                    cok[d] = (unsigned)(cx0 + 2 * b + d) < (unsigned)p.wo;
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const bool ok = rok[t / 3] && cok[t % 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[t][k] = ok ? v[t][k] : -INFINITY;
+                }
+            }
+            const sp_f32x4 bb = bias4[nt];
+            sp_f32x4 mx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float r0 = fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]);
+                const float r1 = fmaxf(fmaxf(v[3][k], v[4][k]), v[5][k]);
+                const float r2 = fmaxf(fmaxf(v[6][k], v[7][k]), v[8][k]);
+                mx[k] = fmaxf(fmaxf(fmaxf(r0, r1), r2) + bb[k], 0.f);
+            }
+            if (item < SP_PR * SP_PC * 8 && py < p.hp && px < p.wp)
+                *reinterpret_cast<sp_f32x4*>(out + (((long long)img * p.hp + py) * p.wp + px) * 64 + 32 * nt + 4 * q) = mx;
+        }
+    };
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (4 * wave + mt) + 8 * (r >> 2) + (r & 3) + 4 * h2;
+                smem[row * 32 + ln] = acc[mt][nt][r];
+            }
+        __syncthreads();
+        if (nt == 0) SP_STAMP(4); else SP_STAMP(6);
+        if (interior) pool(nt, std::false_type{}); else pool(nt, std::true_type{});
+        if (nt == 0) SP_STAMP(5);
+        if (nt == 0) __syncthreads();                       // the second half overwrites the stage
+    }
+#ifdef SS_TUNING
+    if (p.dbg && tid == 0) {
+        unsigned long long* d = p.dbg + (size_t)blockIdx.x * 10;
+        for (int i = 0; i < 7; ++i) d[i] = ts[i];
+        d[8] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+}
+
+// filters [groups][64][7][24] (layers.pack_stem3: w[co][dh][3 dw + c], entries 21..23 of a row zero, BN folded) ->
+// packed [groups][2][21][64 lanes][4]: lane (n = lane & 31, h = lane >> 5), float s = w[32 nt + n][k = 8 g + 4 h + s]
+__global__ void stem_pool_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int groups) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;           // (grp, nt, g, lane)
+    const int total = groups * 2 * SP_NG * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    int r = idx >> 6;
+    const int g = r % SP_NG;
+    r /= SP_NG;
+    const int nt = r & 1, grp = r >> 1;
+    const int co = 32 * nt + (lane & 31);
+    const float* src = w + ((long long)grp * 64 + co) * 168 + 8 * g + 4 * (lane >> 5);
+    reinterpret_cast<float4*>(packed)[idx] = make_float4(src[0], src[1], src[2], src[3]);
+}
+
+extern "C" long long ss_stem_pool_packed_floats(int groups) { return groups > 0 ? (long long)groups * 2 * SP_NG * 64 * 4 : 0; }
+
+extern "C" int ss_stem_pool_pack(const float* wgt, float* packed, int groups, void* stream) {
+    if (!wgt || !packed || groups <= 0) return SS_ERR_ARG;
+    const int total = groups * 2 * SP_NG * 64;
+    hipLaunchKernelGGL(stem_pool_pack_kernel, dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, wgt, packed, groups);
+    return ss_launch_status();
+}
+
+extern "C" int ss_stem_pool(const float* in_padded, const float* packed, const float* bias, float* out, int n, int h, int w,
+                            int groups, long long out_gs, void* stream) {
+    if (!in_padded || !packed || !out || n <= 0 || h <= 0 || w <= 0 || groups <= 0) return SS_ERR_ARG;
+    StemP p;
+    p.in = in_padded; p.packed = packed; p.bias = bias; p.out = out;
+    p.n = n; p.h = h; p.w = w; p.groups = groups;
+    p.ho = (h - 1) / 2 + 1; p.wo = (w - 1) / 2 + 1;          // Conv2d(k 7, s 2, p 3)
+    p.hp = (p.ho - 1) / 2 + 1; p.wp = (p.wo - 1) / 2 + 1;    // MaxPool2d(k 3, s 2, p 1)
+    p.nty = (unsigned)ss_cdiv(p.hp, SP_PR);
+    p.ntx = (unsigned)ss_cdiv(p.wp, SP_PC);
+    p.divTx = ss_div32_make(p.ntx);
+    p.divTy = ss_div32_make(p.nty);
+    p.divG = ss_div32_make((unsigned)groups);
+    p.out_gs = out_gs;
+    const long long in_bytes = (long long)n * h * (w + 8) * 12;
+    const long long wgs = (long long)n * p.nty * p.ntx * groups;
+    if (in_bytes >= (1ll << 32) || wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
+    if (groups > 1 && out_gs < (long long)n * p.hp * p.wp * 64) return SS_ERR_ARG;
+    p.in_bytes = (unsigned)in_bytes;
+    p.pk_bytes = (unsigned)(ss_stem_pool_packed_floats(groups) * 4);
+#ifdef SS_TUNING
+    p.dbg = ss_tuning_dbg;
+    p.stagger = g_wino_knob[0];
+    const unsigned dyn = (unsigned)g_wino_lds_pad;          // ss_debug_set key 20: extra LDS -> one workgroup per CU (experiments)
+#else
+    const unsigned dyn = 0u;
+#endif
+    hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)wgs), dim3(256), dyn, (hipStream_t)stream, p);
+    return ss_launch_status();
+}

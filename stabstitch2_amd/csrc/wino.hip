@@ -496,10 +496,43 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             __builtin_amdgcn_sched_barrier(0);
             mma(1, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(2, 2, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(3, 3, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VAR == 3) {
+                // The first stage of the output transform INSIDE the stream.  A VALU instruction between a wave's own MFMAs costs ~2.3
+                // matrix-pipe clocks; the same instruction in the epilogue, beside the OTHER workgroup's dense MFMA stream, gets an
+                // issue slot once per MFMA (~51 clocks, tools/micro/mfma_neighbor: s_setprio does not change that).  Positions 0 and 1
+                // of the wave's row are final after block (1, 1): T0 = (m0 + m1) + m2 and T1 = (m1 - m2) - m3 are formed in place
+                // (same operation order as the epilogue used: bit-identical) while positions 2 and 3 still multiply.
+                auto tsum = [&](int d, int a, float sg) {      // acc[d] += sg * acc[a]
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[d][blk][r] = sg > 0.f ? acc[d][blk][r] + acc[a][blk][r] : acc[d][blk][r] - acc[a][blk][r];
+                };
+                tsum(0, 1, 1.f);                                // m0 + m1
+                mma(2, 2, 1);
+#pragma unroll
+                for (int i_ = 0; i_ < 8; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                tsum(0, 2, 1.f);                                // (m0 + m1) + m2 = T0
+                tsum(1, 2, -1.f);                               // m1 - m2
+                mma(3, 3, 1);
+#pragma unroll
+                for (int i_ = 0; i_ < 8; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                tsum(1, 3, -1.f);                               // (m1 - m2) - m3 = T1 (the one stage left outside the stream)
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                mma(2, 2, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(3, 3, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         W_SETPRIO_KNOB(1, 3);
 #undef W_SGB_BLOCK
@@ -625,9 +658,14 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float m0 = acc[0][blk][r], m1 = acc[1][blk][r], m2 = acc[2][blk][r], m3 = acc[3][blk][r];
-                srow[tile * BN + blk * 32] = (m0 + m1) + m2;
-                srow[(32 + tile) * BN + blk * 32] = (m1 - m2) - m3;
+                if constexpr (STREAM && VAR == 3) {             // T0 / T1 were formed inside the stream
+                    srow[tile * BN + blk * 32] = acc[0][blk][r];
+                    srow[(32 + tile) * BN + blk * 32] = acc[1][blk][r];
+                } else {
+                    const float m0 = acc[0][blk][r], m1 = acc[1][blk][r], m2 = acc[2][blk][r], m3 = acc[3][blk][r];
+                    srow[tile * BN + blk * 32] = (m0 + m1) + m2;
+                    srow[(32 + tile) * BN + blk * 32] = (m1 - m2) - m3;
+                }
             }
     }
     __syncthreads();
@@ -1290,6 +1328,16 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
 #undef W_ABL_CASE
             default: break;
         }
+    }
+    if (g_wino_variant == 5) {      // output transform stage 1 inside the stream (VAR = 3)
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true, false, 3>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true, false, 3>), g, dim3(256), dyn, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, true, false, 3>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true, false, 3>), g, dim3(256), dyn, st, p);
+        }
+        return ss_launch_status();
     }
     if (g_wino_variant == 4) {      // accumulator-alternation experiment (VAR = 2)
         if (tbh == 8) {

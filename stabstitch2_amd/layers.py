@@ -192,7 +192,9 @@ def run_stage1(x_nchw, p, chunk=None):
     whole = None
     for s in range(0, total, chunk):
         m = min(chunk, total - s)
-        if CONV1_CHUNK > 0 and m > CONV1_CHUNK and h % 2 == 0 and w % 2 == 0:
+        if ops.STEM_FUSED and p['conv1'][0].shape[0] == 64:
+            x = ops.stem_pool(buf[s:s + m], p['conv1'][0], p['conv1'][1])[0]      # conv + BN + ReLU + pool, one kernel
+        elif CONV1_CHUNK > 0 and m > CONV1_CHUNK and h % 2 == 0 and w % 2 == 0:
             x = torch.empty((m, (h // 2 + 1) // 2, (w // 2 + 1) // 2, 64), device=buf.device, dtype=torch.float32)
             for c0 in range(0, m, CONV1_CHUNK):
                 y = ops.conv_stem(buf[s + c0:s + min(c0 + CONV1_CHUNK, m)], p['conv1'][0], p['conv1'][1], relu=True)
@@ -317,9 +319,12 @@ def run_stage1_pair(xs, pp):
     every layer is one grouped launch; conv1 reads the shared input once per group (group stride 0)."""
     buf = ops.stem_input(xs)
     total = buf.shape[0]
-    y = ops.conv_stem(buf, pp['conv1'][0], pp['conv1'][1], relu=True)           # [2, total, H/2, W/2, 64]
-    y = ops.maxpool(y.view(2 * total, *y.shape[2:]), 3, 2, 1)
-    y = y.view(2, total, *y.shape[1:])
+    if ops.STEM_FUSED:
+        y = ops.stem_pool(buf, pp['conv1'][0], pp['conv1'][1])                   # [2, total, H/4, W/4, 64], one kernel
+    else:
+        y = ops.conv_stem(buf, pp['conv1'][0], pp['conv1'][1], relu=True)       # [2, total, H/2, W/2, 64]
+        y = ops.maxpool(y.view(2 * total, *y.shape[2:]), 3, 2, 1)
+        y = y.view(2, total, *y.shape[1:])
     for b in pp['layer1'] + pp['layer2']:
         t = ops.conv_grouped(y, b['c1'][0], b['c1'][1], None, stride=b['stride'], pad=(0, 1, 1), relu=True)
         idt = y if b['ds'] is None else ops.conv_grouped(y, b['ds'][0], b['ds'][1], None, stride=b['stride'], pad=(0, 0, 0))
@@ -340,6 +345,9 @@ def run_stem_shared(xs, stem):
     shared) and a pool that splits the channels; 16-image sub-chunks keep conv1's output MALL-resident."""
     buf = ops.stem_input(xs)
     total, h, w = buf.shape[0], buf.shape[1], buf.shape[2] - 8
+    if ops.STEM_FUSED and stem[0].shape[0] == 128:
+        y = ops.stem_pool(buf, stem[0], stem[1])             # [2,total,H/4,W/4,64]: both stems + pools in one kernel
+        return y[0], y[1]
     dev = buf.device
     ho, wo = ((h - 1) // 2 + 2) // 2, ((w - 1) // 2 + 2) // 2
     pa = torch.empty((total, ho, wo, 64), device=dev, dtype=torch.float32)

@@ -92,6 +92,41 @@ def conv_stem(buf, wgt, bias=None, relu=True):
     return out
 
 
+# The whole stem (conv 7x7/2 + folded BN + ReLU + max-pool 3/2/1) in one kernel (csrc/stem.hip); SS_STEM_FUSED=0 runs the
+# two-kernel path (ss_conv_stem3 + ss_maxpool_nhwc) for A/B measurements and the equivalence test.
+STEM_FUSED = os.environ.get('SS_STEM_FUSED', '1') == '1'
+
+
+def stem_pool_packed(wgt):
+    """Filters of ss_stem_pool in its register layout, built on first use from a `layers.pack_stem3` tensor ([64,7,24], or
+    [g*64,7,24] / [g,64,7,24] for g banks) and kept on it like the Winograd packs."""
+    g = wgt.numel() // (64 * 168)
+    assert wgt.numel() == g * 64 * 168, wgt.shape
+    ent = getattr(wgt, '_stem_packed', None)
+    tag = (wgt._version, wgt.data_ptr())
+    if ent is None or ent.tag != tag:
+        def build():
+            pk = torch.empty(int(H.lib().ss_stem_pool_packed_floats(g)), device=wgt.device, dtype=torch.float32)
+            H.call('ss_stem_pool_pack', H.dptr(wgt), H.dptr(pk), g, H.stream())
+            return pk
+        ent = _Built(build, wgt.device, 'the stem filter pack', tag)
+        wgt._stem_packed = ent
+    return ent.get(wgt.device), g
+
+
+def stem_pool(buf, wgt, bias=None):
+    """Conv2d(3,64,7,2,3) + folded BN + ReLU + MaxPool2d(3,2,1) on `stem_input` frames [n,h,w+8,3] in one kernel.
+    wgt [g*64,7,24] (+ bias [g*64]): g filter banks reading the same frames -> [g,n,hp,wp,64] (each bank contiguous)."""
+    n, h, wp8, _ = buf.shape
+    w = wp8 - 8
+    pk, g = stem_pool_packed(wgt)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    out = torch.empty((g, n, hp, wp, 64), device=buf.device, dtype=torch.float32)
+    H.call('ss_stem_pool', H.dptr(buf), H.dptr(pk), H.dptr(bias, True), H.dptr(out), n, h, w, g, out[0].numel(), H.stream())
+    return out
+
+
 # ------------------------------------------------------------------ conv / pool / fc
 def conv_workspace(device, floats):
     """Split-K scratch for ONE launch, sized by ss_conv_workspace_need and taken from torch's caching allocator on the

@@ -351,3 +351,48 @@ def test_packed_filter_cache_follows_the_weights(dev):
     again = ops.conv_winograd(x, w3)                        # default stream waits for the pack event
     torch.cuda.synchronize()
     assert torch.equal(first, again)
+
+
+# ------------------------------------------------------------------ fused stem (conv 7x7/2 + BN + ReLU + max-pool) in one kernel
+@pytest.mark.parametrize('n,h,w,g', [(2, 360, 480, 2), (3, 90, 130, 1), (1, 47, 61, 2), (2, 72, 96, 1)])
+def test_stem_pool_fused(dev, n, h, w, g):
+    """ss_stem_pool against F.conv2d + ReLU + F.max_pool2d (fp32 reference of the same op) and against the two-kernel path
+    (ss_conv_stem3 + ss_maxpool_nhwc): any image size (tiles at the right / bottom edge are partial, odd sizes), one or two
+    filter banks on the same frames, with and without bias."""
+    import torch.nn.functional as F
+    from stabstitch2_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(n, 3, h, w, device=dev)
+    wt = torch.randn(g * 64, 3, 7, 7, device=dev) * 0.1
+    bias = torch.randn(g * 64, device=dev)
+    packed = torch.zeros((g * 64, 7, 24), device=dev)
+    packed[:, :, :21] = wt.permute(0, 2, 3, 1).reshape(g * 64, 7, 21)           # layers.pack_stem3's layout
+    buf = ops.stem_input(x)
+    for b in (bias, None):
+        ref = F.max_pool2d(F.relu(F.conv2d(x, wt, b, stride=2, padding=3)), 3, 2, 1)            # [n, g*64, hp, wp]
+        got = ops.stem_pool(buf, packed, b)                                               # [g, n, hp, wp, 64]
+        assert got.shape == (g, n, ref.shape[2], ref.shape[3], 64)
+        want = ref.view(n, g, 64, ref.shape[2], ref.shape[3]).permute(1, 0, 3, 4, 2)
+        close(got, want, 2e-5 * float(want.abs().max()) + 1e-5, 'stem_pool vs torch %s' % ('bias' if b is not None else 'no bias'))
+        two = ops.maxpool(ops.conv_stem(buf, packed, b, relu=True), 3, 2, 1)                 # [n, hp, wp, g*64]
+        close(got, two.view(n, ref.shape[2], ref.shape[3], g, 64).permute(3, 0, 1, 2, 4), 2e-5 * float(want.abs().max()) + 1e-5,
+              'stem_pool vs conv_stem + maxpool')
+
+
+def test_stem_fused_in_the_pipeline(dev, hip_nets):
+    """The fused stem is what the networks run (ops.STEM_FUSED); switching it off gives the same motions to fp32 rounding."""
+    from stabstitch2_amd import ops, pipeline
+    _, lr = synth.make_clip_device(9, 360, 480, seed=7, device=dev)
+    assert ops.STEM_FUSED
+    a = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+    b1 = hip_nets[0](lr[0][:2], lr[1][:2])
+    try:
+        ops.STEM_FUSED = False
+        b = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+        b2 = hip_nets[0](lr[0][:2], lr[1][:2])
+    finally:
+        ops.STEM_FUSED = True
+    for k in ('smotion1', 'smotion2', 'tmotion1', 'tmotion2', 'smooth_mesh1', 'smooth_mesh2'):
+        close(a[k], b[k], 2e-4, 'fused vs two-kernel stem: ' + k)
+    for x, y in zip(b1, b2):
+        close(x, y, 1e-4, 'SpatialNet offsets, fused vs two-kernel stem')

@@ -13,7 +13,7 @@ for name, (n, h, w, cin, cout) in SHAPES.items():
     x = torch.randn(n, h, w, cin, device=dev); wt = torch.randn(cout, 1, 3, 3, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     out = ops.conv_winograd(x, wt, b, None, relu=True)
     res = torch.randn_like(out)
-    for var, pad, what in ((0, 0, 'two workgroups per CU'), (0, 40960, 'ONE workgroup per CU'), (4, 0, 'VAR2 two per CU'), (4, 40960, 'VAR2 ONE per CU')):
+    for var, pad, what in ((0, 0, 'two workgroups per CU'), (0, 40960, 'ONE workgroup per CU'), (5, 0, 'VAR3 two per CU'), (5, 40960, 'VAR3 ONE per CU')):
         lib.ss_debug_set(20, pad); lib.ss_debug_set(7, var)
         ref = None if var == 0 else keep
         for _ in range(3): ops.conv_winograd(x, wt, b, res, relu=True, out=out)

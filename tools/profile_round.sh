@@ -25,5 +25,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f_$TAG
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$TAG -- $PCMD > $OUT/${TAG}_pmc_w.log 2>&1
 python $R/tools/pmc_summary.py /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG $PSTEPS > $OUT/${TAG}_pmc_hbm.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_m_$TAG -- $PCMD > $OUT/${TAG}_pmc_m.log 2>&1
-python $R/tools/pmc_kernels.py /tmp/pmc_m_$TAG conv_wino conv_igemm render_average cost_volume maxpool homo_warp > $OUT/${TAG}_pmc_mfma.json
+python $R/tools/pmc_kernels.py /tmp/pmc_m_$TAG conv_wino conv_igemm stem_pool_kernel render_average cost_volume maxpool homo_warp > $OUT/${TAG}_pmc_mfma.json
 ls -la $OUT/${TAG}_*
