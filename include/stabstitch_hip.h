@@ -253,6 +253,19 @@ SS_API int ss_mesh_bbox(const float* mesh, int n_points, float img_h, float img_
 /* out = norm(scale(mesh) - (wmin,hmin); Hc_f, Wc_f) with the float canvas size read from bbox on device */
 SS_API int ss_mesh_normalize(const float* mesh, const float* bbox, float* out, int n_points, float img_h,
                       float img_w, void* stream);
+/* H2Mesh (spatial_network.py:20-36): out = persp_divide(H^-1 [x y 1]^T) over mesh [n][n_points][2]; H [n][3][3]; the 3 x 3
+ * inverse and the products in fp64 */
+SS_API int ss_h2mesh(const float* H, const float* mesh, float* out, int n, int n_points, void* stream);
+/* three-view mesh alignment (test_online_tra_threeview.py:345-420), meshes [frames][63][2] at LR scale:
+ *   ss_three_view_align   scale the four meshes to HR, add the per-frame mean offset of (w12_m2 - w23_m1) to pair (2,3),
+ *                         middle = (w12_m2 + w23_m1) / 2 -> a1, a2, b1, b2, mid in HR pixels (before the canvas translation)
+ *   ss_three_view_finish  bbox = first canvas (ss_mesh_bbox over a1, a2, b1, b2): mesh1 / mesh3 = the re-projected outer
+ *                         meshes n1 / n3 (normalised, from ss_tps_points) back in canvas pixels, middle = mid - (wmin, hmin) */
+SS_API int ss_three_view_align(const float* w12_m1, const float* w12_m2, const float* w23_m1, const float* w23_m2,
+                        float* a1, float* a2, float* b1, float* b2, float* mid, int frames, float img_h, float img_w,
+                        void* stream);
+SS_API int ss_three_view_finish(const float* n1, const float* n3, const float* mid, const float* bbox, float* mesh1,
+                         float* middle, float* mesh3, long long n_points, void* stream);
 /* the same for view `view` of `views` of a clip, mesh [frames][63][2], written into the render's source layout
  * out [frames][views][63][2] (one call per view assembles it; test_online_tra.py:129-136) */
 SS_API int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,

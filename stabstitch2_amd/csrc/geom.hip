@@ -643,3 +643,90 @@ extern "C" int ss_mesh_normalize(const float* mesh, const float* bbox, float* ou
                        bbox, out, n_points, img_h, img_w);
     return ss_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// H2Mesh (spatial_network.py:20-36): mesh = persp_divide(H^-1 [x y 1]^T) over the vertices of a mesh; 3 x 3 inverse and
+// the products in fp64 (the reference's fp32 torch.inverse is itself +-0.02 px from it), result fp32.
+__global__ void h2mesh_kernel(const float* __restrict__ H, const float* __restrict__ mesh, float* __restrict__ out, int npts) {
+    __shared__ double Hi[9];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        double h[9], inv[9];
+        for (int i = 0; i < 9; ++i) h[i] = (double)H[b * 9 + i];
+        inv3(h, inv);
+        for (int i = 0; i < 9; ++i) Hi[i] = inv[i];
+    }
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= npts) return;
+    const double x = (double)mesh[((long long)b * npts + v) * 2], y = (double)mesh[((long long)b * npts + v) * 2 + 1];
+    const double X = Hi[0] * x + Hi[1] * y + Hi[2], Y = Hi[3] * x + Hi[4] * y + Hi[5], Z = Hi[6] * x + Hi[7] * y + Hi[8];
+    out[((long long)b * npts + v) * 2] = (float)(X / Z);
+    out[((long long)b * npts + v) * 2 + 1] = (float)(Y / Z);
+}
+
+extern "C" int ss_h2mesh(const float* H, const float* mesh, float* out, int n, int n_points, void* stream) {
+    if (!H || !mesh || !out || n <= 0 || n_points <= 0 || n > 65535) return SS_ERR_ARG;
+    hipLaunchKernelGGL(h2mesh_kernel, dim3(ss_cdiv(n_points, 64), n), dim3(64), 0, (hipStream_t)stream, H, mesh, out, n_points);
+    return ss_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// three-view mesh alignment (test_online_tra_threeview.py:345-420).  Per frame (one 64-thread block, thread = vertex):
+//   scale the four LR meshes to HR (x * W / 480, y * H / 360); offset = mean over the 63 vertices of (w12_m2 - w23_m1);
+//   add it to both meshes of pair (2,3); middle = (w12_m2 + w23_m1) / 2.   -> a1, a2, b1, b2, mid [n][63][2] in HR pixels,
+//   not yet translated to the first canvas (ss_mesh_bbox / ss_mesh_normalize / ss_three_view_finish do that).
+__global__ void three_view_align_kernel(const float* __restrict__ m12_1, const float* __restrict__ m12_2,
+                                        const float* __restrict__ m23_1, const float* __restrict__ m23_2,
+                                        float* __restrict__ a1, float* __restrict__ a2, float* __restrict__ b1,
+                                        float* __restrict__ b2, float* __restrict__ mid, float img_h, float img_w) {
+    const long long f = blockIdx.x;
+    const int v = threadIdx.x;
+    const bool on = v < SS_NV;
+    const long long o = (f * SS_NV + (on ? v : 0)) * 2;
+    auto sx = [&](float x) { return __fmul_rn(x, img_w) / 480.0f; };
+    auto sy = [&](float y) { return __fmul_rn(y, img_h) / 360.0f; };
+    const float a1x = sx(m12_1[o]), a1y = sy(m12_1[o + 1]), a2x = sx(m12_2[o]), a2y = sy(m12_2[o + 1]);
+    float b1x = sx(m23_1[o]), b1y = sy(m23_1[o + 1]), b2x = sx(m23_2[o]), b2y = sy(m23_2[o + 1]);
+    const float ox = ss_wave_sum(on ? __fsub_rn(a2x, b1x) : 0.f) / (float)SS_NV;
+    const float oy = ss_wave_sum(on ? __fsub_rn(a2y, b1y) : 0.f) / (float)SS_NV;
+    if (!on) return;
+    b1x = __fadd_rn(b1x, ox); b1y = __fadd_rn(b1y, oy);
+    b2x = __fadd_rn(b2x, ox); b2y = __fadd_rn(b2y, oy);
+    a1[o] = a1x; a1[o + 1] = a1y; a2[o] = a2x; a2[o + 1] = a2y;
+    b1[o] = b1x; b1[o + 1] = b1y; b2[o] = b2x; b2[o + 1] = b2y;
+    mid[o] = __fadd_rn(a2x, b1x) / 2.0f;
+    mid[o + 1] = __fadd_rn(a2y, b1y) / 2.0f;
+}
+
+extern "C" int ss_three_view_align(const float* w12_m1, const float* w12_m2, const float* w23_m1, const float* w23_m2,
+                                   float* a1, float* a2, float* b1, float* b2, float* mid, int frames, float img_h,
+                                   float img_w, void* stream) {
+    if (!w12_m1 || !w12_m2 || !w23_m1 || !w23_m2 || !a1 || !a2 || !b1 || !b2 || !mid || frames <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(three_view_align_kernel, dim3(frames), dim3(64), 0, (hipStream_t)stream, w12_m1, w12_m2, w23_m1, w23_m2,
+                       a1, a2, b1, b2, mid, img_h, img_w);
+    return ss_launch_status();
+}
+
+// back from the first canvas' normalised coordinates: mesh = (n + 1) * extent / 2 for the re-projected outer meshes (n1, n3),
+// middle = mid - (wmin, hmin); bbox (device) = wmin, wmax, hmin, hmax of the first canvas (threeview:405-420)
+__global__ void three_view_finish_kernel(const float* __restrict__ n1, const float* __restrict__ n3,
+                                         const float* __restrict__ mid, const float* __restrict__ bbox,
+                                         float* __restrict__ mesh1, float* __restrict__ middle, float* __restrict__ mesh3,
+                                         long long npts) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const float wmin = bbox[0], hmin = bbox[2];
+    const float ow = __fsub_rn(bbox[1], wmin), oh = __fsub_rn(bbox[3], hmin);
+    mesh1[i * 2] = recover1(n1[i * 2], ow); mesh1[i * 2 + 1] = recover1(n1[i * 2 + 1], oh);
+    mesh3[i * 2] = recover1(n3[i * 2], ow); mesh3[i * 2 + 1] = recover1(n3[i * 2 + 1], oh);
+    middle[i * 2] = __fsub_rn(mid[i * 2], wmin); middle[i * 2 + 1] = __fsub_rn(mid[i * 2 + 1], hmin);
+}
+
+extern "C" int ss_three_view_finish(const float* n1, const float* n3, const float* mid, const float* bbox, float* mesh1,
+                                    float* middle, float* mesh3, long long n_points, void* stream) {
+    if (!n1 || !n3 || !mid || !bbox || !mesh1 || !middle || !mesh3 || n_points <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(three_view_finish_kernel, dim3(ss_cdiv(n_points, 256)), dim3(256), 0, (hipStream_t)stream, n1, n3, mid,
+                       bbox, mesh1, middle, mesh3, n_points);
+    return ss_launch_status();
+}

@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     for (int e = 0; e < NE; ++e) {
         const int item = tid + 256 * e;
         const int pix = item >> 2, q = item & 3;
+        if constexpr (VAR == 4) {        // experiment (timing only, wrong results): the prologue without its index arithmetic
+            rbase[e] = (unsigned)(tid * 16 + e * 4096); rinv[e] = 0u; rlds[e] = (tid & 3) * 4 * PLANE + (tid >> 2) + e * 64;
+            continue;
+        }
         const int ry = pix / RW, rx = pix - ry * RW;
         const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
         const bool ok = item < RPIX * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
@@ -1328,6 +1332,16 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
 #undef W_ABL_CASE
             default: break;
         }
+    }
+    if (g_wino_variant == 6) {      // prologue without index arithmetic (VAR = 4, timing only)
+        if (tbh == 8) {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, true, false, 4>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true, false, 4>), g, dim3(256), dyn, st, p);
+        } else {
+            if (res) hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, true, true, false, 4>), g, dim3(256), dyn, st, p);
+            else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true, false, 4>), g, dim3(256), dyn, st, p);
+        }
+        return ss_launch_status();
     }
     if (g_wino_variant == 5) {      // output transform stage 1 inside the stream (VAR = 3)
         if (tbh == 8) {

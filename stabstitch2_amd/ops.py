@@ -625,6 +625,35 @@ def mesh_normalize_views(meshes, bbox, img_h, img_w):
     return out
 
 
+def h2mesh(Hm, mesh):
+    """H [n,3,3], mesh [n,...,2] -> persp_divide(H^-1 [x y 1]^T), same shape as mesh (spatial_network.py:20-36)."""
+    n = Hm.shape[0]
+    m = _f(mesh)
+    out = torch.empty_like(m)
+    H.call('ss_h2mesh', H.dptr(_f(Hm)), H.dptr(m), H.dptr(out), n, m.numel() // (2 * n), H.stream())
+    return out
+
+
+def three_view_align(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w):
+    """Four LR meshes [1,N,7,9,2] -> (a1, a2, b1, b2, mid) [1,N,7,9,2] in HR pixels: pair (2,3) shifted by the per-frame mean
+    offset, middle plane (threeview:345-380)."""
+    n = w12_m1.numel() // 126
+    outs = [torch.empty((1, n, 7, 9, 2), device=w12_m1.device, dtype=torch.float32) for _ in range(5)]
+    H.call('ss_three_view_align', H.dptr(_f(w12_m1)), H.dptr(_f(w12_m2)), H.dptr(_f(w23_m1)), H.dptr(_f(w23_m2)),
+           *[H.dptr(o) for o in outs], n, float(img_h), float(img_w), H.stream())
+    return outs
+
+
+def three_view_finish(n1, n3, mid, bbox):
+    """Re-projected outer meshes n1 / n3 [N,63,2] (normalised on the first canvas `bbox`) and the untranslated middle mesh
+    -> (mesh1, middle, mesh3) [1,N,7,9,2] in first-canvas pixels."""
+    n = mid.numel() // 126
+    outs = [torch.empty((1, n, 7, 9, 2), device=mid.device, dtype=torch.float32) for _ in range(3)]
+    H.call('ss_three_view_finish', H.dptr(_f(n1)), H.dptr(_f(n3)), H.dptr(_f(mid)), H.dptr(bbox), *[H.dptr(o) for o in outs],
+           n * 63, H.stream())
+    return outs
+
+
 def fill(t, value=0.0):
     """t[...] = value in place (t contiguous fp32)."""
     H.call('ss_fill_f32', H.dptr(t), float(value), t.numel(), H.stream())

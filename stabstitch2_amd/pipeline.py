@@ -13,8 +13,8 @@ stitched frame.  The only host round trip is the data-dependent canvas size (tes
 Everything tensor-sized (frames, feature maps, cost volumes, canvases) is computed by the HIP kernels, and in the 2-view
 path so is the mesh-sized bookkeeping (the clip's meshes and the metric harness's stitched paths straight from the sliding
 windows: `ops.smooth_stitch`; the render's control points: `ops.mesh_normalize_views`): a steady-state 2-view clip issues
-no torch (aten) kernel at all (tools/trace_torch_ops.py).  What stays as torch expressions is the three-view mesh alignment
-(`three_view_compose`: scale, mean offset, middle mesh, bbox, normalise on [1,N,7,9,2] tensors) -- device ops, no host sync.
+no torch (aten) kernel at all (tools/trace_torch_ops.py); the three-view mesh alignment (`three_view_compose`: scale, mean
+offset, middle mesh, first canvas, TPS re-projection) runs on `ss_three_view_align / _finish` + the mesh kernels as well.
 
 Long videos: `run_two_view_long` keeps the reference's ONE global canvas (test_online_tra.py:106-120) in bounded device
 memory -- pass 1 estimates the meshes chunk by chunk from the LR frames only, pass 2 renders chunk by chunk onto the
@@ -425,40 +425,19 @@ def run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode='NORMAL', fusion_mode='AVER
 
 
 # ------------------------------------------------------------------ three-view (threeview:345-505)
-def _scale(m, img_h, img_w):
-    return torch.stack([m[..., 0] * img_w / 480, m[..., 1] * img_h / 360], 4)
-
-
 @torch.no_grad()
 def three_view_compose(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w):
-    """Mesh alignment, middle plane and TPS re-projection of the outer views.  Inputs [1,N,7,9,2] (LR scale)
-    -> (mesh1, middle, mesh3) in first-canvas HR pixels.  Mesh-sized glue (scale, mean offset, middle mesh, bbox,
-    normalise: [1,N,7,9,2] tensors) stays in torch on the device; the TPS solves and point evaluations run on the HIP
-    kernels."""
-    a1, a2 = _scale(w12_m1, img_h, img_w), _scale(w12_m2, img_h, img_w)
-    b1, b2 = _scale(w23_m1, img_h, img_w), _scale(w23_m2, img_h, img_w)
-    off = (a2 - b1).reshape(a2.shape[0], a2.shape[1], -1, 2).mean(2).unsqueeze(2).unsqueeze(2)
-    b1, b2 = b1 + off, b2 + off
-    mid = (a2 + b1) / 2.
-    wmin = torch.stack([m[..., 0].min() for m in (a1, a2, b1, b2)]).min()
-    wmax = torch.stack([m[..., 0].max() for m in (a1, a2, b1, b2)]).max()
-    hmin = torch.stack([m[..., 1].min() for m in (a1, a2, b1, b2)]).min()
-    hmax = torch.stack([m[..., 1].max() for m in (a1, a2, b1, b2)]).max()
-    ow, oh = wmax - wmin, hmax - hmin
-
-    def shift(m):
-        return torch.stack([m[..., 0] - wmin, m[..., 1] - hmin], 4)
-
-    def nrm(m):      # [1,N,7,9,2] -> [N,63,2]
-        return torch.stack([m[0, ..., 0] * 2. / ow - 1., m[0, ..., 1] * 2. / oh - 1.], 3).reshape(m.shape[1], -1, 2)
-
-    def rec(nm):
-        return torch.stack([(nm[..., 0] + 1) * ow / 2., (nm[..., 1] + 1) * oh / 2.], 2).reshape(1, -1, 7, 9, 2)
-    a1, a2, b1, b2, mid = map(shift, (a1, a2, b1, b2, mid))
-    nmid = nrm(mid).contiguous()
-    n1 = ops.tps_points(nrm(a1).contiguous(), nrm(a2).contiguous(), ops.tps_solve(nrm(a2).contiguous(), nmid))
-    n3 = ops.tps_points(nrm(b2).contiguous(), nrm(b1).contiguous(), ops.tps_solve(nrm(b1).contiguous(), nmid))
-    return rec(n1), mid, rec(n3)
+    """Mesh alignment, middle plane and TPS re-projection of the outer views (test_online_tra_threeview.py:345-420).
+    Inputs [1,N,7,9,2] (LR scale) -> (mesh1, middle, mesh3) in first-canvas HR pixels.  All of it on the HIP kernels:
+    `ss_three_view_align` (scale, per-frame mean offset, middle mesh), `ss_mesh_bbox` / `ss_mesh_normalize` (first canvas),
+    `ss_tps_solve` / `ss_tps_points` (re-projection), `ss_three_view_finish` (back to canvas pixels); no host sync."""
+    a1, a2, b1, b2, mid = ops.three_view_align(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w)
+    bbox = ops.mesh_bbox([a1, a2, b1, b2], 0.0, 0.0)             # first canvas (meshes are HR pixels already)
+    nrm = lambda m: ops.mesh_normalize(m, bbox, 0.0, 0.0)          # [N,63,2]
+    nmid, na2, nb1 = nrm(mid), nrm(a2), nrm(b1)
+    n1 = ops.tps_points(nrm(a1), na2, ops.tps_solve(na2, nmid))
+    n3 = ops.tps_points(nrm(b2), nb1, ops.tps_solve(nb1, nmid))
+    return tuple(ops.three_view_finish(n1, n3, mid, bbox))
 
 
 @torch.no_grad()

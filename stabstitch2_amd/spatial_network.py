@@ -28,14 +28,9 @@ def get_norm_mesh(mesh, height, width):
 
 
 def H2Mesh(H, rigid_mesh):
-    """spatial_network.py:20-36 -- mesh = persp_divide(H^-1 [x y 1]^T); 3x3 inverse in fp64 on device via the
-    DLT identity is not needed here: torch.inverse is plumbing-sized (B x 3 x 3)."""
+    """spatial_network.py:20-36 -- mesh = persp_divide(H^-1 [x y 1]^T) (`ss_h2mesh`: the 3 x 3 inverse in fp64 on the device)."""
     b = rigid_mesh.shape[0]
-    pts = rigid_mesh.reshape(b, -1, 2)
-    hom = torch.cat((pts, torch.ones(b, pts.shape[1], 1, device=pts.device)), 2)
-    t = torch.matmul(torch.inverse(H.double()), hom.double().permute(0, 2, 1))
-    mesh = torch.stack((t[:, 0] / t[:, 2], t[:, 1] / t[:, 2]), 2).float()
-    return mesh.reshape(b, grid_h + 1, grid_w + 1, 2)
+    return ops.h2mesh(H, rigid_mesh).reshape(b, grid_h + 1, grid_w + 1, 2)
 
 
 class SpatialNet(L.PreparedMixin, nn.Module):

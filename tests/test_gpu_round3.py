@@ -396,3 +396,39 @@ def test_stem_fused_in_the_pipeline(dev, hip_nets):
         close(a[k], b[k], 2e-4, 'fused vs two-kernel stem: ' + k)
     for x, y in zip(b1, b2):
         close(x, y, 1e-4, 'SpatialNet offsets, fused vs two-kernel stem')
+
+
+# ------------------------------------------------------------------ H2Mesh / three-view glue on the device
+def test_h2mesh_vs_reference(dev, golden):
+    """`spatial_network.H2Mesh` (ss_h2mesh: 3x3 inverse + products in fp64) on the REFERENCE's homographies (G1) against the
+    reference's meshes (its fp32 inverse: +-0.02 px) and against an fp64 evaluation."""
+    from stabstitch2_amd.spatial_network import H2Mesh
+    from oracle import geometry as G
+    g = golden('g1_dlt')
+    rigid = torch.from_numpy(g['rigid']).to(dev)
+    for hk, mk in (('H_ref_full', 'mesh_ref'), ('H_tgt_full', 'mesh_tgt')):
+        Hm = torch.from_numpy(g[hk]).to(dev)
+        got = H2Mesh(Hm, rigid)
+        assert got.shape == (16, 7, 9, 2)
+        close(got, g[mk], 5e-2, 'H2Mesh vs reference ' + mk)
+        close(got, G.homography_to_mesh(torch.from_numpy(g[hk]).double(), torch.from_numpy(g['rigid']).double()).float(), 2e-4,
+              'H2Mesh vs fp64 ' + mk)
+
+
+def test_three_view_compose_on_device_kernels(dev, golden):
+    """three_view_compose runs on ss_three_view_align / ss_mesh_bbox / ss_mesh_normalize / ss_tps_* / ss_three_view_finish (no
+    torch arithmetic): against the reference's composition (G10) and the torch formulation it replaced."""
+    from stabstitch2_amd import pipeline, ops
+    g = golden('g10_threeview')
+    meshes = [m.to(dev) for m in cases.g10_meshes()]
+    mesh1, mid, mesh3 = pipeline.three_view_compose(*meshes, 180, 320)
+    close(mesh1, g['mesh1'], 5e-3, 'mesh1 vs reference')
+    close(mid, g['middle'], 1e-3, 'middle vs reference')
+    close(mesh3, g['mesh3'], 5e-3, 'mesh3 vs reference')
+    # the alignment stage against plain torch expressions (threeview:345-380)
+    sc = lambda m: torch.stack([m[..., 0] * 320 / 480, m[..., 1] * 180 / 360], 4)
+    a1, a2, b1, b2 = map(sc, meshes)
+    off = (a2 - b1).reshape(1, a2.shape[1], -1, 2).mean(2).unsqueeze(2).unsqueeze(2)
+    got = ops.three_view_align(*meshes, 180, 320)
+    for x, y, what in zip(got, (a1, a2, b1 + off, b2 + off, (a2 + b1 + off) / 2), ('a1', 'a2', 'b1', 'b2', 'mid')):
+        close(x, y, 1e-4, 'align ' + what)
