@@ -1230,8 +1230,10 @@ extern "C" int ss_conv_uses_winograd(int kt, int kh, int kw, int stride, int cin
     wino_blocks(ho, wo, tbh, tbw, eff);
     const long long wgs = (long long)images * ss_cdiv((ho + 1) / 2, tbh) * ss_cdiv((wo + 1) / 2, tbw) * (cout / 64);
     // >= 96 workgroups: below that the launch is one workgroup deep and its K loop (~2.3 us per chunk) is slower than the
-    // split-K implicit GEMM spread over the whole chip (tools/wino_threshold.py: 256->256 at 23x30 x2: 41 vs 30 us)
-    return eff >= 0.70 && wgs >= 96;
+    // split-K implicit GEMM spread over the whole chip (tools/wino_threshold.py: 256->256 at 23x30 x2: 41 vs 30 us).
+    // Maps that fill only 60-70 % of their tile slots (the regressors' 11x15: 64 %) still win once the launch is two workgroups
+    // deep (tools/wino_small_maps.py, 62 images 128->128: 33 vs 44 us; at 32 images equal; 5x7 maps, 27 %, lose)
+    return eff >= 0.70 ? wgs >= 96 : (eff >= 0.60 && wgs >= 192);
 }
 
 static int wino_launch(const float* in, const float* packed, const float* bias, const float* res, float* out,

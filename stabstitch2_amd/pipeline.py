@@ -110,6 +110,8 @@ def temporal_stage_views(temporal_net, lrs):
 
 
 SHARED_STEM = os.environ.get('SS_SHARED_STEM', '1') == '1'
+# SpatialNet and TemporalNet behind the shared stem on two HIP streams (measured); off by default
+JOINT_OVERLAP = os.environ.get('SS_JOINT_OVERLAP', '0') == '1'
 
 
 class JointEstimator:
@@ -153,12 +155,33 @@ class JointEstimator:
         if e > self.n:
             raise ValueError('more frames pushed (%d) than announced (%d)' % (e, self.n))
         xa, xb = L.run_stem_shared([lr1, lr2], sp['stem_pair'])
+        if JOINT_OVERLAP:
+            # SpatialNet (main stream) and TemporalNet (side stream) are independent behind the shared stem: two chains of
+            # launches whose partially filled last rounds top each other up
+            main = torch.cuda.current_stream(xb.device)
+            side = _side_stream(xb.device)
+            side.wait_stream(main)
+            xb.record_stream(side)
+            with torch.cuda.stream(side):
+                self._temporal(xb, b, s, e)
+            self._spatial(xa, b, s, e)
+            main.wait_stream(side)
+        else:
+            self._spatial(xa, b, s, e)
+            self._temporal(xb, b, s, e)
+        self.pos = e
+
+    def _spatial(self, xa, b, s, e):
+        L, sp = self.L, self.sp
         f64 = L.run_trunk_body(xa, sp['s1'])
         f32 = L.run_stage2(f64, sp['s2'])
         off1, off_ref, off_tgt = self.spatial_net.forward_pair(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
         if self.cache2 is not None:
             self.cache2.append((f64[b:], f32[b:]))
         ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W, out=(self.m1[s:e], self.m2[s:e]))
+
+    def _temporal(self, xb, b, s, e):
+        L, tp = self.L, self.tp
         nv = len(self.views)
         f = L.run_trunk_body(xb if self.tmotion1 is None else xb[b:], tp['s1'])      # [nv*b,45,60,128], view-major
         lead = 0 if s == 0 else 1                       # the pair (last frame of the previous chunk, first of this one)
@@ -175,7 +198,6 @@ class JointEstimator:
                 slices.append((i * rows, (i + 1) * rows, self.tm[i, e - rows:e].view(rows, -1)))
             L.run_regressor(cv, tp['r2'], out_slices=slices)
         self.carry = [f[i * b + b - 1:(i + 1) * b] for i in range(nv)]
-        self.pos = e
 
     def result(self):
         """-> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""
