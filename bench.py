@@ -278,6 +278,17 @@ def cpu_thread_sweep(sds, height, width, candidates):
     return min(full, key=full.get), res
 
 
+def path_traffic(pmc, algorithmic_bytes_per_step):
+    """Static: HBM bytes per clip summed over every kernel the PMC passes list (conv engine, render, cost volume, pools, FC,
+    homography sampler) against the compulsory bytes of SURVEY.md 8d (frames in, canvas out, weights once)."""
+    if not pmc or not pmc.get('kernels'):
+        return None
+    steps = max(pmc.get('steps_profiled', 0), 1)
+    tot = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in pmc['kernels'].values()) / steps
+    return {'hbm_bytes_per_step_static': round(tot), 'algorithmic_bytes_per_step': round(algorithmic_bytes_per_step),
+            'ratio': round(tot / algorithmic_bytes_per_step, 2), 'source': 'static: ' + PMC_PROFILE}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -456,6 +467,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args, argv))
 
+    claim_stdout()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -655,6 +667,8 @@ def main():
                      # the HBM-side kernels (K7 / K8 / max-pool / K12-K13), HIP-event time in this run x STATIC
                      # HBM bytes of the committed PMC passes / 8 TB/s
                      'secondary': probe.secondary_report(pmc),
+                     # all profiled kernels together: HBM bytes per clip from the committed PMC passes against the compulsory bytes
+                     'path_hbm_traffic': path_traffic(pmc, io_bytes * args.frames),
                      'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5),
                      # whole path against the MFMA roof: 41.31 GFLOP of dense contraction per 2-view frame
                      'path_mfma_frac': round(fps / world * 41.31e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if args.views == 2 else None},
@@ -710,16 +724,28 @@ def main():
         dist.destroy_process_group()
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """From here on file descriptor 1 of this rank IS stderr, and the original stdout is kept aside for the one JSON line:
+    whatever native libraries print through C stdio (RCCL writes a version banner when its communicator is created -- on every
+    rank, flushed at exit) can no longer land in front of, behind or instead of the line the driver parses."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(result):
-    """The ONE JSON line, after everything native libraries may still hold in their stdio buffers (RCCL prints a banner
-    through C stdio when its communicator is created; on a pipe that buffer would otherwise be flushed at exit, BEHIND the line)."""
-    import ctypes
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.write(json.dumps(result) + '\n')
-    sys.stdout.flush()
+    """The ONE JSON line of the run, on the real stdout (rank 0 only calls this)."""
+    line = (json.dumps(result) + '\n').encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
 
 
 if __name__ == '__main__':
