@@ -12,7 +12,8 @@
 //   conv region = 19 x 25 pixels (rows 2 py0 - 1 .. 2 py0 + 17, columns 2 px0 - 1 .. 2 px0 + 23) = 475 GEMM rows, padded to
 //   16 row tiles of 32 (the map 90 x 120 is 10 x 10 tiles exactly; 512 computed rows per 432 conv pixels a non-overlapping
 //   tiling would need: 1.185x the MFMA work, the price of never writing the un-pooled map);
-//   K = 7 filter rows x 24 (21 = 7 taps x 3 channels, + 3 zero weights) = 168 = 21 groups of 8, on the row-packed 3-channel
+//   K = 7 filter rows x 22 (21 = 7 taps x 3 channels + 1 zero weight) = 154 in 21 groups (8 + 8 + 6 k per row: 77 MFMA steps per
+//   tile instead of the 84 of a 24-padded row), on the row-packed 3-channel
 //   frames of ss_nchw_to_nhwc3_padded (a filter row is 24 contiguous floats of an image row);
 //   wave w owns row tiles 4 w .. 4 w + 3 x both 32-channel halves: 8 accumulator tiles of v_mfma_f32_32x32x2_f32 = 128 registers.
 //   * the 43 x 168-float input patch is staged once into LDS (coalesced 16-byte buffer loads; rows outside the image and the
@@ -135,13 +136,15 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
     }
 
     // this lane's GEMM rows: row tile mt of the wave -> conv pixel (r, c) of the region -> first float of its window in the patch
-    int abase[4];
+    // (two bases: the 8-k groups read 4 floats at + 4 h, the 6-k group of a filter row 3 floats at 16 + 3 h)
+    int abase[4], abase3[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         int m = 32 * (4 * wave + mt) + ln;
         m = m < SP_M ? m : SP_M - 1;                        // rows 475 .. 511: idle copies of the last pixel
         const int r = m / SP_CC, c = m - r * SP_CC;
         abase[mt] = (2 * r) * SP_PITCH + 6 * c + 4 * h2;
+        abase3[mt] = (2 * r) * SP_PITCH + 6 * c + 16 + 3 * h2;
     }
     const unsigned pk_lane = (unsigned)lane * 16u;
     const unsigned pk_grp = grp * (2u * SP_NG * 1024u);
@@ -156,13 +159,21 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
     // ---- K loop: 21 groups of 8 k; group g = filter row g / 3, floats 8 (g % 3) .. + 7 of its 24
     sp_f32x4 a_cur[4], b_cur[2], a_nxt[4], b_nxt[2];
     auto load = [&](int g, sp_f32x4 (&a)[4], sp_f32x4 (&b)[2]) {
-        const int koff = (g / 3) * SP_PITCH + (g % 3) * 8;
+        if (g % 3 == 2) {           // the 21 real floats of a filter row end with a group of SIX k: three MFMA steps (k = 16 + 3 h + s)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const float* ap = smem + abase[mt] + koff;
-            const sp_f32x2 lo = *reinterpret_cast<const sp_f32x2*>(ap);
-            const sp_f32x2 hi = *reinterpret_cast<const sp_f32x2*>(ap + 2);
-            a[mt] = (sp_f32x4){lo[0], lo[1], hi[0], hi[1]};
+            for (int mt = 0; mt < 4; ++mt) {
+                const float* ap = smem + abase3[mt] + (g / 3) * SP_PITCH;
+                a[mt] = (sp_f32x4){ap[0], ap[1], ap[2], 0.f};
+            }
+        } else {
+            const int koff = (g / 3) * SP_PITCH + (g % 3) * 8;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float* ap = smem + abase[mt] + koff;
+                const sp_f32x2 lo = *reinterpret_cast<const sp_f32x2*>(ap);
+                const sp_f32x2 hi = *reinterpret_cast<const sp_f32x2*>(ap + 2);
+                a[mt] = (sp_f32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
         if (g + 1 < SP_NG) load(g + 1, a_nxt, b_nxt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < (g % 3 == 2 ? 3 : 4); ++s)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -278,7 +289,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
 }
 
 // filters [groups][64][7][24] (layers.pack_stem3: w[co][dh][3 dw + c], entries 21..23 of a row zero, BN folded) ->
-// packed [groups][2][21][64 lanes][4]: lane (n = lane & 31, h = lane >> 5), float s = w[32 nt + n][k = 8 g + 4 h + s]
+// packed [groups][2][21][64 lanes][4]: lane (n = lane & 31, h = lane >> 5), float s = w[32 nt + n][k]: filter row g / 3, within
+// it k = 8 (g % 3) + 4 h + s for the two 8-k groups and 16 + 3 h + s (s < 3) for the 6-k group
 __global__ void stem_pool_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int groups) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;           // (grp, nt, g, lane)
     const int total = groups * 2 * SP_NG * 64;
@@ -289,8 +301,12 @@ __global__ void stem_pool_pack_kernel(const float* __restrict__ w, float* __rest
     r /= SP_NG;
     const int nt = r & 1, grp = r >> 1;
     const int co = 32 * nt + (lane & 31);
-    const float* src = w + ((long long)grp * 64 + co) * 168 + 8 * g + 4 * (lane >> 5);
-    reinterpret_cast<float4*>(packed)[idx] = make_float4(src[0], src[1], src[2], src[3]);
+    const int hh = lane >> 5;
+    const float* row = w + ((long long)grp * 64 + co) * 168 + 24 * (g / 3);
+    float4 v;
+    if (g % 3 == 2) v = make_float4(row[16 + 3 * hh], row[17 + 3 * hh], row[18 + 3 * hh], 0.f);      // k = 16 + 3 h + s, three steps
+    else { const float* src = row + 8 * (g % 3) + 4 * hh; v = make_float4(src[0], src[1], src[2], src[3]); }
+    reinterpret_cast<float4*>(packed)[idx] = v;
 }
 
 extern "C" long long ss_stem_pool_packed_floats(int groups) { return groups > 0 ? (long long)groups * 2 * SP_NG * 64 * 4 : 0; }

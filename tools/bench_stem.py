@@ -26,4 +26,4 @@ flop = 2.0 * n * 180 * 240 * 128 * 147
 for rnd in range(3):
     a = t(lambda: ops.stem_pool(buf, w, b)); c = t(two)
     print('fused %.1f us (%.1f TF/s on the conv\'s 147-tap flop; %.1f executed incl. halo + K padding)   conv_stem + maxpool_split (16-image sub-chunks, incl. layout kernel) %.1f us'
-          % (a, flop / a / 1e6, flop / a / 1e6 * 512 / 432 * 168 / 147, c))
+          % (a, flop / a / 1e6, flop / a / 1e6 * 512 / 432 * 154 / 147, c))
