@@ -22,4 +22,5 @@ out = {'command': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYC
 out['valu_issue_busy_estimate'] = round((waves / 1024.0) * (vpw * 4 + 126 * 12) / cyc, 3)
 out['estimate_formula'] = ('(waves/SIMD x (VALU instr/wave x 4 cycles + 126 v_log_f32 x 12 extra cycles)) / kernel cycles; '
                            'upper estimate: waves of tiles that no view reaches issue no v_log_f32')
+out['valu_active_frac'] = round(mean['SQ_ACTIVE_INST_VALU'] * 4 / 1024.0 / cyc, 3)      # SQ_ACTIVE_INST_* count quad-cycles, summed over the chip
 print(json.dumps(out, indent=1))
