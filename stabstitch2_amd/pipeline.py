@@ -7,8 +7,8 @@ test_online_tra_threeview.py:95-519 (file / video I/O excluded), with the refere
 The reference walks the clip frame by frame with batch 1.  Here every stage is one batched pass
 over the whole clip (the clip is resident in HBM): SpatialNet over all frame pairs, TemporalNet
 over all frames of a view, one batched tsmotion composition per view, all sliding SmoothNet windows
-as one batch, one batched TPS solve for every (frame, view), then one fused warp+blend launch per
-stitched frame.  The only host round trip is the data-dependent canvas size (test_online_tra.py:122-123).
+as one batch, one batched TPS solve for every (frame, view), then one fused warp+blend launch for the
+whole clip.  The only host round trip is the data-dependent canvas size (test_online_tra.py:122-123).
 
 Everything tensor-sized (frames, feature maps, cost volumes, canvases) is computed by the HIP kernels, and in the 2-view
 path so is the mesh-sized bookkeeping (the clip's meshes and the metric harness's stitched paths straight from the sliding
