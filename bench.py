@@ -155,7 +155,7 @@ class ConvProbe:
                 return out
             return timed
         for fn, kern in (('render_average_clip', 'render_average_kernel'), ('render_average', 'render_average_kernel'),
-                         ('cost_volume', 'cost_volume_kernel'), ('maxpool', 'maxpool_kernel'), ('maxpool_split', 'maxpool_kernel'),
+                         ('cost_volume', 'cost_volume_kernel'), ('cost_volume_bidir', 'cost_volume_kernel'), ('maxpool', 'maxpool_kernel'), ('maxpool_split', 'maxpool_kernel'),
                          ('homo_warp_nhwc', 'homo_warp_kernel')):
             setattr(ops, fn, wrap_plain(kern, getattr(ops, fn)))
 

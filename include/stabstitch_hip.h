@@ -144,6 +144,10 @@ SS_API int ss_l2norm_nhwc(const float* in, float* out, long long n_pixels, int c
  * written as 0.  out[.,y,x,d] = leaky_relu_0.1(mean_c x1[y,x,c] * x2[y+j-r, x+i-r, c]). */
 SS_API int ss_cost_volume(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
                    int out_cs, void* stream);
+/* both directions of SpatialNet's stage 2 (spatial_network.py:318, 325) in ONE launch: out [2][n][h][w][out_cs] =
+ * cost_volume(x1, x2), cost_volume(x2, x1) */
+SS_API int ss_cost_volume_bidir(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
+                         int out_cs, void* stream);
 
 /* ---- K6: 4-point DLT, bidirectional decomposition, H -> mesh (fp64 on device) -----------------
  * ss_tensor_dlt: utils/torch_DLT.py:17-45; src, dst [n][4][2] -> H [n][3][3]. */

@@ -18,7 +18,7 @@ extern "C" int ss_conv_nhwc(const float*, const float*, const float*, const floa
 template <int R>
 __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volume_kernel(
     const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ out, int h, int w, int c,
-    int out_cs) {
+    int out_cs, int n_fwd) {
     constexpr int KD = 2 * R + 1;
     constexpr int D = KD * KD;
     constexpr int NT = 64 * ((16 * KD + 63) / 64);      // threads per block (176 -> 192, 112 -> 128)
@@ -33,7 +33,15 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
     __shared__ __attribute__((aligned(16))) float s1[CV_CC][CV_TY * CV_TX];
 
     const int tid = threadIdx.x;
-    const int n = blockIdx.z;
+    // blockIdx.z < n_fwd: cv(x1, x2) of image z; >= n_fwd: the OTHER direction cv(x2, x1) of image z - n_fwd, written behind the
+    // n_fwd forward volumes (both directions of SpatialNet's stage 2, spatial_network.py:318,325, in one launch: 2 x 1536 workgroups
+    // are exactly three rounds of the chip where two launches of 1.5 rounds each cost four)
+    int n = blockIdx.z;
+    if (n >= n_fwd) {
+        const float* t = x1; x1 = x2; x2 = t;
+        out += (long long)n_fwd * h * w * out_cs;
+        n -= n_fwd;
+    }
     const int y0 = blockIdx.y * CV_TY, x0 = blockIdx.x * CV_TX;
     const bool active = tid < 16 * KD;
     const int pg = tid & 15, j = active ? tid >> 4 : 0;   // pixel group (py, 4g) and displacement row
@@ -159,8 +167,22 @@ extern "C" int ss_cost_volume(const float* x1, const float* x2, float* out, int 
     if (out_cs < D) return SS_ERR_ARG;
     dim3 g(ss_cdiv(w, CV_TX), ss_cdiv(h, CV_TY), n);
     hipStream_t st = (hipStream_t)stream;
-    if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs);
-    else if (r == 3) hipLaunchKernelGGL((cost_volume_kernel<3>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs);
+    if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n);
+    else if (r == 3) hipLaunchKernelGGL((cost_volume_kernel<3>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n);
+    else return SS_ERR_UNSUPPORTED;
+    return ss_launch_status();
+}
+
+// both directions in ONE launch: out [2][n][h][w][out_cs] = cv(x1, x2), cv(x2, x1)
+extern "C" int ss_cost_volume_bidir(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
+                                    int out_cs, void* stream) {
+    if (!x1 || !x2 || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || 2 * n > 65535) return SS_ERR_ARG;
+    int D = (2 * r + 1) * (2 * r + 1);
+    if (out_cs < D) return SS_ERR_ARG;
+    dim3 g(ss_cdiv(w, CV_TX), ss_cdiv(h, CV_TY), 2 * n);
+    hipStream_t st = (hipStream_t)stream;
+    if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n);
+    else if (r == 3) hipLaunchKernelGGL((cost_volume_kernel<3>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n);
     else return SS_ERR_UNSUPPORTED;
     return ss_launch_status();
 }

@@ -330,6 +330,17 @@ def cost_volume(x1, x2, r, out=None):
     return out
 
 
+def cost_volume_bidir(x1, x2, r, out=None):
+    """Both directions in one launch: nhwc in -> [2,n,h,w,pad4((2r+1)^2)] = (cost_volume(x1, x2), cost_volume(x2, x1))."""
+    n, h, w, c = x1.shape
+    cs = (((2 * r + 1) ** 2 + 3) // 4) * 4
+    if out is None:
+        out = torch.empty((2, n, h, w, cs), device=x1.device, dtype=torch.float32)
+    assert tuple(out.shape) == (2, n, h, w, cs) and tuple(x2.shape) == tuple(x1.shape)
+    H.call('ss_cost_volume_bidir', H.dptr(x1), H.dptr(x2), H.dptr(out), n, h, w, c, r, cs, H.stream())
+    return out
+
+
 # ------------------------------------------------------------------ geometry
 def tensor_dlt(src, dst):
     n = src.shape[0]

@@ -100,9 +100,7 @@ class SpatialNet(L.PreparedMixin, nn.Module):
         w1 = ops.homo_warp_nhwc(f64_1, th_ref, fh, fw)
         w2 = ops.homo_warp_nhwc(f64_2, th_tgt, fh, fw)
         # stage 2: local cost volumes in both directions -> residual mesh motions
-        cv = torch.empty((2, b, fh, fw, 124), device=w1.device, dtype=torch.float32)
-        ops.cost_volume(w1, w2, 5, out=cv[0])
-        ops.cost_volume(w2, w1, 5, out=cv[1])
+        cv = ops.cost_volume_bidir(w1, w2, 5)                      # [2,b,fh,fw,124]: both directions, one launch
         offset_2_ref, offset_2_tgt = L.run_regressor_pair(cv, p['r2_pair'])
         return offset_1, offset_2_ref, offset_2_tgt
 

@@ -432,3 +432,14 @@ def test_three_view_compose_on_device_kernels(dev, golden):
     got = ops.three_view_align(*meshes, 180, 320)
     for x, y, what in zip(got, (a1, a2, b1 + off, b2 + off, (a2 + b1 + off) / 2), ('a1', 'a2', 'b1', 'b2', 'mid')):
         close(x, y, 1e-4, 'align ' + what)
+
+
+def test_cost_volume_both_directions_one_launch(dev):
+    """ss_cost_volume_bidir == (ss_cost_volume(x1, x2), ss_cost_volume(x2, x1)) bit for bit, r = 5 and r = 3, ragged map."""
+    from stabstitch2_amd import ops
+    torch.manual_seed(9)
+    for (n, h, w, c, r) in ((5, 45, 60, 128, 5), (3, 23, 31, 64, 3), (2, 9, 12, 16, 5)):
+        x1 = torch.randn(n, h, w, c, device=dev)
+        x2 = torch.randn(n, h, w, c, device=dev)
+        both = ops.cost_volume_bidir(x1, x2, r)
+        assert torch.equal(both[0], ops.cost_volume(x1, x2, r)) and torch.equal(both[1], ops.cost_volume(x2, x1, r)), (n, h, w, c, r)
