@@ -655,20 +655,32 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     if (p.bias) bias4 = *reinterpret_cast<const w_f32x4*>(p.bias + (long long)grp * p.Co + cbk * BN + 4 * cq);
     __syncthreads();                            // every wave is done with the raw buffers (the stage aliases them)
     W_STAMP(4);
+    float neg_one = -1.f;
+    asm("" : "+v"(neg_one));                    // opaque to the optimiser: it would turn fma(y, -1, x) back into an unpacked v_sub_f32
     {
         float* srow = smem + (wave * 2) * 32 * BN + (lane & 31);
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            for (int r = 0; r < 16; r += 2) {
+                const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;          // accumulator r + 1 = tile + 1
                 if constexpr (STREAM && VAR == 3) {             // T0 / T1 were formed inside the stream
                     srow[tile * BN + blk * 32] = acc[0][blk][r];
+                    srow[(tile + 1) * BN + blk * 32] = acc[0][blk][r + 1];
                     srow[(32 + tile) * BN + blk * 32] = acc[1][blk][r];
+                    srow[(32 + tile + 1) * BN + blk * 32] = acc[1][blk][r + 1];
                 } else {
-                    const float m0 = acc[0][blk][r], m1 = acc[1][blk][r], m2 = acc[2][blk][r], m3 = acc[3][blk][r];
-                    srow[tile * BN + blk * 32] = (m0 + m1) + m2;
-                    srow[(32 + tile) * BN + blk * 32] = (m1 - m2) - m3;
+                    // two accumulators per packed instruction (the registers of a pair are adjacent): beside the other
+                    // workgroup's MFMA stream every VALU instruction of the epilogue waits for an issue slot
+                    const w_f32x2 m0 = {acc[0][blk][r], acc[0][blk][r + 1]}, m1 = {acc[1][blk][r], acc[1][blk][r + 1]};
+                    const w_f32x2 m2 = {acc[2][blk][r], acc[2][blk][r + 1]}, m3 = {acc[3][blk][r], acc[3][blk][r + 1]};
+                    const w_f32x2 neg1 = {neg_one, neg_one};      // x - y as fma(y, -1, x): same rounding, and it packs (fsub does not)
+                    const w_f32x2 t0 = (m0 + m1) + m2;
+                    const w_f32x2 t1 = __builtin_elementwise_fma(m3, neg1, __builtin_elementwise_fma(m2, neg1, m1));
+                    srow[tile * BN + blk * 32] = t0[0];
+                    srow[(tile + 1) * BN + blk * 32] = t0[1];
+                    srow[(32 + tile) * BN + blk * 32] = t1[0];
+                    srow[(32 + tile + 1) * BN + blk * 32] = t1[1];
                 }
             }
     }
@@ -693,7 +705,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
             const int e = e0 + i;
             const int px = e * PSTEP + tid / QP;
             const float sg = ((px >> 1) & 1) ? -1.f : 1.f;
-            w_f32x4 v = (x[i] + sg * y[i]) + sg * z[i];
+            const w_f32x4 sg4 = {sg, sg, sg, sg};
+            // (+-1) * y is exact: the fused form rounds exactly like the multiply-then-add it replaces, in half the instructions
+            w_f32x4 v = __builtin_elementwise_fma(sg4, z[i], __builtin_elementwise_fma(sg4, y[i], x[i]));
             v = v + bias4;
             if (RES) v = v + __builtin_bit_cast(w_f32x4, rv[e]);
 #pragma unroll
