@@ -27,12 +27,19 @@ for fam in ('conv_wino_kernel', 'conv_igemm_kernel', 'stem_pool_kernel'):
     tot = sum(r[1] for r in rows)
     if not calls:
         continue
+    note = ''
+    if fam == 'conv_igemm_kernel':
+        # a split-K convolution is two kernels inside one event bracket: its partial sums are reduced by splitk_reduce_kernel
+        red = [v for k, v in stats.items() if 'splitk_reduce_kernel' in k]
+        if red:
+            tot += sum(r[1] for r in red)
+            note = '   (+ %d splitk_reduce_kernel launches, inside the same brackets)' % sum(r[0] for r in red)
     tr = tot / calls
     if fam not in prof['roofline']['per_kernel']:
         continue
     ep = prof['roofline']['per_kernel'][fam]['avg_launch_us']
     eu = unprof['roofline']['per_kernel'][fam]['avg_launch_us']
-    print('#   %-22s %12.2f %14.2f %16.2f %10.3f' % (fam, tr, ep, eu, tr / ep))
+    print('#   %-22s %12.2f %14.2f %16.2f %10.3f%s' % (fam, tr, ep, eu, tr / ep, note))
 print('#   frames/s: profiled run %.1f, un-profiled run %.1f; conv engine ms per clip (events): %.3f / %.3f'
       % (prof['value'], unprof['value'], prof['roofline']['kernel_ms_per_step'], unprof['roofline']['kernel_ms_per_step']))
 print('#   (HIP events bracket a launch on the stream and include its ~2 us launch gap; the trace is the kernel alone)')
