@@ -147,14 +147,20 @@ class JointEstimator:
         self.carry = None
 
     @torch.no_grad()
-    def push(self, lr1, lr2):
-        """The next b frames of both views, [b,3,360,480] device tensors."""
+    def push(self, lr1, lr2, cache1=None):
+        """The next b frames of both views, [b,3,360,480] device tensors.  cache1 = (f64, f32): view 1's SpatialNet trunk
+        features for exactly these frames from an earlier pair's `cache2` (needs tmotion1; lr1 is not read then -- only
+        view 2 goes through the stem and the trunks)."""
         L, sp, tp = self.L, self.sp, self.tp
-        b = lr1.shape[0]
+        b = lr2.shape[0]
         s, e = self.pos, self.pos + b
         if e > self.n:
             raise ValueError('more frames pushed (%d) than announced (%d)' % (e, self.n))
-        xa, xb = L.run_stem_shared([lr1, lr2], sp['stem_pair'])
+        if cache1 is not None and self.tmotion1 is None:
+            raise ValueError('cache1 needs tmotion1: view 1 is skipped entirely')
+        xa, xb = L.run_stem_shared([lr2] if cache1 is not None else [lr1, lr2], sp['stem_pair'])
+        if cache1 is None and self.tmotion1 is not None:
+            xb = xb[b:]                                     # TemporalNet continues on view 2 only
         if JOINT_OVERLAP:
             # SpatialNet (main stream) and TemporalNet (side stream) are independent behind the shared stem: two chains of
             # launches whose partially filled last rounds top each other up
@@ -164,26 +170,31 @@ class JointEstimator:
             xb.record_stream(side)
             with torch.cuda.stream(side):
                 self._temporal(xb, b, s, e)
-            self._spatial(xa, b, s, e)
+            self._spatial(xa, b, s, e, cache1)
             main.wait_stream(side)
         else:
-            self._spatial(xa, b, s, e)
+            self._spatial(xa, b, s, e, cache1)
             self._temporal(xb, b, s, e)
         self.pos = e
 
-    def _spatial(self, xa, b, s, e):
+    def _spatial(self, xa, b, s, e, cache1=None):
         L, sp = self.L, self.sp
         f64 = L.run_trunk_body(xa, sp['s1'])
         f32 = L.run_stage2(f64, sp['s2'])
-        off1, off_ref, off_tgt = self.spatial_net.forward_pair(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
+        if cache1 is None:
+            f64_1, f32_1, f64_2, f32_2 = f64[:b], f32[:b], f64[b:], f32[b:]
+        else:
+            (f64_1, f32_1), f64_2, f32_2 = cache1, f64, f32
+        off1, off_ref, off_tgt = self.spatial_net.forward_pair(f64_1, f64_2, f32_1, f32_2, LR_H, LR_W)
         if self.cache2 is not None:
-            self.cache2.append((f64[b:], f32[b:]))
+            self.cache2.append((f64_2, f32_2))
         ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W, out=(self.m1[s:e], self.m2[s:e]))
 
     def _temporal(self, xb, b, s, e):
+        """xb: the TemporalNet stem output of the views in self.views, view-major [nv*b,90,120,64]."""
         L, tp = self.L, self.tp
         nv = len(self.views)
-        f = L.run_trunk_body(xb if self.tmotion1 is None else xb[b:], tp['s1'])      # [nv*b,45,60,128], view-major
+        f = L.run_trunk_body(xb, tp['s1'])              # [nv*b,45,60,128], view-major
         lead = 0 if s == 0 else 1                       # the pair (last frame of the previous chunk, first of this one)
         rows = b - 1 + lead
         if rows > 0:
@@ -210,14 +221,15 @@ class JointEstimator:
 
 
 @torch.no_grad()
-def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None, cache2=None):
+def joint_stage(spatial_net, temporal_net, lr1, lr2, chunk=None, tmotion1=None, cache2=None, cache1=None):
     """SpatialNet and TemporalNet of a resident 2-view clip in one sweep (JointEstimator fed in chunks of `chunk` frames).
+    cache1: per chunk (same chunking) view 1's SpatialNet trunk features kept by an earlier pair (with tmotion1).
     -> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""
     chunk = chunk or SPATIAL_CHUNK
-    n = lr1.shape[0]
-    est = JointEstimator(spatial_net, temporal_net, n, lr1.device, tmotion1, cache2)
-    for s in range(0, n, chunk):
-        est.push(lr1[s:s + chunk], lr2[s:s + chunk])
+    n = lr2.shape[0]
+    est = JointEstimator(spatial_net, temporal_net, n, lr2.device, tmotion1, cache2)
+    for i, s in enumerate(range(0, n, chunk)):
+        est.push(None if cache1 is not None else lr1[s:s + chunk], lr2[s:s + chunk], None if cache1 is None else cache1[i])
     return est.result()
 
 
@@ -262,9 +274,10 @@ def estimate_meshes(nets, lr1, lr2, tmotion1=None, spatial_cache1=None, keep_spa
         main.wait_stream(side)
         for t in (t1, t2):
             t.record_stream(main)
-    elif SHARED_STEM and tmotion1 is None and spatial_cache1 is None:
-        # (with view 1's motions / features known, half of a shared stem would be wasted)
-        s1, s2, t1, t2 = joint_stage(spatial_net, temporal_net, lr1, lr2, cache2=cache2)
+    elif SHARED_STEM and (tmotion1 is None) == (spatial_cache1 is None):
+        # both nets behind one stem; with view 1's motions AND trunk features known (second pair of a three-view clip) only
+        # view 2 goes through it
+        s1, s2, t1, t2 = joint_stage(spatial_net, temporal_net, lr1, lr2, tmotion1=tmotion1, cache2=cache2, cache1=spatial_cache1)
     else:
         s1, s2 = spatial_stage(spatial_net, lr1, lr2, cache1=spatial_cache1)
         if tmotion1 is None:
@@ -508,12 +521,12 @@ U8_FUSED = os.environ.get('SS_U8_FUSED', '1') == '1'
 
 
 @torch.no_grad()
-def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None, bbox=None, size=None):
+def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None, bbox=None, size=None, prescaled=False):
     """frame_lists: V device tensors [N,H,W,3] uint8; meshes: V tensors [1,N,7,9,2] -> (uint8 [N,Hc,Wc,3], Hc, Wc):
     `render_frames(..., 'AVERAGE')` followed by `to_video_frames`, fused, one launch for the clip."""
     n = meshes[0].shape[1]
     img_h, img_w = frame_lists[0].shape[1], frame_lists[0].shape[2]
-    hc, wc, src, T = render_plan(meshes, img_h, img_w, bbox=bbox, size=size)
+    hc, wc, src, T = render_plan(meshes, img_h, img_w, prescaled, bbox=bbox, size=size)
     if out is None or tuple(out.shape) != (n, hc, wc, 3) or not out.is_contiguous():
         out = torch.empty((n, hc, wc, 3), device=meshes[0].device, dtype=torch.uint8)
     fp = ops.render_footprints(src, T, img_h, img_w, hc, wc) if SKIP_OUTSIDE else None
@@ -543,6 +556,25 @@ def run_two_view_u8(frames1, frames2, nets, warp_mode='NORMAL', fusion_mode='AVE
     hr2, lr2 = load_frames_u8(frames2, device=device)
     frames, hc, wc, m1, m2 = run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode, fusion_mode)
     return to_video_frames(frames, to_host), hc, wc, m1, m2
+
+
+@torch.no_grad()
+def run_three_view_u8(frames1, frames2, frames3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', device='cuda', to_host=False):
+    """`run_three_view` from decoded uint8 frames [N,H,W,3] to uint8 video frames (device-resident clip).
+    -> (uint8 [N,Hc,Wc,3], Hc, Wc, mesh1, middle, mesh3)."""
+    f = [_as_device_u8(x, device) for x in (frames1, frames2, frames3)]
+    img_h, img_w = f[0].shape[1], f[0].shape[2]
+    if U8_FUSED and fusion_mode == 'AVERAGE':
+        lr = [ops.ingest_u8(x, want_hr=False)[1] for x in f]
+        a12 = estimate_meshes(nets, lr[0], lr[1], keep_spatial_cache2=True)
+        a23 = estimate_meshes(nets, lr[1], lr[2], tmotion1=a12['tmotion2'], spatial_cache1=a12.get('spatial_cache2'))
+        ms = three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'], a23['smooth_mesh2'], img_h, img_w)
+        u8, hc, wc = render_frames_u8(f, list(ms), warp_mode, prescaled=True)
+        return (u8.cpu().numpy() if to_host else u8), hc, wc, ms[0], ms[1], ms[2]
+    io = [ops.ingest_u8(x) for x in f]
+    frames, hc, wc, m1, mid, m3 = run_three_view(io[0][0], io[1][0], io[2][0], io[0][1], io[1][1], io[2][1], nets, warp_mode,
+                                                 fusion_mode)
+    return to_video_frames(frames, to_host), hc, wc, m1, mid, m3
 
 
 class HostClipRunner:
@@ -633,14 +665,15 @@ class HostClipRunner:
 
 # ------------------------------------------------------------------ long videos, one global canvas, bounded device memory
 class LongVideoStitcher:
-    """The reference's whole-video behaviour for videos of any length: it keeps every frame in host lists
+    """The reference's whole-video behaviour for videos of any length, two or three views: it keeps every frame in host lists
     (test_online_tra.py:250-278), smooths over the whole sequence (:359-392) and renders every frame onto ONE canvas, the
-    bounding box of all frames' meshes (:106-120) -- cutting a video into independent clips (HostClipRunner) does not
-    reproduce that output.  Here the frames stay on the host (uint8 [N,H,W,3] arrays, memory-mapped files, ...) and go
-    through the device twice, `chunk` frames at a time:
+    bounding box of all frames' meshes (:106-120; three views: test_online_tra_threeview.py:154-505) -- cutting a video into
+    independent clips (HostClipRunner) does not reproduce that output.  Here the frames stay on the host (uint8 [N,H,W,3]
+    arrays, memory-mapped files, ...) and go through the device twice, `chunk` frames at a time:
       pass 1  `estimate`: uint8 upload -> cv2-exact LR resize -> SpatialNet / TemporalNet (JointEstimator; a chunk boundary
-              carries one feature map per view) -> the stream's motions [N,7,9,2]; then tsmotion, all sliding SmoothNet
-              windows and the global canvas box on those mesh-sized tensors;
+              carries one feature map per view; three views: pair (2,3) takes the middle view's trunk features of the same
+              chunk and its temporal motions from pair (1,2)) -> the stream's motions [N,7,9,2]; then tsmotion, all sliding
+              SmoothNet windows, the three-view alignment and the global canvas box on those mesh-sized tensors;
       pass 2  `render`: uint8 upload -> fused TPS warp + fusion onto the shared canvas -> uint8 video frames -> host.
     Device memory is that of one chunk plus O(N) mesh-sized tensors (504 bytes per frame, view and motion kind); uploads,
     compute and downloads of neighbouring chunks overlap on three HIP streams.  The meshes equal those of the resident
@@ -651,19 +684,23 @@ class LongVideoStitcher:
         self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
         self.chunk = chunk or SPATIAL_CHUNK
         self.io = HostClipRunner(nets, device, warp_mode, fusion_mode)
-        self.acc = self.bbox = self.hc = self.wc = None
+        self.acc = self.meshes = self.bbox = self.hc = self.wc = None
+        self.prescaled = False
 
-    def _chunks(self, frames1, frames2):
-        n = len(frames1)
-        if len(frames2) != n:
-            raise ValueError('views differ in length: %d vs %d frames' % (n, len(frames2)))
+    def _chunks(self, views):
+        n = len(views[0])
+        if len(views) not in (2, 3):
+            raise ValueError('two or three views, got %d' % len(views))
+        for v in views[1:]:
+            if len(v) != n:
+                raise ValueError('views differ in length: %d vs %d frames' % (n, len(v)))
         for s in range(0, n, self.chunk):
             e = min(s + self.chunk, n)
-            yield s, e, (frames1[s:e], frames2[s:e])
+            yield s, e, tuple(v[s:e] for v in views)
 
-    def _uploads(self, frames1, frames2):
+    def _uploads(self, views):
         """(s, e, device uint8 tensors, ready event), the next chunk's upload always enqueued before this one is consumed."""
-        it = self._chunks(frames1, frames2)
+        it = self._chunks(views)
         nxt = next(it, None)
         up = None if nxt is None else self.io._upload(nxt[2])
         while nxt is not None:
@@ -673,16 +710,18 @@ class LongVideoStitcher:
             yield cur[0], cur[1], cur_up[0], cur_up[1]
 
     @torch.no_grad()
-    def estimate(self, frames1, frames2):
-        """Pass 1 -> the dict of `estimate_meshes` for the WHOLE video (+ the global canvas: self.bbox, self.hc, self.wc)."""
-        n = len(frames1)
+    def estimate(self, *views):
+        """Pass 1 over V = 2 or 3 views -> the dict of `estimate_meshes` for the WHOLE video (three views: of pair (1,2), plus
+        'pair23'); sets self.meshes (the V render meshes [1,N,7,9,2]) and the global canvas self.bbox, self.hc, self.wc."""
+        n = len(views[0])
         if n < WINDOW:
             raise ValueError('need at least %d frames for the sliding smooth window, got %d' % (WINDOW, n))
         spatial_net, temporal_net, smooth_net = self.nets
         comp = self.io.comp
-        est = None
+        est = est23 = None
+        mid_cache = [] if len(views) == 3 else None
         img_h = img_w = None
-        for s, e, d, ev in self._uploads(frames1, frames2):
+        for s, e, d, ev in self._uploads(views):
             comp.wait_event(ev)
             with torch.cuda.stream(comp):
                 for t in d:
@@ -690,40 +729,52 @@ class LongVideoStitcher:
                 d = [t if t.is_contiguous() else t.contiguous() for t in d]
                 img_h, img_w = d[0].shape[1], d[0].shape[2]
                 if est is None:
-                    est = JointEstimator(spatial_net, temporal_net, n, self.dev)
-                _, lr1 = ops.ingest_u8(d[0], want_hr=False)
-                _, lr2 = ops.ingest_u8(d[1], want_hr=False)
-                est.push(lr1, lr2)
+                    est = JointEstimator(spatial_net, temporal_net, n, self.dev, cache2=mid_cache)
+                    if mid_cache is not None:       # the middle view's temporal motions: pair (1,2)'s buffer, filled chunk by chunk
+                        est23 = JointEstimator(spatial_net, temporal_net, n, self.dev, tmotion1=est.tm[1])
+                lrs = [ops.ingest_u8(t, want_hr=False)[1] for t in d]
+                est.push(lrs[0], lrs[1])
+                if est23 is not None:
+                    est23.push(None, lrs[2], mid_cache.pop())
         with torch.cuda.stream(comp):
             self.acc = smooth_stage(smooth_net, *est.result())
-            self.bbox = canvas_bbox([self.acc['smooth_mesh1'], self.acc['smooth_mesh2']], img_h, img_w)
-            self.hc, self.wc = canvas_size(self.bbox)
+            if est23 is None:
+                self.meshes, self.prescaled = [self.acc['smooth_mesh1'], self.acc['smooth_mesh2']], False
+            else:
+                a23 = smooth_stage(smooth_net, *est23.result())
+                self.acc['pair23'] = a23
+                self.meshes = list(three_view_compose(self.acc['smooth_mesh1'], self.acc['smooth_mesh2'], a23['smooth_mesh1'],
+                                                      a23['smooth_mesh2'], img_h, img_w))
+                self.prescaled = True
+            self.bbox = canvas_bbox(self.meshes, img_h, img_w, self.prescaled)
+            self.hc, self.wc = canvas_size(self.bbox)       # (host read-back: the compute stream is drained here)
         return self.acc
 
     @torch.no_grad()
-    def render(self, frames1, frames2):
+    def render(self, *views):
         """Pass 2: yields (uint8 [m,Hc,Wc,3] pinned host tensor, s, e) per chunk of frames [s, e), one chunk late at most;
         a yielded tensor stays valid until two more chunks have been yielded."""
         if self.acc is None:
             raise RuntimeError('estimate() first')
+        if len(views) != len(self.meshes):
+            raise ValueError('estimate() saw %d views, render() got %d' % (len(self.meshes), len(views)))
         io = self.io
-        m1, m2 = self.acc['smooth_mesh1'], self.acc['smooth_mesh2']
         pending = None
         k = 0
-        for s, e, d, ev in self._uploads(frames1, frames2):
+        for s, e, d, ev in self._uploads(views):
             io.comp.wait_event(ev)
             with torch.cuda.stream(io.comp):
                 for t in d:
                     t.record_stream(io.comp)
                 d = [t if t.is_contiguous() else t.contiguous() for t in d]
-                ms = [m1[:, s:e].contiguous(), m2[:, s:e].contiguous()]
+                ms = [m[:, s:e].contiguous() for m in self.meshes]
                 if U8_FUSED and self.fusion_mode == 'AVERAGE':
-                    u8, _, _ = render_frames_u8(d, ms, self.warp_mode, bbox=self.bbox, size=(self.hc, self.wc))
+                    u8, _, _ = render_frames_u8(d, ms, self.warp_mode, bbox=self.bbox, size=(self.hc, self.wc),
+                                                prescaled=self.prescaled)
                 else:
-                    hr1, _ = ops.ingest_u8(d[0])
-                    hr2, _ = ops.ingest_u8(d[1])
-                    fr, _, _ = render_frames([hr1, hr2], ms, self.warp_mode, self.fusion_mode, bbox=self.bbox,
-                                             size=(self.hc, self.wc))
+                    hrs = [ops.ingest_u8(t)[0] for t in d]
+                    fr, _, _ = render_frames(hrs, ms, self.warp_mode, self.fusion_mode, prescaled=self.prescaled,
+                                             bbox=self.bbox, size=(self.hc, self.wc))
                     u8 = ops.canvas_to_u8(fr)
                 ev2 = torch.cuda.Event()
                 ev2.record(io.comp)
@@ -738,6 +789,21 @@ class LongVideoStitcher:
             yield pending[1], pending[2], pending[3]
 
 
+def _run_long(views, nets, warp_mode, fusion_mode, device, chunk, sink):
+    st = LongVideoStitcher(nets, device, warp_mode, fusion_mode, chunk)
+    st.estimate(*views)
+    video = None
+    if sink is None:
+        import numpy as np
+        video = np.empty((len(views[0]), st.hc, st.wc, 3), dtype=np.uint8)
+    for host, s, e in st.render(*views):
+        if sink is None:
+            video[s:e] = host.numpy()
+        else:
+            sink(host, s, e)
+    return (video, st.hc, st.wc) + tuple(st.meshes)
+
+
 @torch.no_grad()
 def run_two_view_long(frames1, frames2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', device='cuda', chunk=None,
                       sink=None):
@@ -746,15 +812,12 @@ def run_two_view_long(frames1, frames2, nets, warp_mode='NORMAL', fusion_mode='A
     (LongVideoStitcher).  sink(video_chunk [m,Hc,Wc,3] uint8 host tensor, s, e) receives the stitched frames in order
     (e.g. cv2.VideoWriter.write per frame, test_online_tra.py:409-417); without a sink they are collected into one
     ndarray.  -> (video | None, Hc, Wc, smooth_mesh1, smooth_mesh2)."""
-    st = LongVideoStitcher(nets, device, warp_mode, fusion_mode, chunk)
-    acc = st.estimate(frames1, frames2)
-    video = None
-    if sink is None:
-        import numpy as np
-        video = np.empty((len(frames1), st.hc, st.wc, 3), dtype=np.uint8)
-    for host, s, e in st.render(frames1, frames2):
-        if sink is None:
-            video[s:e] = host.numpy()
-        else:
-            sink(host, s, e)
-    return video, st.hc, st.wc, acc['smooth_mesh1'], acc['smooth_mesh2']
+    return _run_long((frames1, frames2), nets, warp_mode, fusion_mode, device, chunk, sink)
+
+
+@torch.no_grad()
+def run_three_view_long(frames1, frames2, frames3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', device='cuda', chunk=None,
+                        sink=None):
+    """`run_three_view` (test_online_tra_threeview.py:154-505) for host-resident uint8 videos of any length, on the
+    reference's single global canvas.  -> (video | None, Hc, Wc, mesh1, middle, mesh3), the meshes in canvas pixels."""
+    return _run_long((frames1, frames2, frames3), nets, warp_mode, fusion_mode, device, chunk, sink)

@@ -207,6 +207,51 @@ def test_long_video_equals_resident_clip(dev, hip_nets):
     assert peaks[1] - peaks[0] < 96 * 2 * 7 * 126 * 4 * 12 + (8 << 20), peaks
 
 
+def test_three_view_long_video_equals_resident_clip(dev, hip_nets):
+    """Three views from host memory in chunks of 32 frames (pair (2,3) takes the middle view's trunk features chunk by chunk
+    and its temporal motions from pair (1,2)'s buffer) against the same video resident on the device: the re-projected
+    meshes, the single global canvas and every output byte are equal (test_online_tra_threeview.py:154-505)."""
+    from stabstitch2_amd import pipeline
+    n, h, w = 70, 180, 320
+    u8 = _u8_clip(n, h, w, 9, dev, views=3)
+    host = [t.cpu().numpy() for t in u8]
+    want, hc, wc, m1, mid, m3 = pipeline.run_three_view_u8(u8[0], u8[1], u8[2], hip_nets, device=dev)
+    got, ghc, gwc, g1, gmid, g3 = pipeline.run_three_view_long(host[0], host[1], host[2], hip_nets, device=dev, chunk=32)
+    assert (ghc, gwc) == (hc, wc)
+    for a, b in ((g1, m1), (gmid, mid), (g3, m3)):
+        assert float((a - b).abs().max()) <= 1e-6
+    assert np.array_equal(got, want.cpu().numpy())
+    # the fp32 route (LINEAR-free three-view fusion is AVERAGE only in the reference; SS_U8_FUSED=0 takes fp32 planes)
+    old = pipeline.U8_FUSED
+    pipeline.U8_FUSED = False
+    try:
+        got2, _, _, _, _, _ = pipeline.run_three_view_long(host[0][:40], host[1][:40], host[2][:40], hip_nets, device=dev, chunk=32)
+        want2, _, _, _, _, _ = pipeline.run_three_view_u8(u8[0][:40], u8[1][:40], u8[2][:40], hip_nets, device=dev)
+    finally:
+        pipeline.U8_FUSED = old
+    assert np.array_equal(got2, want2.cpu().numpy())
+    with pytest.raises(ValueError):
+        pipeline.run_three_view_long(host[0], host[1][:50], host[2], hip_nets, device=dev)
+
+
+def test_joint_estimator_cached_first_view(dev, hip_nets):
+    """The second pair of a three-view clip through the JointEstimator (view 1's trunk features and temporal motions given,
+    only view 2 behind the shared stem) against the plain stages with separate stems."""
+    from stabstitch2_amd import pipeline
+    n = 40
+    _, lr = synth.make_clip_device(n, 360, 480, seed=8, views=3, device=dev)
+    a12 = pipeline.estimate_meshes(hip_nets, lr[0], lr[1], keep_spatial_cache2=True)
+    got = pipeline.joint_stage(hip_nets[0], hip_nets[1], None, lr[2], tmotion1=a12['tmotion2'], cache1=a12['spatial_cache2'])
+    s1, s2 = pipeline.spatial_stage(hip_nets[0], lr[1], lr[2])
+    t2 = pipeline.temporal_stage(hip_nets[1], lr[2])
+    close(got[0], s1, 1e-4, 'smotion1 of pair (2,3)')
+    close(got[1], s2, 1e-4, 'smotion2 of pair (2,3)')
+    close(got[3], t2, 1e-4, 'tmotion of view 3')
+    assert got[2] is a12['tmotion2']
+    with pytest.raises(ValueError):
+        pipeline.JointEstimator(hip_nets[0], hip_nets[1], n, dev).push(None, lr[2][:8], a12['spatial_cache2'][0])
+
+
 def test_joint_estimator_chunking_is_exact(dev, hip_nets):
     """Feeding a clip to the JointEstimator in chunks of 32 / 24 / 7 frames: spatial motions per frame pair are batch
     independent up to kernel-variant choice (observed 3e-5 px), temporal motions pair every frame with its predecessor
