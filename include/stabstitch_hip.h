@@ -302,6 +302,14 @@ SS_API int ss_smooth_stitch(const float* smesh1, const float* smesh2, const floa
                      const float* delta, float* ori_mesh1, float* ori_mesh2, float* smooth_mesh1, float* smooth_mesh2,
                      float* ori_path2, float* smooth_path2, int nw, int t, void* stream);
 
+/* Streaming mode (one frame pair per call; the reference's per-frame loop, test_online_tra.py:284-392, keeps Python lists):
+ * the sliding buffers have fixed addresses, a new frame shifts them.  ring [rings][window][elems]: every ring drops its
+ * oldest slot and takes the `elems` floats at src + src_off[r] (src_off: HOST array of `rings` <= 8 element offsets) as its
+ * newest; in the same launch `blocks` blocks of `block` floats are moved inside `state`: block b (at b * stride) <- the
+ * floats `delta` (>= block) further.  (window - 1) * elems <= 2048. */
+SS_API int ss_window_push(float* ring, const float* src, const long long* src_off, int rings, int window, int elems,
+                   float* state, int blocks, int block, long long stride, long long delta, void* stream);
+
 /* canvas-sized elementwise helpers of the harnesses: out = (in + add) * mul  ((img+1)*127.5,
  * test_metric_ssd.py:166);  out = a + b - a*b  (three-view mask union, test_online_tra_threeview.py:501) */
 SS_API int ss_add_mul(const float* in, float* out, float add, float mul, long long n, void* stream);

@@ -81,6 +81,7 @@ SIGNATURES = {
     'ss_smooth_embed': (c_i, [c_fp] * 9 + [c_i] * 4 + [c_st]),
     'ss_smooth_finalize': (c_i, [c_fp] * 13 + [c_i] * 4 + [c_st]),
     'ss_smooth_stitch': (c_i, [c_fp] * 11 + [c_i] * 2 + [c_st]),
+    'ss_window_push': (c_i, [c_fp, c_fp, ctypes.c_void_p, c_i, c_i, c_i, c_fp, c_i, c_i, c_ll, c_ll, c_st]),
     'ss_alignment_psnr_ssim': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_stability_score': (c_i, [c_fp, c_fp, c_i, c_st]),
     'ss_distortion_score': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),

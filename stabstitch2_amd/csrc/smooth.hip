@@ -172,3 +172,50 @@ extern "C" int ss_smooth_stitch(const float* smesh1, const float* smesh2, const 
         hipLaunchKernelGGL(smooth_path_chain_kernel, dim3(1), dim3(128), 0, st, ori_path2, smooth_path2, n, t);
     return ss_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Streaming mode: the sliding windows live in buffers of FIXED address (the steady state is a captured HIP graph), so a new
+// frame SHIFTS them: rings [R][W][E] drop slot 0 and take row src + src_off[r] as slot W-1; in the same launch `blocks`
+// blocks of `block` floats move inside `state` (dst block b at b * stride, its source `delta` floats further: last frame's
+// spatial motions become "previous").  One launch where the torch form took cat + copy per ring (8 + 1 launches per pair).
+struct WinPushArgs { long long src_off[8]; };
+__global__ __launch_bounds__(256) void window_push_kernel(float* __restrict__ ring, const float* __restrict__ src,
+                                                          WinPushArgs a, int R, int W, int E, float* __restrict__ state,
+                                                          int blocks, int block, long long stride, long long delta) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (r == R) {                                        // the state move (source and destination never overlap: delta >= block)
+        for (int i = tid; i < blocks * block; i += 256) {
+            const int b = i / block, e = i - b * block;
+            state[(long long)b * stride + e] = state[(long long)b * stride + delta + e];
+        }
+        return;
+    }
+    float* g = ring + (long long)r * W * E;
+    const int keep = (W - 1) * E;
+    constexpr int MAXV = 8;                              // keep <= 2048 floats (host-checked)
+    float v[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = tid + 256 * k;
+        v[k] = i < keep ? g[E + i] : 0.f;
+    }
+    __syncthreads();                                     // every slot is read before any is overwritten
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = tid + 256 * k;
+        if (i < keep) g[i] = v[k];
+    }
+    for (int e = tid; e < E; e += 256) g[keep + e] = src[a.src_off[r] + e];
+}
+
+extern "C" int ss_window_push(float* ring, const float* src, const long long* src_off, int rings, int window, int elems,
+                              float* state, int blocks, int block, long long stride, long long delta, void* stream) {
+    if (!ring || !src || !src_off || rings <= 0 || rings > 8 || window < 2 || elems <= 0 ||
+        (long long)(window - 1) * elems > 2048 || blocks < 0 || (blocks > 0 && (!state || block <= 0 || delta < block)))
+        return SS_ERR_ARG;
+    WinPushArgs a;
+    for (int r = 0; r < 8; ++r) a.src_off[r] = r < rings ? src_off[r] : 0;
+    hipLaunchKernelGGL(window_push_kernel, dim3(rings + (blocks > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, ring, src, a,
+                       rings, window, elems, state, blocks, block, stride, delta);
+    return ss_launch_status();
+}

@@ -62,33 +62,47 @@ class OnlineStitcher:
         self.wc = int((bb[1] - bb[0]).int())
 
     @torch.no_grad()
-    def _render(self, hr1, hr2, mesh1, mesh2):
-        """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc]."""
+    def _render(self, hr1, hr2, mesh1, mesh2, out=None):
+        """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc] (written to `out` if given)."""
         src = ops.mesh_normalize_views([mesh1, mesh2], self.bbox, self.h, self.w)[0]          # [2,63,2]
         T = ops.tps_solve_shared(src, self.nrigid)
         if self.fusion_mode == 'AVERAGE':
             fp = None
             if pipeline.SKIP_OUTSIDE:        # same footprint skipping as the offline render (pipeline.render_frames)
                 fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc)[0]
-            return ops.render_average([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode, footprint=fp)
+            return ops.render_average([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode, out=out, footprint=fp)
         w = ops.tps_warp_views([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode)
-        return ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
+        res = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
+        return res if out is None else out.copy_(res)
 
     # ------------------------------------------------------------------ steady state (window full, canvas fixed)
+    # State tensors of the steady state (fixed addresses: the step is captured into a HIP graph):
+    #   pair_s [2 views][prev, new][126]   spatial motions of the previous and the current pair
+    #   pair_t [2 views][zero, new][126]   temporal motions (slot 0 stays zero: tsmotion of a 2-frame batch reads slot 1 only)
+    #   ring   [smesh v0, smesh v1, tsm v0, tsm v1][7][126]     the sliding SmoothNet window
+    #   prev_feat [2,45,60,128]            TemporalNet stage-1 features of the previous frame, both views
+    _STATE = ('prev_feat', 'pair_s', 'ring')
+
     def _init_static(self):
         d = self.dev
+        e = 126
+        pair_s = torch.zeros((2, 2, e), device=d)
+        pair_s[:, 0] = self.prev_smotion.reshape(2, e)
+        ring = torch.stack([torch.cat(r, 0).reshape(WINDOW, e) for r in (self.ring_smesh[0], self.ring_smesh[1],
+                                                                          self.ring_tsm[0], self.ring_tsm[1])], 0).contiguous()
         st = {'hr1': torch.empty((1, 3, self.h, self.w), device=d), 'hr2': torch.empty((1, 3, self.h, self.w), device=d),
               'lr1': torch.empty((1, 3, pipeline.LR_H, pipeline.LR_W), device=d),
               'lr2': torch.empty((1, 3, pipeline.LR_H, pipeline.LR_W), device=d),
-              'prev_feat': self.prev_feat.clone(), 'prev_smotion': self.prev_smotion.clone(),
-              'smesh': [torch.cat(self.ring_smesh[v], 0).contiguous() for v in range(2)],      # [7,7,9,2]
-              'tsm': [torch.cat(self.ring_tsm[v], 0).contiguous() for v in range(2)],
+              'prev_feat': self.prev_feat.clone(), 'pair_s': pair_s, 'pair_t': torch.zeros((2, 2, e), device=d),
+              'ring': ring, 'ts_out': torch.empty((2, 4, e), device=d),
               'out': torch.empty((3, self.hc, self.wc), device=d)}
         self.static = st
 
     def _step_static(self):
-        """One steady-state push on the static buffers (capturable: no host sync, no data-dependent shapes)."""
+        """One steady-state push on the static buffers (capturable: no host sync, no data-dependent shapes; every result
+        lands in place -- no torch op in the step besides the copy of the cached features)."""
         st = self.static
+        e = 126
         # SpatialNet and TemporalNet read the same two LR frames through trunks of identical architecture: one grouped
         # launch per layer for both (12 launches fewer per pushed pair)
         if self.trunk_pair is None:
@@ -96,21 +110,21 @@ class OnlineStitcher:
             self.trunk_versions = self._versions()
         f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)            # [2(net),2(view),45,60,128]
         off1, off_ref, off_tgt = self.spatial.forward_features(f2[0], 1, pipeline.LR_H, pipeline.LR_W)
-        m1s, m2s = ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W)
-        smotion = torch.cat((m1s, m2s), 0)
+        ps, pt = st['pair_s'], st['pair_t']
+        ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W,
+                           out=(ps[0, 1].view(1, 7, 9, 2), ps[1, 1].view(1, 7, 9, 2)))
         feat = f2[1]
-        tmotion = self.temporal.motions_from_features(st['prev_feat'], feat)
+        self.temporal.motions_from_features(st['prev_feat'], feat, out_slices=[(0, 1, pt[0, 1:2]), (1, 2, pt[1, 1:2])])
         st['prev_feat'].copy_(feat)
-        for v in range(2):
-            pair_s = torch.cat((st['prev_smotion'][v:v + 1], smotion[v:v + 1]), 0)
-            pair_t = torch.cat((torch.zeros_like(tmotion[v:v + 1]), tmotion[v:v + 1]), 0)
-            sm2, ts2 = ops.tsmotion(pair_s, pair_t, pipeline.LR_H, pipeline.LR_W)
-            st['smesh'][v].copy_(torch.cat((st['smesh'][v][1:], sm2[1:2]), 0))      # shift the ring by one frame
-            st['tsm'][v].copy_(torch.cat((st['tsm'][v][1:], ts2[1:2]), 0))
-        st['prev_smotion'].copy_(smotion)
-        outs, _ = self.smooth.run_windows(st['smesh'][0], st['smesh'][1], st['tsm'][0], st['tsm'][1], 1, WINDOW, 1, 1)
+        # tsmotion of both views as ONE batch of 4 frames (v0 prev, v0 new, v1 prev, v1 new): frame k pairs with frame k - 1,
+        # rows 1 and 3 are this pair's; row 2 (view 1's previous frame against view 0's new one) is computed and ignored
+        ops.tsmotion(ps.view(4, 7, 9, 2), pt.view(4, 7, 9, 2), pipeline.LR_H, pipeline.LR_W, out=(st['ts_out'][0], st['ts_out'][1]))
+        # shift the four rings by one frame, append this pair's rows, and make the current spatial motions the previous ones
+        ops.window_push(st['ring'], st['ts_out'], [1 * e, 3 * e, 5 * e, 7 * e], state=ps, blocks=2, block=e, stride=2 * e, delta=e)
+        r = st['ring'].view(4, WINDOW, 7, 9, 2)
+        outs, _ = self.smooth.run_windows(r[0], r[1], r[2], r[3], 1, WINDOW, 1, 1)
         m1, m2 = outs['smooth_mesh1'][0], outs['smooth_mesh2'][0]
-        st['out'].copy_(self._render(st['hr1'], st['hr2'], m1[-1:], m2[-1:]))
+        self._render(st['hr1'], st['hr2'], m1[-1:], m2[-1:], out=st['out'])
 
     def _versions(self):
         return (self.spatial.weights_version, self.temporal.weights_version, self.smooth.weights_version)
@@ -128,29 +142,20 @@ class OnlineStitcher:
             self._step_static()
         elif self.graph is None:
             # capture: the eager warm-up runs on a copy of the state so that this push is applied exactly once
-            keep = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in st.items()
-                    if k in ('prev_feat', 'prev_smotion', 'smesh', 'tsm')}
+            keep = {k: v.clone() for k, v in st.items() if k in self._STATE}
             side = _warmup_stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
                 self._step_static()
             torch.cuda.current_stream(self.dev).wait_stream(side)
             for k, v in keep.items():
-                if isinstance(v, list):
-                    for dst, src in zip(st[k], v):
-                        dst.copy_(src)
-                else:
-                    st[k].copy_(v)
+                st[k].copy_(v)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step_static()
             self.graph = g
             for k, v in keep.items():          # capture does not execute: state is still the pre-push state
-                if isinstance(v, list):
-                    for dst, src in zip(st[k], v):
-                        dst.copy_(src)
-                else:
-                    st[k].copy_(v)
+                st[k].copy_(v)
             self.graph.replay()
         else:
             self.graph.replay()

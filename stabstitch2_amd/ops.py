@@ -431,16 +431,37 @@ def rigid_winv(img_h, img_w, device):
     return ent.get(device)
 
 
-def tsmotion(smotion, tmotion, img_h=360, img_w=480):
-    """smotion, tmotion [n,7,9,2] -> (smesh, tsmotion) [n,7,9,2]."""
+def tsmotion(smotion, tmotion, img_h=360, img_w=480, out=None):
+    """smotion, tmotion [n,7,9,2] -> (smesh, tsmotion) [n,7,9,2] (out: the two preallocated result tensors)."""
     n = smotion.shape[0]
     ws = torch.empty(int(H.lib().ss_tsmotion_workspace_floats(n)), device=smotion.device, dtype=torch.float32)
-    smesh = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
-    tsm = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
+    if out is None:
+        smesh = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
+        tsm = torch.empty((n, 7, 9, 2), device=smotion.device, dtype=torch.float32)
+    else:
+        smesh, tsm = out
+        assert smesh.numel() == n * 126 and tsm.numel() == n * 126 and smesh.is_contiguous() and tsm.is_contiguous()
     winv = rigid_winv(img_h, img_w, smotion.device) if RIGID_INVERSE_CACHE else None
     H.call('ss_tsmotion', H.dptr(_f(smotion)), H.dptr(_f(tmotion)), H.dptr(smesh), H.dptr(tsm), n, float(img_h),
            float(img_w), H.dptr(winv, True, dtype=torch.float64), H.dptr(ws), H.stream())
     return smesh, tsm
+
+
+def window_push(ring, src, src_off, state=None, blocks=0, block=0, stride=0, delta=0):
+    """Streaming mode: ring [R,W,...] (contiguous, fixed address) drops slot 0 of every ring and appends the row at
+    src.flatten()[src_off[r]:][:E]; optionally moves `blocks` blocks of `block` floats inside `state` (block b at b * stride
+    <- the floats `delta` further) in the same launch (ss_window_push)."""
+    import ctypes
+    r, w = ring.shape[0], ring.shape[1]
+    e = ring[0, 0].numel()
+    assert ring.is_contiguous() and src.is_contiguous() and len(src_off) == r
+    assert all(0 <= o and o + e <= src.numel() for o in src_off)
+    if blocks:
+        assert state.is_contiguous() and (blocks - 1) * stride + delta + block <= state.numel()
+    offs = (ctypes.c_longlong * r)(*src_off)
+    H.call('ss_window_push', H.dptr(ring), H.dptr(src), ctypes.cast(offs, ctypes.c_void_p), r, w, e, H.dptr(state, True),
+           blocks, block, stride, delta, H.stream())
+    return ring
 
 
 # ------------------------------------------------------------------ render

@@ -79,10 +79,11 @@ class TemporalNet(L.PreparedMixin, nn.Module):
         return L.run_stage1(list(frames), self._prepared()['s1'])
 
     @torch.no_grad()
-    def motions_from_features(self, f_prev, f_cur):
-        """nhwc features of consecutive frames [n,45,60,128] x2 -> mesh motions [n,7,9,2]."""
-        off = L.run_regressor(ops.cost_volume(f_prev, f_cur, 3), self._prepared()['r2'])
-        return off.view(-1, grid_h + 1, grid_w + 1, 2)
+    def motions_from_features(self, f_prev, f_cur, out_slices=None):
+        """nhwc features of consecutive frames [n,45,60,128] x2 -> mesh motions [n,7,9,2]
+        (out_slices: [(row0, row1, dst [rows,126])] -- the regressor writes those rows there instead, returns None)."""
+        off = L.run_regressor(ops.cost_volume(f_prev, f_cur, 3), self._prepared()['r2'], out_slices=out_slices)
+        return None if out_slices is not None else off.view(-1, grid_h + 1, grid_w + 1, 2)
 
     def forward(self, img_tensor_list):
         dev = next(self.parameters()).device

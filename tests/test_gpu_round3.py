@@ -488,3 +488,25 @@ def test_cost_volume_both_directions_one_launch(dev):
         x2 = torch.randn(n, h, w, c, device=dev)
         both = ops.cost_volume_bidir(x1, x2, r)
         assert torch.equal(both[0], ops.cost_volume(x1, x2, r)) and torch.equal(both[1], ops.cost_volume(x2, x1, r)), (n, h, w, c, r)
+
+
+# ------------------------------------------------------------------ streaming mode's window shift
+def test_window_push_matches_torch(dev):
+    """ss_window_push: every ring drops its oldest slot and appends its row of `src`; the state move runs in the same launch."""
+    from stabstitch2_amd import ops
+    torch.manual_seed(3)
+    ring = torch.randn(4, 7, 126, device=dev)
+    src = torch.randn(2, 4, 126, device=dev)
+    state = torch.randn(2, 2, 126, device=dev)
+    want_ring = torch.cat((ring[:, 1:], torch.stack((src[0, 1], src[0, 3], src[1, 1], src[1, 3]), 0)[:, None]), 1)
+    want_state = state.clone()
+    want_state[:, 0] = state[:, 1]
+    ops.window_push(ring, src, [126, 3 * 126, 5 * 126, 7 * 126], state=state, blocks=2, block=126, stride=252, delta=126)
+    assert torch.equal(ring, want_ring) and torch.equal(state, want_state)
+    ring2 = torch.randn(3, 2, 5, device=dev)
+    keep = ring2.clone()
+    ops.window_push(ring2, src, [0, 5, 10])                     # no state move
+    assert torch.equal(ring2[:, 0], keep[:, 1]) and torch.equal(ring2[:, 1].flatten(), src.flatten()[:15])
+    from stabstitch2_amd._hip import HipError
+    with pytest.raises(HipError):
+        ops.window_push(torch.zeros(1, 300, 126, device=dev), src, [0])     # (window - 1) * elems > 2048
