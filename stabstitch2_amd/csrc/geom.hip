@@ -243,18 +243,21 @@ extern "C" int ss_homo_warp_nchw(const float* in, const float* theta, float* out
 #define TPS_TQ 17        // columns per thread: 4 x 17 = 66 system columns + 2 right-hand sides
 // One workgroup of 320 threads per system, the augmented 66x68 matrix lives in REGISTERS: thread (r, q) = (tid>>2,
 // tid&3) owns columns 17q..17q+16 of row r.  Gauss-Jordan with partial pivoting and no physical row swaps (a used-row
-// flag instead); per column: publish |A[r][col]| -> wave-0 arg-max -> pivot row broadcast through LDS -> every row
-// subtracts f * pivot_row with f fetched from its 4-lane row group by a shuffle.  All register indices are static
-// (steps unrolled per 17-column quarter); three barriers per step, 94 us per system vs 196 us LDS-resident.  src_stride = 0 shares one source mesh across the batch.
+// flag instead); per column: pivot = LDS atomic max over the unused rows' |A[r][col]| -> pivot row (and 1 / pivot) broadcast
+// through LDS -> every row subtracts f * pivot_row with f fetched from its 4-lane row group by a shuffle.  All register
+// indices are static (steps unrolled per 17-column quarter); two barriers per step (196 us LDS-resident -> 94 us with a
+// shuffle arg-max and three barriers -> see below).  src_stride = 0 shares one source mesh across the batch.
 __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
                                                         const float* __restrict__ target, long long tgt_stride,
                                                         float* __restrict__ T) {
     __shared__ float sx[SS_NV], sy[SS_NV];
-    __shared__ double colabs[SS_NT], prow[TPS_LD], diag[SS_NT];
-    __shared__ int s_piv;
+    __shared__ double prow[TPS_LD], diag[SS_NT];
+    __shared__ unsigned long long pkey[SS_NT];
+    __shared__ double s_pinv;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int r = tid >> 2, q = tid & 3;
     const bool rowok = r < SS_NT;
+    if (tid < SS_NT) pkey[tid] = 0ull;
     const float* src = source + (long long)b * src_stride;
     const float* tgt = target + (long long)b * tgt_stride;
     if (tid < SS_NV) { sx[tid] = src[tid * 2]; sy[tid] = src[tid * 2 + 1]; }
@@ -285,42 +288,34 @@ __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict_
     }
     bool used = false;
     int mycol = 0;
-    // (measured: letting every wave redo the arg-max to save the broadcast barrier, with all 66 steps unrolled into
-    //  one straight-line body, is 1.7x SLOWER -- instruction-cache bound; this form runs 94 us per system)
+    // Pivot search = ONE 64-bit LDS atomic max per unused row: the key is the magnitude's bit pattern (monotone for non-negative
+    // doubles) with its 7 lowest mantissa bits replaced by 127 - row, so the maximum carries its row and the lowest row wins
+    // among magnitudes equal to 2^-45 -- then every thread reads the winner.  Two barriers per column.  (The first version
+    // -- publish |a|, barrier, arg-max by 6 rounds of 64-bit shuffles in wave 0, barrier, broadcast -- spent a third of
+    // each step in those shuffles: 94 us per system; letting every wave redo that arg-max with all 66 steps unrolled into
+    // one straight-line body was 1.7x slower still, instruction-cache bound.)
     for (int qq = 0; qq < 4; ++qq) {         // rolled on purpose (see above); the 17 steps of a quarter are unrolled
 #pragma unroll
         for (int j = 0; j < TPS_TQ; ++j) {
             const int col = qq * TPS_TQ + j;
             if (col < SS_NT) {
-                if (rowok && q == qq) colabs[r] = used ? -1.0 : fabs(a[j]);
-                __syncthreads();
-                if (tid < 64) {     // arg-max over the unused rows (lowest row wins ties)
-                    double best = colabs[tid];
-                    int piv = tid;
-                    if (tid + 64 < SS_NT) {
-                        double v1 = colabs[tid + 64];
-                        if (v1 > best) { best = v1; piv = tid + 64; }
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        double ob = __shfl_xor(best, o, 64);
-                        int op = __shfl_xor(piv, o, 64);
-                        if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
-                    }
-                    if (tid == 0) s_piv = piv;
+                if (rowok && q == qq && !used) {
+                    const unsigned long long key = ((unsigned long long)__double_as_longlong(fabs(a[j])) & ~127ull) | (unsigned long long)(127 - r);
+                    atomicMax(&pkey[col], key);
                 }
+                // A[r][col] sits in lane (row group, qq); fetched before the barrier, it does not depend on the pivot
+                const double arc = __shfl(a[j], (tid & 60) | qq, 64);
                 __syncthreads();
-                const int piv = s_piv;
+                const int piv = 127 - (int)(pkey[col] & 127ull);
                 if (r == piv) {
 #pragma unroll
                     for (int jj = 0; jj < TPS_TQ; ++jj) prow[q * TPS_TQ + jj] = a[jj];
-                    if (q == qq) diag[r] = a[j];
+                    if (q == qq) { diag[r] = a[j]; s_pinv = 1.0 / a[j]; }
                     used = true;
                     mycol = col;
                 }
                 __syncthreads();
-                const double pinv = 1.0 / prow[col];
-                const double f = __shfl(a[j], (tid & 60) | qq, 64) * pinv;   // A[r][col] sits in lane (row group, qq)
+                const double f = arc * s_pinv;
                 if (rowok && r != piv) {
 #pragma unroll
                     for (int jj = 0; jj < TPS_TQ; ++jj) a[jj] -= f * prow[q * TPS_TQ + jj];
