@@ -243,21 +243,20 @@ extern "C" int ss_homo_warp_nchw(const float* in, const float* theta, float* out
 #define TPS_TQ 17        // columns per thread: 4 x 17 = 66 system columns + 2 right-hand sides
 // One workgroup of 320 threads per system, the augmented 66x68 matrix lives in REGISTERS: thread (r, q) = (tid>>2,
 // tid&3) owns columns 17q..17q+16 of row r.  Gauss-Jordan with partial pivoting and no physical row swaps (a used-row
-// flag instead); per column: pivot = LDS atomic max over the unused rows' |A[r][col]| -> pivot row (and 1 / pivot) broadcast
-// through LDS -> every row subtracts f * pivot_row with f fetched from its 4-lane row group by a shuffle.  All register
-// indices are static (steps unrolled per 17-column quarter); two barriers per step (196 us LDS-resident -> 94 us with a
-// shuffle arg-max and three barriers -> see below).  src_stride = 0 shares one source mesh across the batch.
+// flag instead); per column: pivot = the unused row with the largest |A[r][col]| (wave-level DPP reduction, see below) ->
+// pivot row (and 1 / pivot) broadcast through LDS -> every row subtracts f * pivot_row with f fetched from its 4-lane
+// row group by a shuffle.  All register indices are static (steps unrolled per 17-column quarter); two barriers per
+// step.  src_stride = 0 shares one source mesh across the batch.
 __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
                                                         const float* __restrict__ target, long long tgt_stride,
                                                         float* __restrict__ T) {
     __shared__ float sx[SS_NV], sy[SS_NV];
     __shared__ double prow[TPS_LD], diag[SS_NT];
-    __shared__ unsigned long long pkey[SS_NT];
+    __shared__ unsigned wkey[8];
     __shared__ double s_pinv;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int r = tid >> 2, q = tid & 3;
     const bool rowok = r < SS_NT;
-    if (tid < SS_NT) pkey[tid] = 0ull;
     const float* src = source + (long long)b * src_stride;
     const float* tgt = target + (long long)b * tgt_stride;
     if (tid < SS_NV) { sx[tid] = src[tid * 2]; sy[tid] = src[tid * 2 + 1]; }
@@ -288,25 +287,32 @@ __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict_
     }
     bool used = false;
     int mycol = 0;
-    // Pivot search = ONE 64-bit LDS atomic max per unused row: the key is the magnitude's bit pattern (monotone for non-negative
-    // doubles) with its 7 lowest mantissa bits replaced by 127 - row, so the maximum carries its row and the lowest row wins
-    // among magnitudes equal to 2^-45 -- then every thread reads the winner.  Two barriers per column.  (The first version
-    // -- publish |a|, barrier, arg-max by 6 rounds of 64-bit shuffles in wave 0, barrier, broadcast -- spent a third of
-    // each step in those shuffles: 94 us per system; letting every wave redo that arg-max with all 66 steps unrolled into
-    // one straight-line body was 1.7x slower still, instruction-cache bound.)
-    for (int qq = 0; qq < 4; ++qq) {         // rolled on purpose (see above); the 17 steps of a quarter are unrolled
+    // Pivot search without a barrier of its own (tools/micro/tps_solve_probe.hip has the step's anatomy): a 32-bit key = the
+    // magnitude as fp32 bits with its 7 lowest bits replaced by 127 - row (0 for used rows), so a maximum carries its row and
+    // the lowest row wins among magnitudes equal to 16 mantissa bits.  The candidates of a wave sit in lanes 4 i + qq: two
+    // DPP row rotations + four readlanes give the wave's maximum, one lane publishes it, and after the barrier every thread
+    // takes the largest of the five.  1360 clocks per column; the history: LDS-resident matrix 196 us per launch; registers +
+    // arg-max by 6 rounds of 64-bit shuffles in wave 0 between two extra barriers 94 us; one 64-bit LDS atomic max per row
+    // 85 us (66 lanes on one address: 1700 of a column's 2740 clocks); this form 42 us.  Publishing every wave's candidate
+    // row speculatively to save the second barrier was measured slower (1760 clocks per column).
+    for (int qq = 0; qq < 4; ++qq) {         // rolled on purpose (all 66 steps in one straight-line body: instruction-cache bound)
 #pragma unroll
         for (int j = 0; j < TPS_TQ; ++j) {
             const int col = qq * TPS_TQ + j;
             if (col < SS_NT) {
-                if (rowok && q == qq && !used) {
-                    const unsigned long long key = ((unsigned long long)__double_as_longlong(fabs(a[j])) & ~127ull) | (unsigned long long)(127 - r);
-                    atomicMax(&pkey[col], key);
+                unsigned key = 0u;
+                if (rowok && q == qq && !used) key = (__float_as_uint((float)fabs(a[j])) & ~127u) | (unsigned)(127 - r);
+                key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x124, 0xF, 0xF, false));   // row_ror:4
+                key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x128, 0xF, 0xF, false));   // row_ror:8
+                {
+                    const unsigned k0 = __builtin_amdgcn_readlane((int)key, qq), k1 = __builtin_amdgcn_readlane((int)key, 16 + qq);
+                    const unsigned k2 = __builtin_amdgcn_readlane((int)key, 32 + qq), k3 = __builtin_amdgcn_readlane((int)key, 48 + qq);
+                    if ((tid & 63) == 0) wkey[tid >> 6] = max(max(k0, k1), max(k2, k3));      // (everyone read the last column's keys before its second barrier)
                 }
                 // A[r][col] sits in lane (row group, qq); fetched before the barrier, it does not depend on the pivot
                 const double arc = __shfl(a[j], (tid & 60) | qq, 64);
                 __syncthreads();
-                const int piv = 127 - (int)(pkey[col] & 127ull);
+                const int piv = 127 - (int)(max(max(max(wkey[0], wkey[1]), max(wkey[2], wkey[3])), wkey[4]) & 127u);
                 if (r == piv) {
 #pragma unroll
                     for (int jj = 0; jj < TPS_TQ; ++jj) prow[q * TPS_TQ + jj] = a[jj];
