@@ -9,21 +9,38 @@
 
 // ------------------------------------------------------------------------------------------------
 // small dense helpers (fp64, one thread)
-__device__ void solve8(double A[8][9]) {   // in-place Gauss-Jordan with partial pivoting, solution in A[.][8]
+// Every loop is unrolled and the row exchange is a chain of predicated moves, so all indices are compile-time constants and the
+// 8 x 9 system stays in REGISTERS.  (With `A[piv][k]` indexed by a run-time row the array lived in scratch memory: one
+// thread's pair of solves took 25-38 us -- the whole spatial_decompose / spatial_meshes launch.)  Same operations on the same
+// values in the same order as the indexed form: bit-identical results.
+__device__ __forceinline__ void solve8(double (&A)[8][9]) {   // in-place Gauss-Jordan with partial pivoting, solution in A[.][8]
+#pragma unroll
     for (int c = 0; c < 8; ++c) {
         int piv = c;
         double best = fabs(A[c][c]);
+#pragma unroll
         for (int r = c + 1; r < 8; ++r) {
-            double v = fabs(A[r][c]);
+            const double v = fabs(A[r][c]);
             if (v > best) { best = v; piv = r; }
         }
-        if (piv != c)
-            for (int k = 0; k < 9; ++k) { double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
-        double inv = 1.0 / A[c][c];
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double x = A[c][k], y = A[r][k];
+                A[c][k] = sw ? y : x;
+                A[r][k] = sw ? x : y;
+            }
+        }
+        const double inv = 1.0 / A[c][c];
+#pragma unroll
         for (int k = c; k < 9; ++k) A[c][k] *= inv;
+#pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (r == c) continue;
-            double f = A[r][c];
+            const double f = A[r][c];
+#pragma unroll
             for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k];
         }
     }
@@ -82,7 +99,7 @@ __device__ void decompose(const float* off, float img_h, float img_w, float scal
     mul3(Hi, Ht, Hr);
 }
 
-__global__ void tensor_dlt_kernel(const float* __restrict__ src, const float* __restrict__ dst, float* __restrict__ H,
+__global__ __launch_bounds__(64) void tensor_dlt_kernel(const float* __restrict__ src, const float* __restrict__ dst, float* __restrict__ H,
                                   int n) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
@@ -102,7 +119,7 @@ extern "C" int ss_tensor_dlt(const float* src, const float* dst, float* H, int n
     return ss_launch_status();
 }
 
-__global__ void spatial_decompose_kernel(const float* __restrict__ off, float* __restrict__ th_ref,
+__global__ __launch_bounds__(64) void spatial_decompose_kernel(const float* __restrict__ off, float* __restrict__ th_ref,
                                          float* __restrict__ th_tgt, int n, float img_h, float img_w) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
@@ -134,7 +151,7 @@ __device__ __forceinline__ void rigid_vertex(int v, float img_h, float img_w, fl
 }
 
 // one block (64 threads) per batch item; thread v < 63 = vertex
-__global__ void spatial_meshes_kernel(const float* __restrict__ off, const float* __restrict__ off_ref,
+__global__ __launch_bounds__(64) void spatial_meshes_kernel(const float* __restrict__ off, const float* __restrict__ off_ref,
                                       const float* __restrict__ off_tgt, float* __restrict__ motion1,
                                       float* __restrict__ motion2, float img_h, float img_w) {
     __shared__ double sHr[9], sHt[9];

@@ -112,7 +112,7 @@ extern "C" int ss_stability_score(const float* path, float* out, int t, void* st
 
 // ---- distortion (test_metric_ssd.py:38-87, 473-482): mesh [T][7][9][2]; per frame inter + intra, max over frames.
 // inter_grid_loss on a [1,1,7,9,2] tensor reduces the edge products over dim 3 (vertex columns), see oracle/metrics.py.
-__global__ void distortion_kernel(const float* __restrict__ mesh, float* __restrict__ per_frame, int t) {
+__global__ __launch_bounds__(64) void distortion_kernel(const float* __restrict__ mesh, float* __restrict__ per_frame, int t) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= t) return;
     const float* m = mesh + (long long)f * SS_NV * 2;

@@ -293,9 +293,19 @@ __global__ __launch_bounds__(256) void render_order_kernel(float* __restrict__ f
     const int nbx = (nx - 1) / 2, nby = ny - 1, nt = nbx * nby;
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0u;
     __syncthreads();
-    for (int t = threadIdx.x; t < nt; t += 256) {
-        const unsigned m = tile_views(f, views, t / nbx, t % nbx, ny, nx, h, w, hc, wc);
-        atomicAdd(&cnt[3 - __popc(m)], 1u);
+    // counting sort by class with ONE LDS atomic per wave and class (ballot + popcount; a lane's rank inside its wave's share is
+    // the popcount of the lower lanes): 256 threads adding to four counters one by one serialised on the LDS (19 us per frame)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+        const int t = t0 + (int)threadIdx.x;
+        int c = -1;
+        if (t < nt) c = 3 - __popc(tile_views(f, views, t / nbx, t % nbx, ny, nx, h, w, hc, wc));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long b = __ballot(c == k);
+            if (lane == 0 && b) atomicAdd(&cnt[k], (unsigned)__popcll(b));
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -303,11 +313,22 @@ __global__ __launch_bounds__(256) void render_order_kernel(float* __restrict__ f
         for (int c = 0; c < 4; ++c) { base[c] = a; a += cnt[c]; cnt[c] = 0u; }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < nt; t += 256) {
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+        const int t = t0 + (int)threadIdx.x;
         const int by = t / nbx, bx = t - by * nbx;
-        const unsigned m = tile_views(f, views, by, bx, ny, nx, h, w, hc, wc);
-        const int c = 3 - __popc(m);
-        order[base[c] + atomicAdd(&cnt[c], 1u)] = (unsigned)bx | ((unsigned)by << 12) | (m << 24);
+        unsigned m = 0u;
+        int c = -1;
+        if (t < nt) { m = tile_views(f, views, by, bx, ny, nx, h, w, hc, wc); c = 3 - __popc(m); }
+        unsigned slot = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long b = __ballot(c == k);
+            unsigned wb = 0u;
+            if (lane == 0 && b) wb = atomicAdd(&cnt[k], (unsigned)__popcll(b));
+            wb = (unsigned)__shfl((int)wb, 0, 64);
+            if (c == k) slot = base[k] + wb + (unsigned)__popcll(b & below);
+        }
+        if (t < nt) order[slot] = (unsigned)bx | ((unsigned)by << 12) | (m << 24);
     }
 }
 
