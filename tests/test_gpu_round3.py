@@ -510,3 +510,30 @@ def test_window_push_matches_torch(dev):
     from stabstitch2_amd._hip import HipError
     with pytest.raises(HipError):
         ops.window_push(torch.zeros(1, 300, 126, device=dev), src, [0])     # (window - 1) * elems > 2048
+
+
+# ------------------------------------------------------------------ odd geometry against the oracle
+@pytest.mark.parametrize('warp_mode,fusion_mode', [('NORMAL', 'AVERAGE'), ('FAST', 'LINEAR')])
+def test_two_view_odd_geometry_vs_oracle(dev, hip_nets, warp_mode, fusion_mode):
+    """A clip whose sizes are multiples of nothing: 9 frames (one frame behind a full chunk of 8 would be 9 too), HR 251 x 377
+    (render tiles of 64 x 8 and the footprint lattice end in partial tiles, the cv2-exact LR resize has non-integer ratios in both
+    axes) -- HIP path against the CPU oracle: meshes, canvas, every frame; the uint8 route against the fp32 one."""
+    import oracle.pipeline as OP
+    from test_gpu_parity import _oracle_nets
+    from stabstitch2_amd import pipeline, ops
+    n, h, w = 9, 251, 377
+    u8 = _u8_clip(n, h, w, 11, dev)
+    hr = [ops.ingest_u8(t)[0] for t in u8]
+    lr = [ops.ingest_u8(t)[1] for t in u8]
+    fr, hc, wc, m1, m2 = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets, warp_mode, fusion_mode)
+    sl = lambda t: [t[i:i + 1].cpu() for i in range(n)]
+    ofr, ohc, owc, om1, om2 = OP.run_two_view(sl(hr[0]), sl(hr[1]), sl(lr[0]), sl(lr[1]), _oracle_nets(), warp_mode, fusion_mode)
+    close(m1, om1, 5e-3, 'odd geometry smooth_mesh1 vs oracle')
+    close(m2, om2, 5e-3, 'odd geometry smooth_mesh2 vs oracle')
+    assert (hc, wc) == (ohc, owc)
+    for i in range(n):
+        d = np.abs(fr[i].permute(1, 2, 0).cpu().numpy() - ofr[i])
+        assert np.median(d) < 5e-3 and np.quantile(d, 0.999) < 0.25, (i, float(np.median(d)), float(np.quantile(d, 0.999)))
+    video, vhc, vwc, v1, v2 = pipeline.run_two_view_u8(u8[0], u8[1], hip_nets, warp_mode, fusion_mode, device=dev)
+    assert (vhc, vwc) == (hc, wc) and torch.equal(v1, m1) and torch.equal(v2, m2)
+    assert torch.equal(video, ops.canvas_to_u8(fr))
