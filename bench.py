@@ -92,6 +92,8 @@ class ConvProbe:
             def timed(x, wgt, *a, **k):
                 if not probe.active:
                     return orig(x, wgt, *a, **k)
+                if k.get('pool2') and not ops.pool2_is_fused(x, wgt, k.get('stride', 1), k.get('pad', (0, 1, 1))):
+                    return orig(x, wgt, *a, **k)      # two launches: the inner conv and the pool are probed on their own
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -99,6 +101,9 @@ class ConvProbe:
                 e1.record()
                 cout, kt, kh, kw, cin = wgt.shape[-5:]
                 m = out.numel() // out.shape[-1]              # rows (of all groups together)
+                if k.get('pool2'):                            # conv + 2x2 max-pool in one kernel: the conv's rows, not the pooled map's
+                    groups = wgt.shape[0] if wgt.dim() == 6 else 1
+                    m = groups * x.shape[-4] * x.shape[-3] * x.shape[-2]        # 3x3 / stride 1 / pad 1: one output row per input pixel
                 res = k.get('res')
                 nbytes = 4 * (x.numel() + wgt.numel() + out.numel() + (res.numel() if res is not None else 0))
                 stride = k.get('stride', 1)

@@ -116,6 +116,14 @@ SS_API int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const floa
                                 int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
                                 long long in_gs, long long u_gs, long long out_gs, void* stream);
 
+/* The same convolution followed by the regressors' MaxPool2d(2, 2) (spatial_network.py / temporal_network.py: conv3x3, ReLU,
+ * conv3x3, ReLU, MaxPool2d) in ONE kernel: an F(2x2,3x3) output tile is a pooling window, the epilogue takes the maximum of its
+ * four pixels before bias and ReLU (both monotone: bit-identical to ss_conv3x3_wino_nhwc + ss_maxpool_nhwc), the un-pooled map
+ * is never written.  out [groups][n][h/2][w/2][out_cs] (floor, like MaxPool2d); out_gs = its group stride; no residual. */
+SS_API int ss_conv3x3_wino_pool2_nhwc(const float* in, const float* packed, const float* bias, float* out, int n, int h, int w,
+                               int cin, int cout, int relu, int out_cs, int groups, long long in_gs, long long u_gs,
+                               long long out_gs, void* stream);
+
 /* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */
 SS_API int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
                     void* stream);

@@ -206,9 +206,27 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     // this thread's output items: (pixel, channel quad); BN / 4 quads per pixel -> 128 * BN / 4 / 256 = 4 NB items
     constexpr int QP = BN / 4, NI = 4 * NB, PSTEP = 256 / QP;
     const int cq = tid % QP;
+    // POOL (VAR = 8; no residual): the 2 x 2 / 2 max-pool that follows the convolution in the regressors (spatial_network.py:
+    // conv, ReLU, conv, ReLU, MaxPool2d(2, 2)) taken inside the epilogue -- an F(2x2, 3x3) output tile IS a pooling window.
+    // max over the four pixels first, then bias and ReLU (both monotone: bit-identical to pooling the stored map); the
+    // un-pooled map is never written.  A thread owns 2 x (tile, 4 couts) instead of 8 x (pixel, 4 couts).
+    constexpr bool POOL = STREAM && !RES && VAR == 8;
+    constexpr int NIP = 32 * QP / 256;                      // pooled items per thread
     unsigned goff[NI];
     w_u32x4 rv[NI];
     auto res_issue = [&]() {
+        if constexpr (POOL) {
+            const int hp = p.H >> 1, wp = p.W >> 1;         // MaxPool2d(2, 2): floor
+#pragma unroll
+            for (int e = 0; e < NIP; ++e) {
+                const int tile = e * PSTEP + tid / QP;
+                const int ty = tile / TBW, tx = tile - ty * TBW;
+                const int oyp = (oy0 >> 1) + ty, oxp = (ox0 >> 1) + tx;
+                const bool ok = oyp < hp && oxp < wp;
+                goff[e] = ok ? ((((unsigned)img * hp + oyp) * wp + oxp) * (unsigned)p.out_cs + cbk * BN + 4u * cq) * 4u : 0xFFFFFFFFu;
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < NI; ++e) {
             const int px = e * PSTEP + tid / QP;
@@ -686,6 +704,36 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv_wino_kernel(WinoP p
     }
     __syncthreads();
     W_STAMP(7);
+    if constexpr (POOL) {
+#pragma unroll
+        for (int e = 0; e < NIP; ++e) {
+            const int tile = e * PSTEP + tid / QP;
+            w_f32x4 x[4], y[4], z[4];
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {                // pixel (a, b) of the tile: 12 LDS reads in flight
+                const float* s0 = smem + (ab * 32 + tile) * BN + 4 * cq;
+                x[ab] = *reinterpret_cast<const w_f32x4*>(s0);
+                y[ab] = *reinterpret_cast<const w_f32x4*>(s0 + 2 * 32 * BN);
+                z[ab] = *reinterpret_cast<const w_f32x4*>(s0 + 4 * 32 * BN);
+            }
+            w_f32x4 m;
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                const float sg = (ab >> 1) ? -1.f : 1.f;
+                const w_f32x4 sg4 = {sg, sg, sg, sg};
+                const w_f32x4 v = __builtin_elementwise_fma(sg4, z[ab], __builtin_elementwise_fma(sg4, y[ab], x[ab]));
+                if (ab == 0) m = v;
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+                }
+            }
+            m = m + bias4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], relu_lo);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w_u32x4, m), rout, goff[e], 0, 0);
+        }
+    } else
     // four pixels at a time: 12 LDS reads in flight, then the adds and stores
 #pragma unroll
     for (int e0 = 0; e0 < NI; e0 += 4) {
@@ -1252,11 +1300,12 @@ extern "C" int ss_conv_uses_winograd(int kt, int kh, int kw, int stride, int cin
 
 static int wino_launch(const float* in, const float* packed, const float* bias, const float* res, float* out,
                        int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
-                       long long in_gs, long long u_gs, long long out_gs, void* stream, bool sliced) {
+                       long long in_gs, long long u_gs, long long out_gs, void* stream, bool sliced, bool pool = false) {
     if (!in || !packed || !out || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || (cin & 3) || cout <= 0 || (cout & 63) ||
-        groups <= 0 || out_cs < cout)
+        groups <= 0 || out_cs < cout || (pool && (res || sliced || h < 2 || w < 2)))
         return SS_ERR_ARG;
-    const long long in_elems = (long long)n * h * w * cin, out_elems = (long long)n * h * w * out_cs;
+    const long long in_elems = (long long)n * h * w * cin;
+    const long long out_elems = pool ? (long long)n * (h / 2) * (w / 2) * out_cs : (long long)n * h * w * out_cs;
     const long long u_floats = sliced ? ss_wino_packed3_floats(cout, cin) : ss_wino_packed_floats(cout, cin);
     if (in_elems * 4 >= (1ll << 32) || out_elems * 4 >= (1ll << 32) || u_floats * 4 >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
     WinoP p;
@@ -1288,7 +1337,7 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
     hipStream_t st = (hipStream_t)stream;
 #ifdef SS_TUNING
     // pair kernel (one persistent workgroup per CU, two tile blocks per job): needs >= 2 chunks for its prefetch distance
-    if (!sliced && g_wino_variant == 2 && nb == 2 && p.nchunk >= 2 && p.nchunk <= 512 && in_elems * 4 <= 0xFFFF0000ll) {
+    if (!sliced && !pool && g_wino_variant == 2 && nb == 2 && p.nchunk >= 2 && p.nchunk <= 512 && in_elems * 4 <= 0xFFFF0000ll) {
         p.nmb = (unsigned)((long long)n * p.nbx * p.nby);
         p.njobs = (unsigned)(((long long)p.nmb + 1) / 2 * p.ncb);
         long long cap = (long long)(256 / groups) & ~7ll;
@@ -1305,6 +1354,11 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
     }
 #endif
     dim3 g((unsigned)wgs, 1, groups);
+    if (pool) {             // conv + bias + ReLU + MaxPool2d(2, 2) in one kernel (VAR = 8)
+        if (tbh == 8) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, false, true, false, 8>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true, false, 8>), g, dim3(256), 0, st, p);
+        return ss_launch_status();
+    }
     if (sliced) {           // fp32 products from three bf16 slices per operand on the bf16 matrix pipe (opt-in entry point)
         if (tbh == 8) {
             if (res) hipLaunchKernelGGL((conv_wino_kernel<8, 4, 2, true, false, true>), g, dim3(256), 0, st, p);
@@ -1400,6 +1454,13 @@ static int wino_launch(const float* in, const float* packed, const float* bias, 
         else hipLaunchKernelGGL((conv_wino_kernel<4, 8, 2, false, true>), g, dim3(256), dyn, st, p);
     }
     return ss_launch_status();
+}
+
+extern "C" int ss_conv3x3_wino_pool2_nhwc(const float* in, const float* packed, const float* bias, float* out, int n, int h, int w,
+                                          int cin, int cout, int relu, int out_cs, int groups, long long in_gs, long long u_gs,
+                                          long long out_gs, void* stream) {
+    return wino_launch(in, packed, bias, nullptr, out, n, h, w, cin, cout, relu, out_cs, groups, in_gs, u_gs, out_gs, stream, false,
+                       true);
 }
 
 extern "C" int ss_conv3x3_wino_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,

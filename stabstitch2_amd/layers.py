@@ -263,10 +263,8 @@ def run_regressor(x, p, chunk=None, out=None, out_slices=None, row0=0):
             e = min(s + chunk, x.shape[0])
             run_regressor(x[s:e], p, chunk, None if out is None else out[s:e], out_slices, row0 + s)
         return out
-    for i, w in enumerate(p['convs']):
-        x = ops.conv(x, w, None, stride=1, pad=(0, 1, 1), relu=True)
-        if i & 1:
-            x = ops.maxpool(x, 2, 2, 0)
+    for i, w in enumerate(p['convs']):          # conv, ReLU, conv, ReLU, MaxPool2d(2, 2): the pool rides in the second conv's kernel
+        x = ops.conv(x, w, None, stride=1, pad=(0, 1, 1), relu=True, pool2=bool(i & 1))
     return _fc_tail(x.reshape(x.shape[0], -1), p['fc'], out, out_slices, row0)
 
 
@@ -289,10 +287,7 @@ def run_regressor_pair(x, pp, chunk=None, outs=None):
             run_regressor_pair(x[:, s:e].contiguous(), pp, chunk, [o[s:e] for o in outs])
         return outs
     for i, w in enumerate(pp['convs']):
-        x = ops.conv_grouped(x, w, None, None, stride=1, pad=(0, 1, 1), relu=True)
-        if i & 1:
-            x = ops.maxpool(x.view(g * n, *x.shape[2:]), 2, 2, 0)
-            x = x.view(g, n, *x.shape[1:])
+        x = ops.conv_grouped(x, w, None, None, stride=1, pad=(0, 1, 1), relu=True, pool2=bool(i & 1))
     return [_fc_tail(x[k].reshape(n, -1), pp['fc'][k], None if outs is None else outs[k]) for k in range(g)]
 
 

@@ -194,29 +194,59 @@ def wino_packed(wgt, groups, sliced=False):
     return ent.get(wgt.device)
 
 
-def conv_winograd(x, wgt, bias=None, res=None, relu=False, out=None):
+POOL_FUSED = os.environ.get('SS_POOL_FUSED', '1') == '1'      # the regressors' 2x2 max-pool inside the Winograd epilogue
+
+
+def conv_winograd(x, wgt, bias=None, res=None, relu=False, out=None, pool2=False):
     """3x3 / stride 1 / pad 1 convolution on the fused Winograd F(2x2,3x3) kernel, unconditionally (ops.conv applies the
-    library's dispatch rule).  x nhwc [n,h,w,c] (or [g,n,h,w,c] with wgt [g,cout,1,3,3,c]: grouped launch)."""
+    library's dispatch rule).  x nhwc [n,h,w,c] (or [g,n,h,w,c] with wgt [g,cout,1,3,3,c]: grouped launch).
+    pool2: followed by MaxPool2d(2, 2) in the same kernel -> [.., h // 2, w // 2, cout] (no residual; fp32 MFMA arithmetic only)."""
     grouped = wgt.dim() == 6
     g = wgt.shape[0] if grouped else 1
     cout, cin = wgt.shape[-5], wgt.shape[-1]
     assert tuple(wgt.shape[-4:-1]) == (1, 3, 3) and x.shape[-1] == cin, (wgt.shape, x.shape)
     shared = grouped and x.dim() == 4
     n, h, w = x.shape[-4], x.shape[-3], x.shape[-2]
-    if out is None:
-        out = torch.empty(((g, n, h, w, cout) if grouped else (n, h, w, cout)), device=x.device, dtype=torch.float32)
     sliced = WINO_MATH == 'bf16x9'
-    pk = wino_packed(wgt, g, sliced)
     global last_conv_path
     last_conv_path = 'wino'
+    in_gs = 0 if (shared or not grouped) else x[0].numel()
+    if pool2:
+        assert res is None and not sliced
+        if out is None:
+            out = torch.empty(((g, n, h // 2, w // 2, cout) if grouped else (n, h // 2, w // 2, cout)), device=x.device,
+                              dtype=torch.float32)
+        pk = wino_packed(wgt, g, False)
+        H.call('ss_conv3x3_wino_pool2_nhwc', H.dptr(x), H.dptr(pk), H.dptr(bias, True), H.dptr(out), n, h, w, cin, cout,
+               int(relu), out.shape[-1], g, in_gs, pk.shape[1], out[0].numel() if grouped else 0, H.stream())
+        return out
+    if out is None:
+        out = torch.empty(((g, n, h, w, cout) if grouped else (n, h, w, cout)), device=x.device, dtype=torch.float32)
+    pk = wino_packed(wgt, g, sliced)
     H.call('ss_conv3x3_wino3_nhwc' if sliced else 'ss_conv3x3_wino_nhwc', H.dptr(x), H.dptr(pk), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
-           n, h, w, cin, cout, int(relu), out.shape[-1], g, 0 if (shared or not grouped) else x[0].numel(),
+           n, h, w, cin, cout, int(relu), out.shape[-1], g, in_gs,
            pk.shape[1], out[0].numel() if grouped else 0, H.stream())
     return out
 
 
-def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=None):
-    """x nhwc [n,h,w,c] or [n,t,h,w,c]; wgt [cout,kt,kh,kw,cin] (cin == x channels)."""
+def pool2_is_fused(x, wgt, stride=1, pad=(0, 1, 1)):
+    """Does ops.conv / ops.conv_grouped (pool2=True) run convolution + MaxPool2d(2, 2) as ONE kernel for these operands?
+    (Where the Winograd kernel is dispatched; elsewhere the two are separate launches.)"""
+    cout, kt, kh, kw, cin = wgt.shape[-5:]
+    groups = wgt.shape[0] if wgt.dim() == 6 else 1
+    n, h, w = x.shape[-4], x.shape[-3], x.shape[-2]
+    return bool(POOL_FUSED and WINO_MATH != 'bf16x9' and _uses_winograd(kt, kh, kw, stride, pad, cin, cout, h, w, n * groups))
+
+
+def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=None, pool2=False):
+    """x nhwc [n,h,w,c] or [n,t,h,w,c]; wgt [cout,kt,kh,kw,cin] (cin == x channels).
+    pool2: the convolution is followed by MaxPool2d(2, 2) -- inside the Winograd kernel where that kernel runs, else as a
+    second launch."""
+    if pool2:
+        assert x.dim() == 4 and out is None and res is None
+        if pool2_is_fused(x, wgt, stride, pad):
+            return conv_winograd(x, wgt, bias, None, relu, None, pool2=True)
+        return maxpool(conv(x, wgt, bias, None, stride, pad, relu), 2, 2, 0)
     five = x.dim() == 5
     if five:
         n, t, h, w, c = x.shape
@@ -243,7 +273,7 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     return out
 
 
-def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False):
+def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, pool2=False):
     """G independent convolutions of identical geometry in ONE launch: x [G,n,h,w,c], wgt [G,cout,kt,kh,kw,cin],
     bias [G,cout] | None, res [G,n,ho,wo,cout] | None -> [G,n,ho,wo,cout]; a 4-D x [n,h,w,c] is shared by all groups.  Used where the reference runs twin
     sub-networks (regressNet2 ref/tgt, the SpatialNet and TemporalNet trunks in streaming mode)."""
@@ -258,6 +288,12 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
     pt, ph, pw = pad
     ho = (h + 2 * ph - kh) // stride + 1
     wo = (w + 2 * pw - kw) // stride + 1
+    if pool2:      # conv + MaxPool2d(2, 2): one kernel on the Winograd path, two launches otherwise -> [g,n,ho//2,wo//2,cout]
+        assert res is None
+        if pool2_is_fused(x, wgt, stride, pad):
+            return conv_winograd(x, wgt, bias, None, relu, None, pool2=True)
+        y = conv_grouped(x, wgt, bias, None, stride, pad, relu)
+        return maxpool(y.view(g * n, ho, wo, cout), 2, 2, 0).view(g, n, ho // 2, wo // 2, cout)
     out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
     if _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n * g):
         return conv_winograd(x, wgt, bias, res, relu, out)

@@ -537,3 +537,32 @@ def test_two_view_odd_geometry_vs_oracle(dev, hip_nets, warp_mode, fusion_mode):
     video, vhc, vwc, v1, v2 = pipeline.run_two_view_u8(u8[0], u8[1], hip_nets, warp_mode, fusion_mode, device=dev)
     assert (vhc, vwc) == (hc, wc) and torch.equal(v1, m1) and torch.equal(v2, m2)
     assert torch.equal(video, ops.canvas_to_u8(fr))
+
+
+# ------------------------------------------------------------------ conv + ReLU + MaxPool2d(2, 2) in the Winograd epilogue
+@pytest.mark.parametrize('n,h,w,cin,cout,g', [(3, 45, 60, 64, 64, 1), (62, 11, 15, 128, 128, 1), (4, 90, 120, 64, 64, 1),
+                                              (5, 23, 31, 64, 128, 1), (32, 45, 60, 64, 64, 2), (40, 22, 30, 128, 128, 1)])
+def test_conv_pool2_fused(dev, n, h, w, cin, cout, g):
+    """ss_conv3x3_wino_pool2_nhwc against ss_conv3x3_wino_nhwc + ss_maxpool_nhwc: bit-identical (max before bias / ReLU, both
+    monotone), odd map sizes (MaxPool2d floors), grouped launches; and against torch (fp32 reference of the same op)."""
+    import torch.nn.functional as F
+    from stabstitch2_amd import ops
+    torch.manual_seed(4)
+    x = torch.randn((g, n, h, w, cin) if g > 1 else (n, h, w, cin), device=dev)
+    wt = torch.randn((g, cout, 1, 3, 3, cin) if g > 1 else (cout, 1, 3, 3, cin), device=dev) * 0.05
+    bias = torch.randn((g, cout) if g > 1 else (cout,), device=dev)
+    for relu in (True, False):
+        fused = ops.conv_winograd(x, wt, bias, None, relu, None, pool2=True)
+        full = ops.conv_winograd(x, wt, bias, None, relu)
+        two = ops.maxpool(full.view(-1, h, w, cout), 2, 2, 0).view(fused.shape)
+        assert fused.shape[-3:] == (h // 2, w // 2, cout)
+        assert torch.equal(fused, two), float((fused - two).abs().max())
+    xs, ws, bs = (x, wt, bias) if g == 1 else (x[1], wt[1], bias[1])
+    ref = F.max_pool2d(F.relu(F.conv2d(xs.permute(0, 3, 1, 2), ws[:, 0].permute(0, 3, 1, 2), bs, padding=1)), 2, 2)
+    got = ops.conv_winograd(x, wt, bias, None, True, None, pool2=True)
+    got = got if g == 1 else got[1]
+    close(got, ref.permute(0, 2, 3, 1), 2e-5 * float(ref.abs().max()) + 1e-5, 'fused conv + pool vs torch')
+    # the dispatching wrappers take the same route as conv + maxpool wherever the Winograd kernel is not chosen
+    a = ops.conv(xs, ws, bs, relu=True, pool2=True)
+    b = ops.maxpool(ops.conv(xs, ws, bs, relu=True), 2, 2, 0)
+    assert torch.equal(a, b)
