@@ -37,7 +37,7 @@ def test_cabi_exports_exactly_the_declared_symbols(built_lib):
     assert 'getenv' not in nm                                   # no environment overrides inside the product library
     und = subprocess.run(['nm', '-D', '--undefined-only', _hip.LIB_PATH], capture_output=True, text=True).stdout
     assert 'getenv' not in und
-    assert built_lib.ss_version() >= 200
+    assert built_lib.ss_version() >= 300
     assert built_lib.ss_error_string(-1) == b'bad argument'
     # argument validation happens before any device work, so it can be exercised without a GPU
     assert built_lib.ss_conv_nhwc(None, None, None, None, None, *([1] * 15), 1, 0, 0, 0, None, 0, None) == -1
