@@ -27,10 +27,16 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
     constexpr int WPIX = WH * WW;
     constexpr int NV = 4 + 2 * R;                       // x2 values per thread per channel (14 / 10)
     constexpr int OUTF = CV_TY * CV_TX * (D + 3);       // staging for the epilogue
-    constexpr int X2F = CV_CC * WPIX;
+    // Channel planes in groups of four (one staged item = the 4 channels of a pixel, written by one lane in four instructions):
+    // the plane pitches (392 / 240 / 64 floats) are multiples of 8, so the four lanes that hold the four channel quads of one
+    // pixel would hit ONE bank in every staging write (rocprofv3: 59 % of the kernel's LDS cycles were bank-conflict stalls, the
+    // LDS busy 63 % of the time).  Eight floats of skew per quad put them 8 banks apart: a half-wave's 8 pixels x 4 quads cover
+    // the 32 banks once.  (Multiples of 4: the 16-byte reads stay aligned.)
+    constexpr int QP2 = 4 * WPIX + 8, QP1 = 4 * CV_TY * CV_TX + 8;         // quad pitches of the x2 window / the x1 tile
+    constexpr int X2F = (CV_CC / 4) * QP2;
     constexpr int LDSF = (X2F > OUTF ? X2F : OUTF);
     __shared__ __attribute__((aligned(16))) float s2[LDSF];
-    __shared__ __attribute__((aligned(16))) float s1[CV_CC][CV_TY * CV_TX];
+    __shared__ __attribute__((aligned(16))) float s1f[(CV_CC / 4) * QP1];
 
     const int tid = threadIdx.x;
     // blockIdx.z < n_fwd: cv(x1, x2) of image z; >= n_fwd: the OTHER direction cv(x2, x1) of image z - n_fwd, written behind the
@@ -46,6 +52,10 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
     const bool active = tid < 16 * KD;
     const int pg = tid & 15, j = active ? tid >> 4 : 0;   // pixel group (py, 4g) and displacement row
     const int py = pg >> 2, g4 = (pg & 3) * 4;
+    // (Eight lanes of a 16-byte read = the four g4 of two ADJACENT window rows, one row pitch apart: 3 of the 4 chunks of the
+    // second row share banks with the first.  A lane map that pairs rows half a bank cycle apart instead -- 4 rows at R = 5,
+    // 2 at R = 3 -- removes those conflicts but needs 256 threads with 80 idle lanes at R = 5: measured 181-190 us against
+    // 166-168 for both directions of 32 pairs, equal at R = 3.  Not adopted.)
     const float* x1n = x1 + (long long)n * h * w * c;
     const float* x2n = x2 + (long long)n * h * w * c;
 
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
         const int yy = y0 - R + wy, xx = x0 - R + wx;
         const bool in = e < WH * (CV_TX + 2 * R) * (CV_CC / 4);
         o2[k] = (in && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? (yy * w + xx) * c + q * 4 : -1;
-        l2[k] = in ? (q * 4) * WPIX + wy * WW + wx : -1;
+        l2[k] = in ? q * QP2 + wy * WW + wx : -1;
     }
 #pragma unroll
     for (int k = 0; k < N1; ++k) {
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
         const int yy = y0 + (pp >> 4), xx = x0 + (pp & 15);
         const bool in = e < CV_TY * CV_TX * (CV_CC / 4);
         o1[k] = (in && yy < h && xx < w) ? (yy * w + xx) * c + q * 4 : -1;
-        l1[k] = in ? (q * 4) * (CV_TY * CV_TX) + pp : -1;
+        l1[k] = in ? q * QP1 + pp : -1;
     }
     float4 r2[N2], r1[N1];
     auto fetch = [&](int c0) {
@@ -98,7 +108,6 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
             if (o1[k] >= 0 && cok) r1[k] = *reinterpret_cast<const float4*>(x1n + o1[k] + c0);
         }
     };
-    float* s1f = &s1[0][0];
     fetch(0);
     for (int c0 = 0; c0 < c; c0 += CV_CC) {
         // registers -> LDS, channel-major
@@ -118,9 +127,9 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
         if (active) {
 #pragma unroll 2
             for (int cc = 0; cc < CV_CC; ++cc) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&s1[cc][py * 16 + g4]);
+                const float4 a4 = *reinterpret_cast<const float4*>(&s1f[(cc >> 2) * QP1 + (cc & 3) * (CV_TY * CV_TX) + py * 16 + g4]);
                 const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-                const float* row = s2 + cc * WPIX + (py + j) * WW + g4;
+                const float* row = s2 + (cc >> 2) * QP2 + (cc & 3) * WPIX + (py + j) * WW + g4;
                 float v[NV];
 #pragma unroll
                 for (int q = 0; q < NV / 4; ++q) {

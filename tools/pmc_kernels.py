@@ -28,5 +28,10 @@ for p in pats:
         o['mfma_util'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (c['GRBM_GUI_ACTIVE'] / 8), 4)
     if 'SQ_INSTS_VALU' in c and 'SQ_INSTS_MFMA' in c and c['SQ_INSTS_MFMA']:
         o['non_mfma_valu_per_mfma'] = round((c['SQ_INSTS_VALU'] - c['SQ_INSTS_MFMA']) / c['SQ_INSTS_MFMA'], 2)
+    if c.get('SQ_LDS_IDX_ACTIVE'):
+        # cycles the LDS is stalled by bank conflicts per cycle it is busy with indexed accesses
+        o['lds_bank_conflict_frac'] = round(c.get('SQ_LDS_BANK_CONFLICT', 0.0) / c['SQ_LDS_IDX_ACTIVE'], 4)
+        if 'GRBM_GUI_ACTIVE' in c:
+            o['lds_busy_frac'] = round(c['SQ_LDS_IDX_ACTIVE'] / 256 / (c['GRBM_GUI_ACTIVE'] / 8), 4)      # per CU, of the kernel's cycles
     out[p] = o
 print(json.dumps(out, indent=1))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile passes of one round on the GPU box (run through gpurun from the repo root):
 #   bash tools/profile_round.sh r03      -> gpurun_out/<tag>_kernel_stats.txt, <tag>_bench_unprofiled.json, <tag>_bench_profiled.json,
-#                                           <tag>_pmc_hbm.json, <tag>_pmc_mfma.json
+#                                           <tag>_pmc_hbm.json, <tag>_pmc_mfma.json, <tag>_pmc_lds.json
 # The kernel trace is taken with the DRIVER'S OWN command (bench.py --steps 20 --warmup 5; CPU baseline / other configs off so that
 # only headline steps are in the trace), and the same command is run un-profiled right before it: the two JSON lines give the
 # per-kernel HIP-event averages with and without the profiler attached (profiled passes clock lower; never mix the arms).
@@ -15,7 +15,7 @@ ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"
 CMD="python $R/bench.py $ARGS"
 PSTEPS=5            # steps of the PMC passes (warm-up 2 + 3 timed): counters are summed per kernel over all of them
 PCMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs"
-rm -rf /tmp/prof_$TAG /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG /tmp/pmc_m_$TAG /tmp/pmc_v_$TAG
+rm -rf /tmp/prof_$TAG /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG /tmp/pmc_m_$TAG /tmp/pmc_v_$TAG /tmp/pmc_l_$TAG
 $CMD > $OUT/${TAG}_bench_unprofiled.json 2> $OUT/${TAG}_bench_unprofiled.err
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- $CMD > $OUT/${TAG}_bench_profiled.json 2> $OUT/${TAG}_prof.log
 DB=$(find /tmp/prof_$TAG -name "*_results.db" | head -1)
@@ -26,4 +26,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$TAG
 python $R/tools/pmc_summary.py /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG $PSTEPS > $OUT/${TAG}_pmc_hbm.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_m_$TAG -- $PCMD > $OUT/${TAG}_pmc_m.log 2>&1
 python $R/tools/pmc_kernels.py /tmp/pmc_m_$TAG conv_wino conv_igemm stem_pool_kernel render_average cost_volume maxpool homo_warp > $OUT/${TAG}_pmc_mfma.json
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_l_$TAG -- $PCMD > $OUT/${TAG}_pmc_l.log 2>&1
+python $R/tools/pmc_kernels.py /tmp/pmc_l_$TAG conv_wino conv_igemm stem_pool_kernel render_average cost_volume ccl_softmax > $OUT/${TAG}_pmc_lds.json
 ls -la $OUT/${TAG}_*
