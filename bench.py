@@ -56,6 +56,28 @@ def build_nets(dev):
 build_nets.weights = 'synthetic checkpoints'
 
 
+def _measured_limiters():
+    """Kernels of the `secondary` list that are NOT HBM-bound although SURVEY.md 8d prices them against HBM: what the committed
+    PMC passes (profiles/r03_pmc_render.json, profiles/r03_pmc_lds.json) measured instead.  Static, like the HBM bytes."""
+    out = {}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_render.json')) as f:
+            r = json.load(f)
+        out['render_average_kernel'] = {'unit': 'valu', 'valu_issue_active_frac': r['valu_active_frac'],
+                                        'source': 'profiles/r03_pmc_render.json (SQ_ACTIVE_INST_VALU)'}
+    except (OSError, KeyError, ValueError):
+        pass
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_lds.json')) as f:
+            l = json.load(f)['cost_volume']
+        out['cost_volume_kernel'] = {'unit': 'lds', 'lds_active_frac': l['lds_busy_frac'],
+                                     'lds_bank_conflict_frac': l['lds_bank_conflict_frac'],
+                                     'source': 'profiles/r03_pmc_lds.json (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT)'}
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
 class ConvProbe:
     """HIP-event timing of every conv-engine launch (the dominant kernel family) on the launch stream."""
 
@@ -81,6 +103,9 @@ class ConvProbe:
                 ent['hbm_bytes_per_step_static'] = round(per_step)
                 ent['achieved_GBps'] = round(per_step / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
                 ent['frac_of_hbm_peak'] = round(per_step / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if ms > 0 else 0.0
+            lim = _measured_limiters().get(k)
+            if lim:
+                ent['measured_limiter_static'] = lim      # what the committed PMC passes say the kernel is bound by (not HBM)
             out[k] = ent
         return out
 
