@@ -566,3 +566,24 @@ def test_conv_pool2_fused(dev, n, h, w, cin, cout, g):
     a = ops.conv(xs, ws, bs, relu=True, pool2=True)
     b = ops.maxpool(ops.conv(xs, ws, bs, relu=True), 2, 2, 0)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ streaming mode, the other warp / fusion modes
+def test_online_linear_fast_matches_offline(dev, hip_nets):
+    """OnlineStitcher with warp FAST / fusion LINEAR (the blend's result is copied into the static output buffer) against the
+    offline clip rendered on the same canvas, across the warm-up -> steady-state (HIP graph) seam."""
+    from stabstitch2_amd import pipeline, ops
+    from stabstitch2_amd.online import OnlineStitcher
+    n = 11
+    hr, lr = synth.make_clip_device(n, 360, 480, seed=12, device=dev)
+    acc = pipeline.estimate_meshes(hip_nets, lr[0], lr[1])
+    ms = [acc['smooth_mesh1'], acc['smooth_mesh2']]
+    off, hc, wc = pipeline.render_frames([hr[0], hr[1]], ms, 'FAST', 'LINEAR')
+    bbox = ops.mesh_bbox(ms, 360, 480).cpu().tolist()
+    st = OnlineStitcher(hip_nets, 360, 480, canvas=bbox, warp_mode='FAST', fusion_mode='LINEAR')
+    frames = []
+    for t in range(n):
+        frames += st.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
+    assert len(frames) == n and (st.hc, st.wc) == (hc, wc) and st.graph is not None
+    d = (torch.stack(frames, 0) - off).abs()
+    assert float(d.median()) < 1e-3 and float(torch.quantile(d.flatten()[::17], 0.999)) < 0.1, (float(d.median()), float(d.max()))
