@@ -20,7 +20,12 @@ import subprocess
 import sys
 import time
 
-import torch
+# the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams sharing a
+# queue execute in order, which serialises the host->host path's PCIe copies with its kernels (stabstitch2_amd/__init__.py,
+# tools/diag_overlap.py).  Must be in the environment before the runtime initialises, i.e. before the first device call.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
@@ -342,6 +347,9 @@ def parse_args(argv=None):
     ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'), help='nccl = RCCL over xGMI; gloo for the CPU launcher test')
     ap.add_argument('--force-collective', action='store_true',
                     help='initialise the process group and run the result all_gather even with ONE rank (RCCL smoke on a 1-GPU box)')
+    ap.add_argument('--share-device', action='store_true',
+                    help='multi-rank readiness check on a 1-GPU box: every rank drives cuda:0 (real kernels, per-rank clip seeds, '
+                         'the gather and the N > 1 JSON line; use with --backend gloo -- RCCL refuses two ranks on one device)')
     ap.add_argument('--stub-step-ms', type=float, default=0.0,
                     help='launcher self-test without GPUs: every step is a sleep of this many ms (backend gloo)')
     return ap.parse_args(argv)
@@ -361,7 +369,7 @@ def self_launch(args, argv):
     if not args.stub_step_ms:
         assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not args.share_device:
             raise SystemExit('--gpus %d but only %d GPU(s) visible on this node' % (args.gpus, have))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
@@ -434,6 +442,11 @@ def other_configs(nets, dev, args):
     entry('720p 2-view fusion LINEAR', n, dt, K, o[1], o[2], sg)
     dt, o, sg = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets, 'FAST', 'AVERAGE'), sync, W, K, True)
     entry('720p 2-view warp FAST', n, dt, K, o[1], o[2], sg)
+    # three views with the reference's default fusion (test_online_tra_threeview.py:541): warp once, two chained blend passes
+    dt, o, sg = measure(lambda: pipeline.run_three_view(hr[0], hr[1], hr[2], lr[0], lr[1], lr[2], nets, 'NORMAL', 'LINEAR'),
+                        sync, W, K, True)
+    entry('720p 3-view fusion LINEAR', n, dt, K, o[1], o[2], sg)
+    del o
     # opt-in arithmetic of the Winograd GEMMs: fp32 products formed exactly from three bf16 slices per operand (nine slice
     # products) on the bf16 matrix pipe, fp32 accumulation (ops.WINO_MATH, csrc/wino.hip SLICED).  NOT the headline.
     from stabstitch2_amd import ops
@@ -452,21 +465,54 @@ def other_configs(nets, dev, args):
     # host-to-host: uint8 frames in pinned host memory -> stitched uint8 frames in pinned host memory (H2D + ingest +
     # path + uint8 sink + D2H of every fused frame, as the reference's printed fps includes .cpu())
     u8 = [hr[v].permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).contiguous().cpu().pin_memory() for v in range(2)]
-    runner = pipeline.HostClipRunner(nets, dev)
+    from stabstitch2_amd import hostbind
+    place = hostbind.report(dev) or {}
+    for fusion in ('AVERAGE', 'LINEAR'):
+        runner = pipeline.HostClipRunner(nets, dev, fusion_mode=fusion)
 
-    def host_steps(k):
-        last = None
-        for last in runner.run((u8[0], u8[1]) for _ in range(k)):
-            pass
-        return last
-    host_steps(3)
-    sync()
-    t0 = time.perf_counter()
-    last = host_steps(K)
-    sync()
-    entry('720p 2-view uint8 host->host incl. D2H of every fused frame', n, time.perf_counter() - t0, K, last[1], last[2],
-          note='PCIe both ways (5.5 MB in + 3.1 MB out per frame), copies overlapped with compute on three HIP streams; '
-               'the clips of one run are pipelined, so there is no single-step time')
+        stamps = []
+
+        def host_steps(k):
+            last = None
+            for last in runner.run((u8[0], u8[1]) for _ in range(k)):
+                stamps.append(time.perf_counter())
+            return last
+        host_steps(3)
+        sync()
+        runner.timed = True
+        KH = 3 * K                      # the first upload and the last download of a run are not hidden: a long run
+        del stamps[:]
+        t0 = time.perf_counter()
+        last = host_steps(KH)
+        sync()
+        name = '720p 2-view uint8 host->host incl. D2H of every fused frame' + ('' if fusion == 'AVERAGE' else ', fusion LINEAR')
+        entry(name, n, time.perf_counter() - t0, KH, last[1], last[2],
+              note='PCIe both ways (5.5 MB in + 3.1 MB out per frame), copies overlapped with compute on three HIP streams; '
+                   'the clips of one run are pipelined: fps includes the un-hidden first upload and last download of the run, '
+                   'ms_per_clip_steady = median time between two delivered clips; h2d / d2h = HIP events around the '
+                   'copies on their own streams while the compute stream runs the neighbouring clip')
+        gaps = sorted(b - a for a, b in zip(stamps[:-2], stamps[1:-1]))
+        res[name]['ms_per_clip_steady'] = round(gaps[len(gaps) // 2] * 1e3, 3)
+        res[name]['fps_steady'] = round(n / gaps[len(gaps) // 2], 1)
+        res[name].update(runner.copy_stats())
+        res[name]['numa_node'] = place.get('numa_node')
+        res[name]['cpus_bound'] = place.get('cpus_bound')
+        res[name]['GPU_MAX_HW_QUEUES'] = os.environ.get('GPU_MAX_HW_QUEUES')
+        if fusion == 'AVERAGE':
+            # the same copies with nothing else on the GPU
+            dbuf = torch.empty_like(u8[0], device=dev)
+            hout = torch.empty(tuple(last[0].shape), dtype=torch.uint8).pin_memory()
+            dout = torch.empty(tuple(last[0].shape), dtype=torch.uint8, device=dev)
+            for key, fn, nb in (('h2d_alone_GBps', lambda: dbuf.copy_(u8[0], non_blocking=True), u8[0].numel()),
+                                ('d2h_alone_GBps', lambda: hout.copy_(dout, non_blocking=True), hout.numel())):
+                fn(); sync()
+                t1 = time.perf_counter()
+                for _ in range(4):
+                    fn()
+                sync()
+                res[name][key] = round(4 * nb / (time.perf_counter() - t1) / 1e9, 1)
+            del dbuf, hout, dout
+        del runner
     # synchronous variant: fp32 fused frames copied to the host after every clip (the reference's .cpu() per frame)
     def step_d2h():
         o = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets)
@@ -505,12 +551,18 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     stub = args.stub_step_ms > 0
     dist = None
+    host = None
     if stub:
         dev = torch.device('cpu')
     else:
         assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+        if args.share_device:
+            local = 0
         torch.cuda.set_device(local)
         dev = torch.device('cuda', local)
+        # this rank's launch thread, copy threads and pinned buffers on the GPU's NUMA node (before anything is pinned)
+        from stabstitch2_amd import hostbind
+        host = hostbind.bind_to_gpu(dev, local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -631,8 +683,13 @@ def main():
         torch.cuda.synchronize()
     frames_out, hc, wc = out[0], out[1], out[2]
 
-    rec = torch.tensor([float(args.frames * args.steps), dt, float(hc), float(wc), float(rank)], dtype=torch.float64)
-    allrec = ssdist.gather_records(rec, dist, dev, args.force_collective)            # the only collective: result gather
+    vis = os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', ''))
+    rec = torch.tensor([float(args.frames * args.steps), dt, float(hc), float(wc), float(rank), float(local),
+                        float(-1 if not host or host.get('numa_node') is None else host['numa_node']),
+                        float(0 if not host or not host.get('cpus_bound') else host['cpus_bound']),
+                        float(int(vis.split(',')[0]) if vis.split(',')[0].strip().isdigit() else -1)], dtype=torch.float64)
+    # the only collective: result gather (RCCL takes the record from device memory, gloo from the host)
+    allrec = ssdist.gather_records(rec, dist, dev if args.backend == 'nccl' else None, args.force_collective)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -708,7 +765,15 @@ def main():
         result['backend'] = (ssdist.collective_backend_version() or 'rccl') if args.backend == 'nccl' else args.backend
         result['per_rank_seconds'] = [round(float(x), 4) for x in allrec[:, 1]]
         result['clip_seeds'] = [int(x) for x in allrec[:, 4]]
-    base = world == 1 and args.views == 2 and not args.online and args.io == 'f32' and not args.force_collective
+        result['per_rank_device'] = [int(x) for x in allrec[:, 5]]
+        result['per_rank_numa_node'] = [int(x) for x in allrec[:, 6]]
+        result['per_rank_cpus_bound'] = [int(x) for x in allrec[:, 7]]
+        result['per_rank_first_visible_device'] = [int(x) for x in allrec[:, 8]]
+        if args.share_device:
+            result['share_device'] = True
+    result['host'] = {'placement': host, 'HIP_VISIBLE_DEVICES': vis or None, 'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
+                      'logical_cpus': os.cpu_count()}
+    base = world == 1 and args.views == 2 and not args.online and args.io == 'f32' and not args.force_collective and not args.share_device
     if base and not args.no_other_configs:
         result['other_configs'] = other_configs(nets, dev, args)
     if base and not args.no_cpu_baseline:

@@ -254,6 +254,22 @@ SS_API int ss_render_footprints(const float* source, const float* T, float* fp, 
 SS_API long long ss_linear_blend_workspace_floats(int hc, int wc);
 SS_API int ss_linear_blend(const float* ref, const float* tgt, const float* ref_m, const float* tgt_m, float* out,
                     float* mask1_out, int hc, int wc, float* ws, void* stream);
+/* LINEAR fusion of a whole clip -- the frame loop of get_stable_sqe with fusion_mode == 'LINEAR' (test_online_tra.py:127-152
+ * around linear_blender :34-58; three views chained ((1 (+) 2) (+) 3) with mask12 = m1 + m2 - m1 m2 as
+ * test_online_tra_threeview.py:489-502) in three launches (a second blend pass with three views): warp of every view with the
+ * blender's statistics gathered on the way, one reduction per (frame, pass), one fused X / blur / blend kernel.
+ * views_base = host array of `views` device pointers to [frames][3][h][w] fp32 (the _u8 form: decoded uint8 [frames][h][w][3]);
+ * source [frames][views][63][2]; T [frames][views][2][66]; out [frames][3][hc][wc] fp32 (the _u8 form: the video frames
+ * [frames][hc][wc][3] uint8, `.astype(np.uint8)` of the blend); mask1_out optional [frames][views-1][hc][wc] (mask1 of every
+ * blend pass); ws: ss_linear_clip_workspace_floats(frames, views, hc, wc) floats.  Bit-identical, frame by frame, to
+ * ss_tps_warp_views + ss_linear_blend (+ ss_mask_union + ss_linear_blend). */
+SS_API long long ss_linear_clip_workspace_floats(int frames, int views, int hc, int wc);
+SS_API int ss_render_linear_clip(const float* const* views_base, const float* source, const float* T, float* out,
+                          float* mask1_out, int frames, int views, int h, int w, int hc, int wc, int mode, float* ws,
+                          void* stream);
+SS_API int ss_render_linear_clip_u8(const unsigned char* const* views_base, const float* source, const float* T,
+                             unsigned char* out, float* mask1_out, int frames, int views, int h, int w, int hc, int wc,
+                             int mode, float* ws, void* stream);
 
 /* ---- K14: canvas bounding box and mesh normalisation (test_online_tra.py:103-136) ------------
  * mesh: n_points (x,y) pairs at LR scale (480x360); each is scaled to the HR frame as the reference

@@ -814,3 +814,370 @@ extern "C" int ss_linear_blend(const float* ref, const float* tgt, const float* 
                        mask1_out, hc, wc);
     return ss_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// LINEAR fusion of a whole clip (round 4): the per-frame chain above -- one warp launch + seven blender launches per
+// frame, 256 launches per 32-frame clip -- as THREE launches per clip (four with three views: a second blend pass), bit-identical to it:
+//   A  lb_clip_warp_kernel    every view of every frame warped once (colour planes + ones-mask plane, the layout of
+//                             ss_tps_warp_views), all views of a tile in ONE workgroup so that the blender's whole-canvas
+//                             statistics fall out of the masks while they are still in registers: per wave and pass the six
+//                             centroid sums (ballot + popcount on the scalar unit: count, sum of rows, sum of columns of the
+//                             non-zero mask pixels) and, per row, the first and last overlap column of the tile;
+//   R  lb_clip_reduce_kernel  per (frame, pass): the wave partials -> mask centroids -> projection range of the overlap.
+//                             lb_proj is weakly monotone along a row (fp32 rounding preserves order), so its extremes over
+//                             the overlap are attained at the first / last overlap column of some (row, tile) segment:
+//                             the range needs those candidates only, not another pass over the masks;
+//   C  lb_clip_blend_kernel   per 64 x 64 canvas tile: X = ref_only + (1 - ovl_mask) m1 on the tile + 10-pixel reflect halo
+//                             -> LDS, horizontal 21-tap pass -> LDS, vertical pass, mask1, blend, store (fp32 planes or the
+//                             uint8 video frame).  X and the horizontally blurred plane never exist in memory.
+// Three views chain ((1 (+) 2) (+) 3) like test_online_tra_threeview.py:489-502: pass 2 takes the union mask
+// m1 + m2 - m1 m2 (recomputed on the fly from the two planes) and the fused planes of pass 1.
+//   ws: W [n][V][4][hc][wc] | F [n][3][hc][wc] (V = 3 only) | scalars [n][P][16] u64 | partials [n][tiles][4 waves][P][8] u32
+//   scalars as in ss_linear_blend: words 0..5 = cnt1, sumr1, sumc1, cnt2, sumr2, sumc2; u32[12] / u32[13] = range keys
+#define LBC_PW 8          // partial words per (wave, pass): k1, r1, c1, k2, r2, c2, candidates of row a, row b
+
+extern "C" long long ss_linear_clip_workspace_floats(int frames, int views, int hc, int wc) {
+    if (frames <= 0 || (views != 2 && views != 3) || hc <= 1 || wc <= 1) return 0;
+    const long long ohw = (long long)hc * wc, p = views - 1;
+    const long long tiles = (long long)ss_cdiv(wc, 64) * ss_cdiv(hc, 8);
+    return (long long)frames * (views * 4 * ohw + (views == 3 ? 3 * ohw : 0) + p * 32 + tiles * 4 * p * LBC_PW);
+}
+
+// sum of the lane indices whose bit is set (scalar unit: six popcounts)
+__device__ __forceinline__ unsigned lane_index_sum(unsigned long long m) {
+    return (unsigned)__popcll(m & 0xAAAAAAAAAAAAAAAAull) + 2u * (unsigned)__popcll(m & 0xCCCCCCCCCCCCCCCCull) +
+           4u * (unsigned)__popcll(m & 0xF0F0F0F0F0F0F0F0ull) + 8u * (unsigned)__popcll(m & 0xFF00FF00FF00FF00ull) +
+           16u * (unsigned)__popcll(m & 0xFFFF0000FFFF0000ull) + 32u * (unsigned)__popcll(m & 0xFFFFFFFF00000000ull);
+}
+
+template <int VIEWS, bool U8>
+__global__ __launch_bounds__(256) void lb_clip_warp_kernel(RenderViews rv, const float* __restrict__ source,
+                                                           const float* __restrict__ T, float* __restrict__ W,
+                                                           unsigned* __restrict__ partials, int h, int w, int hc, int wc,
+                                                           int mode, long long img_fs) {
+    constexpr int P = VIEWS - 1;
+    const long long frame = blockIdx.y;
+    const long long hw = (long long)h * w, ohw = (long long)hc * wc;
+    source += frame * (VIEWS * SS_NV * 2);
+    T += frame * (VIEWS * 2 * SS_NT);
+    W += frame * (VIEWS * 4) * ohw;
+#pragma unroll
+    for (int k = 0; k < VIEWS; ++k)
+        rv.img[k] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(rv.img[k]) + frame * img_fs);
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nbx = (wc + 63) / 64;
+    const int tby = blockIdx.x / nbx, tbx = blockIdx.x - tby * nbx;
+    unsigned* part = partials + ((frame * gridDim.x + blockIdx.x) * 4 + wv) * (P * LBC_PW);
+    const int x = tbx * 64 + lx;
+    const int ya = tby * 8 + wv, yb = ya + 4;
+    if (ya >= hc) {                                  // a wave below the canvas: its partials are read all the same
+        if (lx < P * LBC_PW) part[lx] = (lx & 7) >= 6 ? 0xFFFFFFFFu : 0u;
+        return;
+    }
+    const bool xin = x < wc;
+    const float gx = linspace_at(-1.f, 1.f, wc, min(x, wc - 1));
+    __shared__ ss_f2 dytab[4][VIEWS][64];
+    const float gya = linspace_at(-1.f, 1.f, hc, ya), gyb = linspace_at(-1.f, 1.f, hc, min(yb, hc - 1));
+#pragma unroll
+    for (int k = 0; k < VIEWS; ++k) tps_rows_table(source + k * SS_NV * 2, gya, gyb, lx, dytab[wv][k]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same wave reads it back: ordering only, no barrier
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float ma[VIEWS], mb[VIEWS];                      // the ones-mask plane of every view at the lane's pixel of row a / row b
+    const bool rowb = yb < hc;
+#pragma unroll
+    for (int k = 0; k < VIEWS; ++k) {
+        ss_f2 px, py;
+        tps_eval_rows(source + k * SS_NV * 2, T + k * 2 * SS_NT, dytab[wv][k], gx, gya, gyb, px, py);
+        float va[3], vb[3];
+        if (U8) {
+            const unsigned char* img8 = reinterpret_cast<const unsigned char*>(rv.img[k]);
+            sample3_u8(img8, px.x, py.x, w, h, mode, va);
+            sample3_u8(img8, px.y, py.y, w, h, mode, vb);
+        } else {
+            sample3(rv.img[k], px.x, py.x, w, h, hw, mode, va);
+            sample3(rv.img[k], px.y, py.y, w, h, hw, mode, vb);
+        }
+        if (mode == SS_WARP_NORMAL) {
+            const SsTaps ta = taps_normal(px.x, py.x, w, h), tb = taps_normal(px.y, py.y, w, h);
+            ma[k] = blend4(ta, 1.f, 1.f, 1.f, 1.f);
+            mb[k] = blend4(tb, 1.f, 1.f, 1.f, 1.f);
+        } else {
+            ma[k] = fast_mask(px.x, py.x, w, h);
+            mb[k] = fast_mask(px.y, py.y, w, h);
+        }
+        if (xin) {
+            float* o = W + (long long)k * 4 * ohw + (long long)ya * wc + x;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) o[ch * ohw] = va[ch];
+            o[3 * ohw] = ma[k];
+            if (rowb) {
+                o += 4ll * wc;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) o[ch * ohw] = vb[ch];
+                o[3 * ohw] = mb[k];
+            }
+        }
+    }
+    // the blender's statistics of this wave's two rows, per pass: ref mask = m0 (pass 1) / m0 + m1 - m0 m1 (pass 2)
+    float ra = ma[0], rb = mb[0];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float ta = ma[p + 1], tb = mb[p + 1];
+        const unsigned long long r_a = __ballot(xin && ra != 0.f), r_b = __ballot(xin && rowb && rb != 0.f);
+        const unsigned long long t_a = __ballot(xin && ta != 0.f), t_b = __ballot(xin && rowb && tb != 0.f);
+        const unsigned long long o_a = __ballot(xin && lb_overlap(ra, ta)), o_b = __ballot(xin && rowb && lb_overlap(rb, tb));
+        const unsigned k1a = (unsigned)__popcll(r_a), k1b = (unsigned)__popcll(r_b);
+        const unsigned k2a = (unsigned)__popcll(t_a), k2b = (unsigned)__popcll(t_b);
+        if (lx == 0) {
+            unsigned* q = part + p * LBC_PW;
+            q[0] = k1a + k1b;
+            q[1] = k1a * (unsigned)ya + k1b * (unsigned)yb;
+            q[2] = (k1a + k1b) * (unsigned)(tbx * 64) + lane_index_sum(r_a) + lane_index_sum(r_b);
+            q[3] = k2a + k2b;
+            q[4] = k2a * (unsigned)ya + k2b * (unsigned)yb;
+            q[5] = (k2a + k2b) * (unsigned)(tbx * 64) + lane_index_sum(t_a) + lane_index_sum(t_b);
+            // first | last << 16 overlap column of the row inside this tile (0xFFFFFFFF: none)
+            q[6] = o_a ? (unsigned)(tbx * 64 + __ffsll((long long)o_a) - 1) | ((unsigned)(tbx * 64 + 63 - __clzll((long long)o_a)) << 16)
+                       : 0xFFFFFFFFu;
+            q[7] = o_b ? (unsigned)(tbx * 64 + __ffsll((long long)o_b) - 1) | ((unsigned)(tbx * 64 + 63 - __clzll((long long)o_b)) << 16)
+                       : 0xFFFFFFFFu;
+        }
+        if (p + 1 < P) {                              // mask12 = m1 + m2 - m1 m2 (threeview:498; ss_mask_union)
+            ra = __fsub_rn(__fadd_rn(ra, ta), __fmul_rn(ra, ta));
+            rb = __fsub_rn(__fadd_rn(rb, tb), __fmul_rn(rb, tb));
+        }
+    }
+}
+
+// one workgroup per (frame, pass): wave partials -> scalars block
+__global__ __launch_bounds__(256) void lb_clip_reduce_kernel(const unsigned* __restrict__ partials, unsigned long long* __restrict__ scalars,
+                                                             int tiles, int nbx, int passes) {
+    const int frame = blockIdx.x / passes, p = blockIdx.x - frame * passes;
+    const unsigned* q0 = partials + ((long long)frame * tiles * 4) * (passes * LBC_PW) + p * LBC_PW;
+    const long long stride = (long long)passes * LBC_PW;
+    const int nw = tiles * 4;                        // wave partials of this frame
+    unsigned long long* s = scalars + (long long)blockIdx.x * 16;
+    __shared__ unsigned long long red[6];
+    __shared__ LbCenters Ls;
+    __shared__ float smn[4], smx[4];
+    if (threadIdx.x < 6) red[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    for (int i = threadIdx.x; i < nw; i += 256) {
+        const unsigned* q = q0 + i * stride;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += q[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        unsigned long long t = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], t);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) s[threadIdx.x] = red[threadIdx.x];
+    if (threadIdx.x == 0) Ls = lb_centers(red);
+    __syncthreads();
+    const LbCenters L = Ls;
+    float mn = INFINITY, mx = -INFINITY;
+    // wave partial i belongs to tile i / 4, wave i % 4: rows (tile / nbx) * 8 + wave and + 4 -- the row is recomputed from
+    // the partial's position, the columns come packed
+    for (int i = threadIdx.x; i < nw; i += 256) {
+        const unsigned* q = q0 + i * stride;
+        const int tile = i >> 2, wv = i & 3;
+        const int ya = (tile / nbx) * 8 + wv;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const unsigned e = q[6 + rr];
+            if (e != 0xFFFFFFFFu) {
+                const int r = ya + 4 * rr;
+                const float p0 = lb_proj(L, r, (int)(e & 0xFFFFu)), p1 = lb_proj(L, r, (int)(e >> 16));
+                mn = fminf(mn, fminf(p0, p1));
+                mx = fmaxf(mx, fmaxf(p0, p1));
+            }
+        }
+    }
+    mn = ss_wave_min(mn);
+    mx = ss_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        unsigned* u = reinterpret_cast<unsigned*>(s);
+        u[12] = mn != INFINITY ? f2key(mn) : 0xffffffffu;         // (the values lb_init_kernel + atomicMin / atomicMax leave)
+        u[13] = mx != -INFINITY ? f2key(mx) : 0u;
+    }
+}
+
+struct LbClipArgs {
+    const float *ref, *tgt, *m1a, *m1b, *m2;          // m1b != nullptr: ref mask = m1a + m1b - m1a m1b
+    long long ref_fs, tgt_fs, m_fs;                   // frame strides in floats (all masks share W's)
+    float* out;                                       // fp32 [n][3][hc][wc] or uint8 [n][hc][wc][3]
+    float* mask1_out;                                 // nullable, this pass's plane of [n][P][hc][wc]
+    long long mask1_fs;
+    const unsigned long long* scalars;                // this pass's block of frame 0
+    long long sc_fs;                                  // u64 words between frames
+};
+
+#define LBC_T 64
+#define LBC_E (LBC_T + 20)
+template <bool UNION, bool U8OUT>
+__global__ __launch_bounds__(256) void lb_clip_blend_kernel(LbClipArgs a, int hc, int wc, Gauss21 g) {
+    __shared__ float XL[LBC_E * LBC_E];              // X on the tile + halo, reflected coordinates resolved
+    __shared__ float TL[LBC_E * LBC_T];              // horizontally blurred rows of the tile + vertical halo
+    __shared__ LbCenters Ls;
+    __shared__ float prange[2];
+    const long long frame = blockIdx.z;
+    const long long ohw = (long long)hc * wc;
+    const float* m1a = a.m1a + frame * a.m_fs;
+    const float* m1b = UNION ? a.m1b + frame * a.m_fs : nullptr;
+    const float* m2 = a.m2 + frame * a.m_fs;
+    const unsigned long long* s = a.scalars + frame * a.sc_fs;
+    if (threadIdx.x == 0) {
+        Ls = lb_centers(s);
+        const unsigned* u = reinterpret_cast<const unsigned*>(s);
+        prange[0] = key2f(u[12]);
+        prange[1] = key2f(u[13]);
+    }
+    __syncthreads();
+    const LbCenters L = Ls;
+    const float pmin = prange[0], pmax = prange[1];
+    const int r0 = blockIdx.y * LBC_T, c0 = blockIdx.x * LBC_T;
+    for (int idx = threadIdx.x; idx < LBC_E * LBC_E; idx += 256) {
+        const int row = idx / LBC_E, col = idx - row * LBC_E;
+        // rows / columns of a partial last tile beyond the canvas feed no stored pixel: any in-range index will do
+        const int r = min(max(reflect_idx(r0 - 10 + row, hc), 0), hc - 1), c = min(max(reflect_idx(c0 - 10 + col, wc), 0), wc - 1);
+        const long long i = (long long)r * wc + c;
+        float ma = m1a[i];
+        if (UNION) { const float mb = m1b[i]; ma = __fsub_rn(__fadd_rn(ma, mb), __fmul_rn(ma, mb)); }
+        const float b = m2[i];
+        const float ovl = rintf(__fmul_rn(ma, b));
+        const float ref_only = __fsub_rn(ma, ovl);
+        float om = 0.f;
+        if (ovl != 0.f) om = __fsub_rn(lb_proj(L, r, c), pmin) / __fadd_rn(__fsub_rn(pmax, pmin), 1e-3f);
+        XL[idx] = __fadd_rn(ref_only, __fmul_rn(__fsub_rn(1.f, om), ma));
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int row = wv; row < LBC_E; row += 4) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) acc = fmaf(g.k[k], XL[row * LBC_E + lx + k], acc);
+        TL[row * LBC_T + lx] = acc;
+    }
+    __syncthreads();
+    const int c = c0 + lx;
+    if (c >= wc) return;
+    const float* ref = a.ref + frame * a.ref_fs;
+    const float* tgt = a.tgt + frame * a.tgt_fs;
+    float* mk_out = a.mask1_out ? a.mask1_out + frame * a.mask1_fs : nullptr;
+    for (int row = wv; row < LBC_T; row += 4) {
+        const int r = r0 + row;
+        if (r >= hc) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) acc = fmaf(g.k[k], TL[(row + k) * LBC_T + lx], acc);
+        const long long i = (long long)r * wc + c;
+        float ma = m1a[i];
+        if (UNION) { const float mb = m1b[i]; ma = __fsub_rn(__fadd_rn(ma, mb), __fmul_rn(ma, mb)); }
+        const float b = m2[i];
+        const float ovl = rintf(__fmul_rn(ma, b));
+        const float ref_only = __fsub_rn(ma, ovl);
+        const float mk = fminf(fmaxf(__fadd_rn(__fmul_rn(acc, ma), ref_only), 0.f), 1.f);
+        if (mk_out) mk_out[i] = mk;
+        const float mk2 = __fmul_rn(__fsub_rn(1.f, mk), b);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = __fadd_rn(__fmul_rn(ref[ch * ohw + i], mk), __fmul_rn(tgt[ch * ohw + i], mk2));
+            if (U8OUT) reinterpret_cast<unsigned char*>(a.out)[(frame * ohw + i) * 3 + ch] = render_to_u8(v);
+            else a.out[(frame * 3 + ch) * ohw + i] = v;
+        }
+    }
+}
+
+static Gauss21 lb_gauss() {
+    // 1-D kernel exp(-0.5 (t/sigma)^2) on linspace(-10,10,21), normalised, fp32 like torchvision (as ss_linear_blend)
+    Gauss21 g;
+    float s = 0.f;
+    for (int i = 0; i < 21; ++i) {
+        float t = (float)(i - 10) / 20.0f;
+        g.k[i] = expf(-0.5f * (t * t));
+        s += g.k[i];
+    }
+    for (int i = 0; i < 21; ++i) g.k[i] /= s;
+    return g;
+}
+
+static int render_linear_clip_launch(const void* const* views_base, const float* source, const float* T, void* out,
+                                     float* mask1_out, int frames, int views, int h, int w, int hc, int wc, int mode,
+                                     float* ws, void* stream, bool u8) {
+    if (!views_base || !source || !T || !out || !ws || frames <= 0 || frames > 65535 || (views != 2 && views != 3) || h <= 1 ||
+        w <= 1 || hc < 11 || wc < 11 || wc > 65535 || hc > 65535 || (mode != SS_WARP_NORMAL && mode != SS_WARP_FAST))
+        return SS_ERR_ARG;
+    RenderViews rv;
+    for (int i = 0; i < 3; ++i) rv.img[i] = i < views ? static_cast<const float*>(views_base[i]) : nullptr;
+    for (int i = 0; i < views; ++i)
+        if (!rv.img[i]) return SS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long long ohw = (long long)hc * wc;
+    const int P = views - 1, nbx = ss_cdiv(wc, 64), tiles = nbx * ss_cdiv(hc, 8);
+    float* W = ws;
+    float* F = W + (long long)frames * views * 4 * ohw;
+    unsigned long long* scalars = reinterpret_cast<unsigned long long*>(F + (views == 3 ? (long long)frames * 3 * ohw : 0));
+    unsigned* partials = reinterpret_cast<unsigned*>(scalars + (long long)frames * P * 16);
+    const long long img_fs = u8 ? 3ll * h * w : 12ll * h * w;
+    const dim3 ga(tiles, frames);
+    if (views == 2) {
+        if (u8) hipLaunchKernelGGL((lb_clip_warp_kernel<2, true>), ga, dim3(256), 0, st, rv, source, T, W, partials, h, w, hc, wc, mode, img_fs);
+        else hipLaunchKernelGGL((lb_clip_warp_kernel<2, false>), ga, dim3(256), 0, st, rv, source, T, W, partials, h, w, hc, wc, mode, img_fs);
+    } else {
+        if (u8) hipLaunchKernelGGL((lb_clip_warp_kernel<3, true>), ga, dim3(256), 0, st, rv, source, T, W, partials, h, w, hc, wc, mode, img_fs);
+        else hipLaunchKernelGGL((lb_clip_warp_kernel<3, false>), ga, dim3(256), 0, st, rv, source, T, W, partials, h, w, hc, wc, mode, img_fs);
+    }
+    hipLaunchKernelGGL(lb_clip_reduce_kernel, dim3(frames * P), dim3(256), 0, st, (const unsigned*)partials, scalars, tiles, nbx, P);
+    const Gauss21 g = lb_gauss();
+    const dim3 gc(ss_cdiv(wc, LBC_T), ss_cdiv(hc, LBC_T), frames);
+    LbClipArgs a;
+    a.m_fs = views * 4 * ohw;
+    a.ref = W; a.ref_fs = a.m_fs;
+    a.tgt = W + 4 * ohw; a.tgt_fs = a.m_fs;
+    a.m1a = W + 3 * ohw; a.m1b = nullptr; a.m2 = W + 7 * ohw;
+    a.mask1_out = mask1_out; a.mask1_fs = P * ohw;
+    a.scalars = scalars; a.sc_fs = P * 16;
+    if (views == 2) {
+        a.out = static_cast<float*>(out);
+        if (u8) hipLaunchKernelGGL((lb_clip_blend_kernel<false, true>), gc, dim3(256), 0, st, a, hc, wc, g);
+        else hipLaunchKernelGGL((lb_clip_blend_kernel<false, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+    } else {
+        a.out = F;
+        hipLaunchKernelGGL((lb_clip_blend_kernel<false, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+        a.ref = F; a.ref_fs = 3 * ohw;
+        a.tgt = W + 8 * ohw;
+        a.m1b = W + 7 * ohw; a.m2 = W + 11 * ohw;
+        a.mask1_out = mask1_out ? mask1_out + ohw : nullptr;
+        a.scalars = scalars + 16;
+        a.out = static_cast<float*>(out);
+        if (u8) hipLaunchKernelGGL((lb_clip_blend_kernel<true, true>), gc, dim3(256), 0, st, a, hc, wc, g);
+        else hipLaunchKernelGGL((lb_clip_blend_kernel<true, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+    }
+    return ss_launch_status();
+}
+
+// whole clip, LINEAR fusion: view k's frame f at views_base[k] + f * 3 h w floats (planar fp32 [n,3,h,w]) -> out [n,3,hc,wc];
+// mask1_out (nullable): the blender's mask1 of every pass [n][V-1][hc][wc]; ws: ss_linear_clip_workspace_floats(...) floats
+extern "C" int ss_render_linear_clip(const float* const* views_base, const float* source, const float* T, float* out,
+                                     float* mask1_out, int frames, int views, int h, int w, int hc, int wc, int mode,
+                                     float* ws, void* stream) {
+    return render_linear_clip_launch(reinterpret_cast<const void* const*>(views_base), source, T, out, mask1_out, frames, views,
+                                     h, w, hc, wc, mode, ws, stream, false);
+}
+
+// the same from decoded uint8 frames [n,h,w,3] per view to uint8 video frames [n,hc,wc,3] (`.astype(np.uint8)` of the blend)
+extern "C" int ss_render_linear_clip_u8(const unsigned char* const* views_base, const float* source, const float* T,
+                                        unsigned char* out, float* mask1_out, int frames, int views, int h, int w, int hc,
+                                        int wc, int mode, float* ws, void* stream) {
+    return render_linear_clip_launch(reinterpret_cast<const void* const*>(views_base), source, T, out, mask1_out, frames, views,
+                                     h, w, hc, wc, mode, ws, stream, true);
+}

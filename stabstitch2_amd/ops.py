@@ -659,6 +659,33 @@ def linear_blend(ref, tgt, ref_m, tgt_m, want_mask=False, out=None):
     return mk if want_mask else out
 
 
+def render_linear_clip(views, source, T, hc, wc, mode='NORMAL', out=None, want_masks=False):
+    """LINEAR fusion of a whole clip in three launches (four with three views): views = list of 2|3 contiguous device tensors
+    [n,3,h,w] fp32 -> [n,3,hc,wc]; or [n,h,w,3] uint8 -> the uint8 video frames [n,hc,wc,3].  source [n,V,63,2]; T [n,V,2,66].
+    want_masks: also return the blender's mask1 of every pass [n,V-1,hc,wc].  Bit-identical to the per-frame chain
+    tps_warp_views + linear_blend (+ mask_union + linear_blend)."""
+    v = len(views)
+    u8 = views[0].dtype == torch.uint8
+    if u8:
+        n, h, w, _ = views[0].shape
+        assert all(tuple(t.shape) == (n, h, w, 3) for t in views)
+    else:
+        n, _, h, w = views[0].shape
+        assert all(tuple(t.shape) == (n, 3, h, w) for t in views)
+    assert source.shape[0] == n and T.shape[0] == n
+    dev = views[0].device
+    arr = H.ptr_array(views, dtype=torch.uint8 if u8 else torch.float32)
+    shape = (n, hc, wc, 3) if u8 else (n, 3, hc, wc)
+    if out is None:
+        out = torch.empty(shape, device=dev, dtype=views[0].dtype)
+    assert tuple(out.shape) == shape and out.dtype == views[0].dtype
+    ws = torch.empty(int(H.lib().ss_linear_clip_workspace_floats(n, v, hc, wc)), device=dev, dtype=torch.float32)
+    mk = torch.empty((n, v - 1, hc, wc), device=dev, dtype=torch.float32) if want_masks else None
+    H.call('ss_render_linear_clip_u8' if u8 else 'ss_render_linear_clip', arr, H.dptr(_f(source)), H.dptr(T),
+           _u8ptr(out) if u8 else H.dptr(out), H.dptr(mk, True), n, v, h, w, hc, wc, MODES[mode], H.dptr(ws), H.stream())
+    return (out, mk) if want_masks else out
+
+
 def mesh_bbox(meshes, img_h, img_w, bbox=None):
     """meshes: list of LR-scale tensors [...,2] -> device tensor [4] = wmin, wmax, hmin, hmax (HR px).
     bbox: an existing box to fold these meshes into (in place)."""

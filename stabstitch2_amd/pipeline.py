@@ -403,6 +403,20 @@ def _as_clip(x, n):
     return None
 
 
+# LINEAR fusion of clips held as tensors: three launches per clip (ops.render_linear_clip) instead of eight per frame.
+# SS_LINEAR_CLIP=0: the per-frame chain (tps_warp_views + linear_blend), which lists of separate frames always take.
+LINEAR_CLIP = os.environ.get('SS_LINEAR_CLIP', '1') == '1'
+LINEAR_CLIP_FRAMES = int(os.environ.get('SS_LINEAR_CLIP_FRAMES', '64'))     # frames per launch group (workspace: 44 MB per 720p frame and view)
+
+
+def _linear_clip(clips, src, T, hc, wc, warp_mode, out):
+    n = src.shape[0]
+    for s in range(0, n, LINEAR_CLIP_FRAMES):
+        e = min(s + LINEAR_CLIP_FRAMES, n)
+        ops.render_linear_clip([c[s:e] for c in clips], src[s:e], T[s:e], hc, wc, warp_mode, out=out[s:e])
+    return out
+
+
 @torch.no_grad()
 def render_frames(img_lists, meshes, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None, prescaled=False, bbox=None,
                   size=None):
@@ -423,6 +437,9 @@ def render_frames(img_lists, meshes, warp_mode='NORMAL', fusion_mode='AVERAGE', 
     clips = [_as_clip(x, n) for x in img_lists]
     if fusion_mode == 'AVERAGE' and all(c is not None for c in clips):
         ops.render_average_clip(clips, src, T, hc, wc, warp_mode, out=out, footprint=fp)
+        return out, hc, wc
+    if fusion_mode == 'LINEAR' and LINEAR_CLIP and all(c is not None for c in clips):
+        _linear_clip(clips, src, T, hc, wc, warp_mode, out)
         return out, hc, wc
     for i in range(n):
         imgs = [img_lists[k][i].to(dev, non_blocking=True) for k in range(v)]
@@ -520,15 +537,24 @@ def to_video_frames(frames, to_host=False):
 U8_FUSED = os.environ.get('SS_U8_FUSED', '1') == '1'
 
 
+def _u8_fused(fusion_mode):
+    return U8_FUSED and (fusion_mode == 'AVERAGE' or (fusion_mode == 'LINEAR' and LINEAR_CLIP))
+
+
 @torch.no_grad()
-def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None, bbox=None, size=None, prescaled=False):
+def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None, bbox=None, size=None, prescaled=False,
+                     fusion_mode='AVERAGE'):
     """frame_lists: V device tensors [N,H,W,3] uint8; meshes: V tensors [1,N,7,9,2] -> (uint8 [N,Hc,Wc,3], Hc, Wc):
-    `render_frames(..., 'AVERAGE')` followed by `to_video_frames`, fused, one launch for the clip."""
+    `render_frames(..., fusion_mode)` followed by `to_video_frames`, fused: one launch for the clip (AVERAGE), three / four
+    (LINEAR: the warped planes are fp32 either way, the blend writes the video frame)."""
     n = meshes[0].shape[1]
     img_h, img_w = frame_lists[0].shape[1], frame_lists[0].shape[2]
     hc, wc, src, T = render_plan(meshes, img_h, img_w, prescaled, bbox=bbox, size=size)
     if out is None or tuple(out.shape) != (n, hc, wc, 3) or not out.is_contiguous():
         out = torch.empty((n, hc, wc, 3), device=meshes[0].device, dtype=torch.uint8)
+    if fusion_mode == 'LINEAR':
+        _linear_clip([f if f.is_contiguous() else f.contiguous() for f in frame_lists], src, T, hc, wc, warp_mode, out)
+        return out, hc, wc
     fp = ops.render_footprints(src, T, img_h, img_w, hc, wc) if SKIP_OUTSIDE else None
     ops.render_average_clip_u8([f if f.is_contiguous() else f.contiguous() for f in frame_lists], src, T, hc, wc, warp_mode,
                                out=out, footprint=fp)
@@ -544,13 +570,13 @@ def _as_device_u8(frames, device):
 @torch.no_grad()
 def run_two_view_u8(frames1, frames2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', device='cuda', to_host=False):
     """uint8 in, uint8 out: ingest -> estimate -> render -> video frames.  -> (uint8 [N,Hc,Wc,3], Hc, Wc, m1, m2)."""
-    if U8_FUSED and fusion_mode == 'AVERAGE':
+    if _u8_fused(fusion_mode):
         f1, f2 = _as_device_u8(frames1, device), _as_device_u8(frames2, device)
         _, lr1 = ops.ingest_u8(f1, want_hr=False)
         _, lr2 = ops.ingest_u8(f2, want_hr=False)
         acc = estimate_meshes(nets, lr1, lr2)
         m1, m2 = acc['smooth_mesh1'], acc['smooth_mesh2']
-        u8, hc, wc = render_frames_u8([f1, f2], [m1, m2], warp_mode)
+        u8, hc, wc = render_frames_u8([f1, f2], [m1, m2], warp_mode, fusion_mode=fusion_mode)
         return (u8.cpu().numpy() if to_host else u8), hc, wc, m1, m2
     hr1, lr1 = load_frames_u8(frames1, device=device)
     hr2, lr2 = load_frames_u8(frames2, device=device)
@@ -564,17 +590,28 @@ def run_three_view_u8(frames1, frames2, frames3, nets, warp_mode='NORMAL', fusio
     -> (uint8 [N,Hc,Wc,3], Hc, Wc, mesh1, middle, mesh3)."""
     f = [_as_device_u8(x, device) for x in (frames1, frames2, frames3)]
     img_h, img_w = f[0].shape[1], f[0].shape[2]
-    if U8_FUSED and fusion_mode == 'AVERAGE':
+    if _u8_fused(fusion_mode):
         lr = [ops.ingest_u8(x, want_hr=False)[1] for x in f]
         a12 = estimate_meshes(nets, lr[0], lr[1], keep_spatial_cache2=True)
         a23 = estimate_meshes(nets, lr[1], lr[2], tmotion1=a12['tmotion2'], spatial_cache1=a12.get('spatial_cache2'))
         ms = three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'], a23['smooth_mesh2'], img_h, img_w)
-        u8, hc, wc = render_frames_u8(f, list(ms), warp_mode, prescaled=True)
+        u8, hc, wc = render_frames_u8(f, list(ms), warp_mode, prescaled=True, fusion_mode=fusion_mode)
         return (u8.cpu().numpy() if to_host else u8), hc, wc, ms[0], ms[1], ms[2]
     io = [ops.ingest_u8(x) for x in f]
     frames, hc, wc, m1, mid, m3 = run_three_view(io[0][0], io[1][0], io[2][0], io[0][1], io[1][1], io[2][1], nets, warp_mode,
                                                  fusion_mode)
     return to_video_frames(frames, to_host), hc, wc, m1, mid, m3
+
+
+def io_streams(dev):
+    """(upload, compute, download) HIP streams of a host-fed runner.  The three must sit on DIFFERENT hardware queues: the
+    HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) AQL queues, and two streams that
+    share one execute in order -- an upload enqueued ahead of the current clip's kernels then holds them back for its whole
+    PCIe time (measured, tools/diag_overlap.py: 9.4 ms per clip with a queue each, 12.1 with one copy stream on the compute
+    queue, 15.3 with both; which streams collide depends on how many streams the process used before).  The package
+    therefore raises GPU_MAX_HW_QUEUES to 16 at import (stabstitch2_amd/__init__.py; only effective before the HIP
+    runtime initialises) -- `HostClipRunner.copy_stats()` reports what the copies achieved beside the compute."""
+    return tuple(torch.cuda.Stream(dev) for _ in range(3))
 
 
 class HostClipRunner:
@@ -589,15 +626,43 @@ class HostClipRunner:
     uint8 tensor [N,Hc,Wc,3], Hc, Wc) one clip late at most; a yielded tensor stays valid until `depth` more clips
     have been yielded."""
 
-    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', depth=2):
+    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', depth=2, streams=None):
         self.nets, self.dev = nets, torch.device(device)
         self.warp_mode, self.fusion_mode, self.depth = warp_mode, fusion_mode, depth
-        self.up, self.comp, self.down = (torch.cuda.Stream(self.dev) for _ in range(3))
+        self.up, self.comp, self.down = streams if streams is not None else io_streams(self.dev)
         self._host = [dict() for _ in range(depth + 1)]
+        self.timed = False                   # True: HIP events around every upload / download (copy_stats)
+        self._copies = {'h2d': [], 'd2h': []}
+
+    def _timed_copy(self, kind, stream, nbytes, fn):
+        if not self.timed:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r = fn()
+        e1.record(stream)
+        self._copies[kind].append((e0, e1, nbytes))
+        return r
+
+    def copy_stats(self, reset=True):
+        """With `timed` set: {'h2d_GBps', 'd2h_GBps', 'h2d_ms', 'd2h_ms'} of the copies enqueued since the last call, each
+        measured on its own stream while the compute stream runs the neighbouring clip (call after a synchronize)."""
+        out = {}
+        for kind, evs in self._copies.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            nb = sum(n for _, _, n in evs)
+            if evs and ms > 0:
+                out[kind + '_GBps'] = round(nb / (ms * 1e-3) / 1e9, 1)
+                out[kind + '_ms_per_clip'] = round(ms / len(evs), 3)
+        if reset:
+            self._copies = {'h2d': [], 'd2h': []}
+        return out
 
     def _upload(self, clip):
         with torch.cuda.stream(self.up):
-            d = [(torch.from_numpy(f) if not torch.is_tensor(f) else f).to(self.dev, non_blocking=True) for f in clip]
+            src = [(torch.from_numpy(f) if not torch.is_tensor(f) else f) for f in clip]
+            d = self._timed_copy('h2d', self.up, sum(t.numel() * t.element_size() for t in src),
+                                 lambda: [t.to(self.dev, non_blocking=True) for t in src])
             ev = torch.cuda.Event()
             ev.record(self.up)
         return d, ev
@@ -608,11 +673,12 @@ class HostClipRunner:
             for t in d:
                 t.record_stream(self.comp)
             d = [t if t.is_contiguous() else t.contiguous() for t in d]
-            if U8_FUSED and self.fusion_mode == 'AVERAGE':
+            if _u8_fused(self.fusion_mode):
                 _, lr1 = ops.ingest_u8(d[0], want_hr=False)
                 _, lr2 = ops.ingest_u8(d[1], want_hr=False)
                 acc = estimate_meshes(self.nets, lr1, lr2)
-                u8, hc, wc = render_frames_u8(d, [acc['smooth_mesh1'], acc['smooth_mesh2']], self.warp_mode)
+                u8, hc, wc = render_frames_u8(d, [acc['smooth_mesh1'], acc['smooth_mesh2']], self.warp_mode,
+                                              fusion_mode=self.fusion_mode)
             else:
                 hr1, lr1 = ops.ingest_u8(d[0])
                 hr2, lr2 = ops.ingest_u8(d[1])
@@ -632,7 +698,7 @@ class HostClipRunner:
         self.down.wait_event(ev)
         with torch.cuda.stream(self.down):
             u8.record_stream(self.down)
-            slot[key].copy_(u8, non_blocking=True)
+            self._timed_copy('d2h', self.down, u8.numel(), lambda: slot[key].copy_(u8, non_blocking=True))
             done = torch.cuda.Event()
             done.record(self.down)
         return slot[key], done
@@ -768,9 +834,9 @@ class LongVideoStitcher:
                     t.record_stream(io.comp)
                 d = [t if t.is_contiguous() else t.contiguous() for t in d]
                 ms = [m[:, s:e].contiguous() for m in self.meshes]
-                if U8_FUSED and self.fusion_mode == 'AVERAGE':
+                if _u8_fused(self.fusion_mode):
                     u8, _, _ = render_frames_u8(d, ms, self.warp_mode, bbox=self.bbox, size=(self.hc, self.wc),
-                                                prescaled=self.prescaled)
+                                                prescaled=self.prescaled, fusion_mode=self.fusion_mode)
                 else:
                     hrs = [ops.ingest_u8(t)[0] for t in d]
                     fr, _, _ = render_frames(hrs, ms, self.warp_mode, self.fusion_mode, prescaled=self.prescaled,
