@@ -772,7 +772,7 @@ def main():
         if args.share_device:
             result['share_device'] = True
     result['host'] = {'placement': host, 'HIP_VISIBLE_DEVICES': vis or None, 'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
-                      'logical_cpus': os.cpu_count()}
+                      'logical_cpus': os.cpu_count(), 'rccl_version': ssdist.collective_backend_version()}
     base = world == 1 and args.views == 2 and not args.online and args.io == 'f32' and not args.force_collective and not args.share_device
     if base and not args.no_other_configs:
         result['other_configs'] = other_configs(nets, dev, args)

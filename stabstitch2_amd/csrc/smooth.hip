@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void window_push_kernel(float* __restrict__ ri
 extern "C" int ss_window_push(float* ring, const float* src, const long long* src_off, int rings, int window, int elems,
                               float* state, int blocks, int block, long long stride, long long delta, void* stream) {
     if (!ring || !src || !src_off || rings <= 0 || rings > 8 || window < 2 || elems <= 0 ||
-        (long long)(window - 1) * elems > 2048 || blocks < 0 || (blocks > 0 && (!state || block <= 0 || delta < block)))
+        (long long)(window - 1) * elems > 2048 || blocks < 0 || (blocks > 0 && (!state || block <= 0 || delta < block)) ||
+        (blocks > 1 && stride < delta + block))       // block b + 1's destination must not reach into block b's source
         return SS_ERR_ARG;
     WinPushArgs a;
     for (int r = 0; r < 8; ++r) a.src_off[r] = r < rings ? src_off[r] : 0;

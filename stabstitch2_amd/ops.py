@@ -114,6 +114,9 @@ def stem_pool_packed(wgt):
     return ent.get(wgt.device), g
 
 
+STEM_POOL_MAX_BYTES = 1 << 32        # bytes of row-packed input one ss_stem_pool launch can address
+
+
 def stem_pool(buf, wgt, bias=None):
     """Conv2d(3,64,7,2,3) + folded BN + ReLU + MaxPool2d(3,2,1) on `stem_input` frames [n,h,w+8,3] in one kernel.
     wgt [g*64,7,24] (+ bias [g*64]): g filter banks reading the same frames -> [g,n,hp,wp,64] (each bank contiguous)."""
@@ -123,7 +126,13 @@ def stem_pool(buf, wgt, bias=None):
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
     out = torch.empty((g, n, hp, wp, 64), device=buf.device, dtype=torch.float32)
-    H.call('ss_stem_pool', H.dptr(buf), H.dptr(pk), H.dptr(bias, True), H.dptr(out), n, h, w, g, out[0].numel(), H.stream())
+    # one launch addresses its frames with 32-bit byte offsets (< 4 GiB of row-packed input, ss_stem_pool returns
+    # SS_ERR_UNSUPPORTED beyond: ~2000 LR frames): larger batches go in several launches, each bank's slice written in place
+    per = max(1, (STEM_POOL_MAX_BYTES - 1) // (h * wp8 * 12))
+    for s in range(0, n, per):
+        e = min(s + per, n)
+        H.call('ss_stem_pool', H.dptr(buf[s:e]), H.dptr(pk), H.dptr(bias, True), H.dptr(out[0, s:e]), e - s, h, w, g,
+               out[0].numel(), H.stream())
     return out
 
 
@@ -494,6 +503,7 @@ def window_push(ring, src, src_off, state=None, blocks=0, block=0, stride=0, del
     assert all(0 <= o and o + e <= src.numel() for o in src_off)
     if blocks:
         assert state.is_contiguous() and (blocks - 1) * stride + delta + block <= state.numel()
+        assert delta >= block and (blocks == 1 or stride >= delta + block), 'window_push: overlapping state blocks'
     offs = (ctypes.c_longlong * r)(*src_off)
     H.call('ss_window_push', H.dptr(ring), H.dptr(src), ctypes.cast(offs, ctypes.c_void_p), r, w, e, H.dptr(state, True),
            blocks, block, stride, delta, H.stream())

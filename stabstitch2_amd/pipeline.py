@@ -120,7 +120,7 @@ class JointEstimator:
     (spatial_network.py:127-130 and temporal_network.py:47-50 build identical stems), so the stem runs ONCE with 2 x 64
     filters and each net continues from its half of the channels.  TemporalNet's cost volumes pair every frame with its
     predecessor; across a chunk boundary the predecessor's stage-1 features are carried over (one [1,45,60,128] map per
-    view), so feeding a video in chunks launches exactly the kernels a resident clip of the same chunking launches:
+    view, copied into a buffer of its own), so feeding a video in chunks launches exactly the kernels a resident clip of the same chunking launches:
     the motions are bit-identical however the frames arrive.
         est = JointEstimator(spatial_net, temporal_net, n_frames, device); est.push(lr1[s:e], lr2[s:e]) ...; est.result()
     tmotion1: view 1's temporal motions when a previous pass already produced them (three-view: the middle view is view 2
@@ -208,7 +208,13 @@ class JointEstimator:
                     ops.cost_volume(fi[:b - 1], fi[1:], 3, out=cv[i * rows + lead:(i + 1) * rows])
                 slices.append((i * rows, (i + 1) * rows, self.tm[i, e - rows:e].view(rows, -1)))
             L.run_regressor(cv, tp['r2'], out_slices=slices)
-        self.carry = [f[i * b + b - 1:(i + 1) * b] for i in range(nv)]
+        # the last frame's features of every view in a small buffer of their own: a slice of `f` would keep the whole chunk's
+        # [nv*b,45,60,128] features alive through the next push
+        if e < self.n:                                   # (the last chunk carries nothing)
+            if self.carry is None:
+                self.carry = [torch.empty((1,) + tuple(f.shape[1:]), device=f.device, dtype=torch.float32) for _ in range(nv)]
+            for i in range(nv):
+                self.carry[i].copy_(f[i * b + b - 1:(i + 1) * b])
 
     def result(self):
         """-> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""
@@ -630,7 +636,9 @@ class HostClipRunner:
         self.nets, self.dev = nets, torch.device(device)
         self.warp_mode, self.fusion_mode, self.depth = warp_mode, fusion_mode, depth
         self.up, self.comp, self.down = streams if streams is not None else io_streams(self.dev)
-        self._host = [dict() for _ in range(depth + 1)]
+        # depth + 2 pinned result slots: the download of clip k + depth + 1 is enqueued before clip k + depth is yielded, so a
+        # tensor yielded for clip k is only overwritten after `depth` more clips have been handed out
+        self._host = [None] * (depth + 2)
         self.timed = False                   # True: HIP events around every upload / download (copy_stats)
         self._copies = {'h2d': [], 'd2h': []}
 
@@ -689,19 +697,21 @@ class HostClipRunner:
         return u8, hc, wc, ev2
 
     def _download(self, k, u8, ev):
-        key = tuple(u8.shape)
-        if key not in self._host[0]:         # new canvas size: pin every slot now, not one clip at a time
-            for s_ in self._host:
-                s_.clear()
-                s_[key] = torch.empty(key, dtype=torch.uint8).pin_memory()
-        slot = self._host[k % (self.depth + 1)]
+        m, frame = u8.shape[0], tuple(u8.shape[1:])
+        h0 = self._host[0]
+        if h0 is None or tuple(h0.shape[1:]) != frame or h0.shape[0] < m:
+            # new canvas size (or a longer clip than any before): pin every slot now, not one clip at a time.  Slots are
+            # sized for the longest clip seen; a shorter last chunk takes a slice (no re-pinning at the end of a video)
+            cap = m if h0 is None or tuple(h0.shape[1:]) != frame else max(m, h0.shape[0])
+            self._host = [torch.empty((cap,) + frame, dtype=torch.uint8).pin_memory() for _ in self._host]
+        dst = self._host[k % len(self._host)][:m]
         self.down.wait_event(ev)
         with torch.cuda.stream(self.down):
             u8.record_stream(self.down)
-            self._timed_copy('d2h', self.down, u8.numel(), lambda: slot[key].copy_(u8, non_blocking=True))
+            self._timed_copy('d2h', self.down, u8.numel(), lambda: dst.copy_(u8, non_blocking=True))
             done = torch.cuda.Event()
             done.record(self.down)
-        return slot[key], done
+        return dst, done
 
     @torch.no_grad()
     def run(self, clips):
@@ -819,7 +829,7 @@ class LongVideoStitcher:
     @torch.no_grad()
     def render(self, *views):
         """Pass 2: yields (uint8 [m,Hc,Wc,3] pinned host tensor, s, e) per chunk of frames [s, e), one chunk late at most;
-        a yielded tensor stays valid until two more chunks have been yielded."""
+        a yielded tensor stays valid until two more chunks have been yielded (HostClipRunner keeps depth + 2 slots)."""
         if self.acc is None:
             raise RuntimeError('estimate() first')
         if len(views) != len(self.meshes):

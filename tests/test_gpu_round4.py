@@ -101,3 +101,92 @@ def test_linear_u8_pipeline_matches_float_pipeline(dev, hip_nets):
     fr, hc2, wc2, _, _ = pipeline.run_two_view(hr1, hr2, lr1, lr2, hip_nets, 'NORMAL', 'LINEAR')
     assert (hc, wc) == (hc2, wc2)
     assert torch.equal(a, pipeline.to_video_frames(fr))
+
+
+# ------------------------------------------------------------------ advisor items of round 3
+def test_tps_solve_relaxed_pivot_on_near_degenerate_points(dev):
+    """the TPS elimination picks its pivot by a 25-bit key of the fp64 magnitude (relaxed partial pivoting).  On
+    near-coincident and near-collinear control points the solution must still be as good as an fp64 LAPACK solve of the
+    same system: compared through the residual of the 66 x 66 system (the solutions themselves are ill-conditioned)."""
+    from stabstitch2_amd import ops
+    rs = np.random.RandomState(7)
+    base = np.stack(np.meshgrid(np.linspace(-1, 1, 9), np.linspace(-1, 1, 7)), -1).reshape(63, 2)
+    sets = []
+    a = base.copy(); a[10] = a[11] + 1e-4; a[40] = a[41] + np.array([0.0, 2e-4]); sets.append(a)          # near-coincident pairs
+    b = base.copy(); b[:, 1] = 0.3 * b[:, 0] + 1e-3 * rs.randn(63); sets.append(b)                         # near-collinear
+    c = base + 0.02 * rs.randn(63, 2); sets.append(c)                                                      # well-posed control
+    src = torch.from_numpy(np.stack(sets).astype(np.float32)).to(dev)
+    tgt = torch.from_numpy((np.stack(sets) + 0.05 * rs.randn(3, 63, 2)).astype(np.float32)).to(dev)
+    T = ops.tps_solve(src, tgt).cpu().numpy().astype(np.float64)          # [3,2,66], coefficient order [a0, ax, ay, w_1..w_63]
+    for i in range(3):
+        s = src[i].cpu().numpy()
+        dx = (s[:, None, 0] - s[None, :, 0]).astype(np.float32)
+        dy = (s[:, None, 1] - s[None, :, 1]).astype(np.float32)
+        d2 = (dx * dx + dy * dy).astype(np.float32)
+        R = (d2 * np.log((d2 + np.float32(1e-6)).astype(np.float64)).astype(np.float32)).astype(np.float64)
+        P = np.concatenate((np.ones((63, 1)), s.astype(np.float64)), 1)
+        W = np.zeros((66, 66))
+        W[:63, :3], W[:63, 3:], W[63:, 3:] = P, R, P.T
+        rhs = np.concatenate((tgt[i].cpu().numpy().astype(np.float64), np.zeros((3, 2))), 0)
+        ref = np.linalg.solve(W, rhs).astype(np.float32).astype(np.float64)            # fp64 solve, rounded like the kernel's output
+        res_ref = np.abs(W @ ref - rhs).max()
+        res_gpu = np.abs(W @ T[i].T - rhs).max()
+        scale = np.abs(W).max() * max(np.abs(ref).max(), 1.0)
+        assert res_gpu <= 10 * res_ref + 1e-6 * scale, (i, res_gpu, res_ref)
+
+
+def test_window_push_rejects_overlapping_state_blocks(dev):
+    """ss_window_push moves its state blocks without ordering between them -- overlapping source / destination
+    ranges are an argument error at the C ABI, not a silent race."""
+    import ctypes
+    from stabstitch2_amd import _hip as H
+    ring = torch.zeros((1, 7, 126), device=dev)
+    src = torch.zeros(126, device=dev)
+    state = torch.zeros(1024, device=dev)
+    offs = (ctypes.c_longlong * 1)(0)
+    args = lambda blocks, block, stride, delta: (H.dptr(ring), H.dptr(src), ctypes.cast(offs, ctypes.c_void_p), 1, 7, 126,
+                                                 H.dptr(state), blocks, block, stride, delta, H.stream())
+    H.call('ss_window_push', *args(2, 126, 252, 126))                         # stride = delta + block: fine
+    with pytest.raises(H.HipError):
+        H.call('ss_window_push', *args(2, 126, 200, 126))                     # block 1's destination inside block 0's source
+    with pytest.raises(H.HipError):
+        H.call('ss_window_push', *args(1, 126, 0, 100))                       # delta < block
+
+
+def test_stem_pool_in_several_launches(dev, monkeypatch):
+    """batches beyond one launch's 32-bit input offsets are split by ops.stem_pool -- same result."""
+    from stabstitch2_amd import ops
+    n, h, w = 5, 72, 96
+    x = torch.randn(n, 3, h, w, device=dev)
+    wgt = torch.zeros(128, 7, 24, device=dev)
+    wgt[:, :, :21] = torch.randn(128, 7, 21, device=dev) * 0.1
+    bias = torch.randn(128, device=dev)
+    buf = ops.stem_input([x])
+    want = ops.stem_pool(buf, wgt, bias)
+    monkeypatch.setattr(ops, 'STEM_POOL_MAX_BYTES', 2 * h * (w + 8) * 12 + 1)          # two frames per launch
+    got = ops.stem_pool(buf, wgt, bias)
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------ multi-GPU readiness on one GPU
+def test_bench_two_ranks_share_one_gpu():
+    """`bench.py --gpus 2 --backend gloo --share-device` self-launches two ranks that BOTH drive cuda:0 with
+    the real kernels: rank -> clip seed, per-rank timing, the result gather and the N > 1 JSON line on hardware, short of RCCL
+    itself (which refuses two ranks on one device; its one-rank all_gather is test_rccl_one_rank_all_gather)."""
+    import json
+    env = dict(os.environ)
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--share-device',
+                        '--steps', '2', '--warmup', '1', '--frames', '8', '--no-cpu-baseline', '--no-other-configs'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks'] == 2 and d['backend'] == 'gloo' and d['share_device'] is True
+    assert d['clip_seeds'] == [0, 1] and d['per_rank_device'] == [0, 0]
+    assert len(d['per_rank_seconds']) == 2 and all(s > 0 for s in d['per_rank_seconds'])
+    assert len(d['per_rank_numa_node']) == 2 and 'placement' in d['host']
+    # whole-job value = frames of both ranks / slowest rank
+    assert abs(d['value'] - 2 * 8 * 2 / max(d['per_rank_seconds'])) < 1e-2 * d['value']
+    assert d['scaling'] == 'weak' and 'x 2 GPUs = configs[3]' in d['config']['workload']
