@@ -534,6 +534,31 @@ def other_configs(nets, dev, args):
         return out, st.hc, st.wc
     dt, o, sg = measure(stream_once, sync, 1, 4, True)
     entry('720p 2-view streaming (batch 1, one pair per push)', pushes, dt, 4, o[1], o[2], sg)
+    # batch of S independent live streams advancing together (one graph launch per push of S pairs)
+    from stabstitch2_amd.online import MultiOnlineStitcher
+    S = 8
+    mh1, mh2 = hr[0][:S].contiguous(), hr[1][:S].contiguous()        # the S streams' current frames: [S,3,H,W]
+    ml1, ml2 = lr[0][:S].contiguous(), lr[1][:S].contiguous()
+    def multi_once():
+        st = MultiOnlineStitcher(nets, 720, 1280, streams=S)
+        out = None
+        for t in range(7 + 40):
+            got = st.push(mh1, mh2, ml1, ml2)
+            if got[0]:
+                out = got[0][-1]
+        return out, st.canvas_sizes[0][0], st.canvas_sizes[0][1], st
+    multi_once()
+    sync()
+    # time the steady state only (the first window of every stream runs through the single-stream code)
+    _, hc_, wc_, stm = multi_once()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        stm.push(mh1, mh2, ml1, ml2)
+    sync()
+    entry('720p 2-view streaming, %d streams per push (aggregate over the streams)' % S, 40 * S, time.perf_counter() - t0, 1, hc_, wc_,
+          note='MultiOnlineStitcher: S independent live pairs advance one frame per push as one batch (one HIP graph); '
+               'steady state, 40 pushes of %d pairs' % S)
     return res
 
 

@@ -197,6 +197,10 @@ SS_API int ss_tps_inverse(const float* source, double* winv, void* stream);
 SS_API long long ss_tsmotion_workspace_floats(int n);
 SS_API int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
                        float img_h, float img_w, const double* rigid_winv, float* ws, void* stream);
+/* the same with frame k pairing with frame k - lag (test_online_tra.py:320-340 for S streams interleaved as frame = time * S +
+ * stream: lag = S; the first `lag` frames get tsmotion 0).  ss_tsmotion = lag 1. */
+SS_API int ss_tsmotion_lag(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n, int lag,
+                    float img_h, float img_w, const double* rigid_winv, float* ws, void* stream);
 
 /* ---- K12/K13: dense TPS warp and fusion (utils/torch_tps_transform.py:108-165,
  *      test_online_tra.py:34-58, 138-150) ----------------------------------------------------- */
@@ -298,6 +302,10 @@ SS_API int ss_three_view_finish(const float* n1, const float* n3, const float* m
  * out [frames][views][63][2] (one call per view assembles it; test_online_tra.py:129-136) */
 SS_API int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,
                             float img_h, float img_w, void* stream);
+/* the same with ONE CANVAS BOX PER FRAME (bboxes [frames][4]) and frame f's mesh at mesh + f * mesh_frame_stride floats: S live
+ * streams, each with its own fixed canvas, normalised in one launch per view (batch-of-streams streaming mode) */
+SS_API int ss_mesh_normalize_views_boxes(const float* mesh, long long mesh_frame_stride, const float* bboxes, float* out,
+                                  int frames, int view, int views, float img_h, float img_w, void* stream);
 /* p[0..n) = value (the zero motion of frame 0, temporal_network.py:31-33, written in place) */
 SS_API int ss_fill_f32(float* p, float value, long long n, void* stream);
 
@@ -333,6 +341,11 @@ SS_API int ss_smooth_stitch(const float* smesh1, const float* smesh2, const floa
  * floats `delta` (>= block) further.  (window - 1) * elems <= 2048. */
 SS_API int ss_window_push(float* ring, const float* src, const long long* src_off, int rings, int window, int elems,
                    float* state, int blocks, int block, long long stride, long long delta, void* stream);
+/* S streams advancing together (batch-of-streams streaming mode): groups x per rings, ring g * per + j takes the row at
+ * src + src_off[g] + j * elems (src_off: HOST array of `groups` <= 8 offsets, one per ring KIND; per = S).  With more than one
+ * state block, stride >= delta + block (the blocks move without ordering between them). */
+SS_API int ss_window_push_groups(float* ring, const float* src, const long long* src_off, int groups, int per, int window,
+                          int elems, float* state, int blocks, int block, long long stride, long long delta, void* stream);
 
 /* canvas-sized elementwise helpers of the harnesses: out = (in + add) * mul  ((img+1)*127.5,
  * test_metric_ssd.py:166);  out = a + b - a*b  (three-view mask union, test_online_tra_threeview.py:501) */

@@ -57,6 +57,7 @@ SIGNATURES = {
     'ss_tsmotion_workspace_floats': (c_ll, [c_i]),
     'ss_tps_inverse': (c_i, [c_fp, c_fp, c_st]),
     'ss_tsmotion': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_f, c_fp, c_fp, c_st]),
+    'ss_tsmotion_lag': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp, c_fp, c_st]),
     'ss_tps_warp_nchw': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_tps_warp_mask_nchw': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_tps_warp_views': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     'ss_mesh_bbox': (c_i, [c_fp, c_i, c_f, c_f, c_fp, c_i, c_st]),
     'ss_mesh_normalize': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
     'ss_mesh_normalize_views': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_st]),
+    'ss_mesh_normalize_views_boxes': (c_i, [c_fp, c_ll, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_st]),
     'ss_fill_f32': (c_i, [c_fp, c_f, c_ll, c_st]),
     'ss_h2mesh': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_st]),
     'ss_three_view_align': (c_i, [c_fp] * 9 + [c_i, c_f, c_f, c_st]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     'ss_smooth_finalize': (c_i, [c_fp] * 13 + [c_i] * 4 + [c_st]),
     'ss_smooth_stitch': (c_i, [c_fp] * 11 + [c_i] * 2 + [c_st]),
     'ss_window_push': (c_i, [c_fp, c_fp, ctypes.c_void_p, c_i, c_i, c_i, c_fp, c_i, c_i, c_ll, c_ll, c_st]),
+    'ss_window_push_groups': (c_i, [c_fp, c_fp, ctypes.c_void_p, c_i, c_i, c_i, c_i, c_fp, c_i, c_i, c_ll, c_ll, c_st]),
     'ss_alignment_psnr_ssim': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_stability_score': (c_i, [c_fp, c_fp, c_i, c_st]),
     'ss_distortion_score': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),

@@ -499,9 +499,11 @@ extern "C" int ss_tps_inverse(const float* source, double* winv, void* stream) {
 // ------------------------------------------------------------------------------------------------
 // tsmotion (test_online_tra.py:309-347), one view, all frames
 // ws layout: [nrigid 126][ntgt n*126][npts n*126][T n*132]
+// lag: frame k pairs with frame k - lag (1 = one stream, frames in time order; S = S interleaved streams advancing together,
+// frame index = time * S + stream); the first `lag` frames have no predecessor (tsmotion 0)
 __global__ void tsm_prepare_kernel(const float* __restrict__ smotion, const float* __restrict__ tmotion,
                                    float* __restrict__ smesh, float* __restrict__ ws, int n, float img_h,
-                                   float img_w) {
+                                   float img_w, int lag) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * SS_NV) return;
     int k = idx / SS_NV, v = idx - k * SS_NV;
@@ -514,11 +516,11 @@ __global__ void tsm_prepare_kernel(const float* __restrict__ smotion, const floa
     float smx = __fadd_rn(rx, smotion[idx * 2]), smy = __fadd_rn(ry, smotion[idx * 2 + 1]);
     smesh[idx * 2] = smx;
     smesh[idx * 2 + 1] = smy;
-    if (k + 1 < n) {   // target of frame k+1 = normalised spatial mesh of frame k
-        ntgt[(long long)(k + 1) * 126 + v * 2] = norm1(smx, img_w);
-        ntgt[(long long)(k + 1) * 126 + v * 2 + 1] = norm1(smy, img_h);
+    if (k + lag < n) {   // target of frame k+lag = normalised spatial mesh of frame k
+        ntgt[(long long)(k + lag) * 126 + v * 2] = norm1(smx, img_w);
+        ntgt[(long long)(k + lag) * 126 + v * 2 + 1] = norm1(smy, img_h);
     }
-    if (k == 0) { ntgt[v * 2] = norm1(rx, img_w); ntgt[v * 2 + 1] = norm1(ry, img_h); }   // unused, keep defined
+    if (k < lag) { ntgt[(long long)k * 126 + v * 2] = norm1(rx, img_w); ntgt[(long long)k * 126 + v * 2 + 1] = norm1(ry, img_h); }   // unused, keep defined
     npts[(long long)k * 126 + v * 2] = norm1(__fadd_rn(rx, tmotion[idx * 2]), img_w);
     npts[(long long)k * 126 + v * 2 + 1] = norm1(__fadd_rn(ry, tmotion[idx * 2 + 1]), img_h);
 }
@@ -527,7 +529,7 @@ __global__ void tsm_prepare_kernel(const float* __restrict__ smotion, const floa
 // reference's `T.type(torch.float32)`); else T comes from the per-system elimination
 __global__ __launch_bounds__(256) void tsm_finish_kernel(const float* __restrict__ ws, const float* __restrict__ smesh,
                                                          const double* __restrict__ winv, float* __restrict__ tsmotion,
-                                                         int n, float img_h, float img_w) {
+                                                         int n, float img_h, float img_w, int lag) {
     __shared__ float sx[SS_NV], sy[SS_NV], Tx[SS_NT], Ty[SS_NT];
     __shared__ float tg[SS_NV * 2];
     int k = blockIdx.x, v = threadIdx.x;
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256) void tsm_finish_kernel(const float* __restrict
     __syncthreads();
     if (v >= SS_NV) return;
     long long o = ((long long)k * SS_NV + v) * 2;
-    if (k == 0) { tsmotion[o] = 0.f; tsmotion[o + 1] = 0.f; return; }
+    if (k < lag) { tsmotion[o] = 0.f; tsmotion[o + 1] = 0.f; return; }
     float ox, oy;
     tps_eval(sx, sy, Tx, Ty, npts[(long long)k * 126 + v * 2], npts[(long long)k * 126 + v * 2 + 1], ox, oy);
     tsmotion[o] = __fsub_rn(recover1(ox, img_w), smesh[o]);
@@ -558,19 +560,24 @@ __global__ __launch_bounds__(256) void tsm_finish_kernel(const float* __restrict
 
 extern "C" long long ss_tsmotion_workspace_floats(int n) { return 126 + (long long)n * (126 + 126 + 132); }
 
-extern "C" int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
-                           float img_h, float img_w, const double* rigid_winv, float* ws, void* stream) {
-    if (!smotion || !tmotion || !smesh || !tsmotion || !ws || n <= 0) return SS_ERR_ARG;
+extern "C" int ss_tsmotion_lag(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n, int lag,
+                               float img_h, float img_w, const double* rigid_winv, float* ws, void* stream) {
+    if (!smotion || !tmotion || !smesh || !tsmotion || !ws || n <= 0 || lag < 1) return SS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tsm_prepare_kernel, dim3(ss_cdiv(n * SS_NV, 128)), dim3(128), 0, st, smotion, tmotion, smesh, ws,
-                       n, img_h, img_w);
+                       n, img_h, img_w, lag);
     float* ntgt = ws + 126;
     float* T = ntgt + (long long)n * 252;
     if (!rigid_winv)
         hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, st, (const float*)ws, 0ll, (const float*)ntgt, (long long)SS_NV * 2, T);
     hipLaunchKernelGGL(tsm_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)ws, (const float*)smesh, rigid_winv,
-                       tsmotion, n, img_h, img_w);
+                       tsmotion, n, img_h, img_w, lag);
     return ss_launch_status();
+}
+
+extern "C" int ss_tsmotion(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n,
+                           float img_h, float img_w, const double* rigid_winv, float* ws, void* stream) {
+    return ss_tsmotion_lag(smotion, tmotion, smesh, tsmotion, n, 1, img_h, img_w, rigid_winv, ws, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -625,18 +632,33 @@ __global__ void mesh_normalize_kernel(const float* __restrict__ mesh, const floa
 
 // the same for view `view` of `views`, written where the render wants it: frame f's 63 points at out[(f * views + view) * 126]
 // (source [frames][views][63][2] assembled by `views` launches, no torch.stack)
+// bbox_fs: floats between the canvas boxes of consecutive frames (0: one box for all; 4: a box per frame -- S live streams with a
+// canvas each); mesh_fs: floats between consecutive frames' meshes (126 = packed)
 __global__ void mesh_normalize_views_kernel(const float* __restrict__ mesh, const float* __restrict__ bbox,
-                                            float* __restrict__ out, int npts, int view, int views, float img_h, float img_w) {
+                                            float* __restrict__ out, int npts, int view, int views, float img_h, float img_w,
+                                            int bbox_fs, long long mesh_fs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npts) return;
-    float wmin = bbox[0], wmax = bbox[1], hmin = bbox[2], hmax = bbox[3];
-    float ow = __fsub_rn(wmax, wmin), oh = __fsub_rn(hmax, hmin);
-    float x = img_w > 0.f ? __fmul_rn(mesh[i * 2], img_w) / 480.0f : mesh[i * 2];
-    float y = img_h > 0.f ? __fmul_rn(mesh[i * 2 + 1], img_h) / 360.0f : mesh[i * 2 + 1];
     const int f = i / SS_NV, k = i - f * SS_NV;
+    const float* bb = bbox + (long long)f * bbox_fs;
+    const float* m = mesh + (long long)f * mesh_fs + k * 2;
+    float wmin = bb[0], wmax = bb[1], hmin = bb[2], hmax = bb[3];
+    float ow = __fsub_rn(wmax, wmin), oh = __fsub_rn(hmax, hmin);
+    float x = img_w > 0.f ? __fmul_rn(m[0], img_w) / 480.0f : m[0];
+    float y = img_h > 0.f ? __fmul_rn(m[1], img_h) / 360.0f : m[1];
     float* o = out + (((long long)f * views + view) * SS_NV + k) * 2;
     o[0] = norm1(__fsub_rn(x, wmin), ow);
     o[1] = norm1(__fsub_rn(y, hmin), oh);
+}
+
+extern "C" int ss_mesh_normalize_views_boxes(const float* mesh, long long mesh_frame_stride, const float* bboxes, float* out,
+                                             int frames, int view, int views, float img_h, float img_w, void* stream) {
+    if (!mesh || !bboxes || !out || frames <= 0 || views <= 0 || view < 0 || view >= views || mesh_frame_stride < 126)
+        return SS_ERR_ARG;
+    const int npts = frames * SS_NV;
+    hipLaunchKernelGGL(mesh_normalize_views_kernel, dim3(ss_cdiv(npts, 256)), dim3(256), 0, (hipStream_t)stream, mesh, bboxes,
+                       out, npts, view, views, img_h, img_w, 4, mesh_frame_stride);
+    return ss_launch_status();
 }
 
 extern "C" int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,
@@ -644,7 +666,7 @@ extern "C" int ss_mesh_normalize_views(const float* mesh, const float* bbox, flo
     if (!mesh || !bbox || !out || frames <= 0 || views <= 0 || view < 0 || view >= views) return SS_ERR_ARG;
     const int npts = frames * SS_NV;
     hipLaunchKernelGGL(mesh_normalize_views_kernel, dim3(ss_cdiv(npts, 256)), dim3(256), 0, (hipStream_t)stream, mesh, bbox,
-                       out, npts, view, views, img_h, img_w);
+                       out, npts, view, views, img_h, img_w, 0, (long long)SS_NV * 2);
     return ss_launch_status();
 }
 

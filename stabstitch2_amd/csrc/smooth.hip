@@ -181,7 +181,7 @@ extern "C" int ss_smooth_stitch(const float* smesh1, const float* smesh2, const 
 struct WinPushArgs { long long src_off[8]; };
 __global__ __launch_bounds__(256) void window_push_kernel(float* __restrict__ ring, const float* __restrict__ src,
                                                           WinPushArgs a, int R, int W, int E, float* __restrict__ state,
-                                                          int blocks, int block, long long stride, long long delta) {
+                                                          int blocks, int block, long long stride, long long delta, int per) {
     const int r = blockIdx.x, tid = threadIdx.x;
     if (r == R) {                                        // the state move (source and destination never overlap: delta >= block)
         for (int i = tid; i < blocks * block; i += 256) {
@@ -205,18 +205,27 @@ __global__ __launch_bounds__(256) void window_push_kernel(float* __restrict__ ri
         const int i = tid + 256 * k;
         if (i < keep) g[i] = v[k];
     }
-    for (int e = tid; e < E; e += 256) g[keep + e] = src[a.src_off[r] + e];
+    for (int e = tid; e < E; e += 256) g[keep + e] = src[a.src_off[r / per] + (long long)(r % per) * E + e];
 }
 
-extern "C" int ss_window_push(float* ring, const float* src, const long long* src_off, int rings, int window, int elems,
-                              float* state, int blocks, int block, long long stride, long long delta, void* stream) {
-    if (!ring || !src || !src_off || rings <= 0 || rings > 8 || window < 2 || elems <= 0 ||
+// groups x per rings: ring g * per + j takes the row at src + src_off[g] + j * elems (per = S streams advancing together, one
+// offset per ring KIND; per = 1: one offset per ring)
+extern "C" int ss_window_push_groups(float* ring, const float* src, const long long* src_off, int groups, int per, int window,
+                                     int elems, float* state, int blocks, int block, long long stride, long long delta,
+                                     void* stream) {
+    const int rings = groups * per;
+    if (!ring || !src || !src_off || groups <= 0 || groups > 8 || per <= 0 || per > 4096 || window < 2 || elems <= 0 ||
         (long long)(window - 1) * elems > 2048 || blocks < 0 || (blocks > 0 && (!state || block <= 0 || delta < block)) ||
         (blocks > 1 && stride < delta + block))       // block b + 1's destination must not reach into block b's source
         return SS_ERR_ARG;
     WinPushArgs a;
-    for (int r = 0; r < 8; ++r) a.src_off[r] = r < rings ? src_off[r] : 0;
+    for (int r = 0; r < 8; ++r) a.src_off[r] = r < groups ? src_off[r] : 0;
     hipLaunchKernelGGL(window_push_kernel, dim3(rings + (blocks > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, ring, src, a,
-                       rings, window, elems, state, blocks, block, stride, delta);
+                       rings, window, elems, state, blocks, block, stride, delta, per);
     return ss_launch_status();
+}
+
+extern "C" int ss_window_push(float* ring, const float* src, const long long* src_off, int rings, int window, int elems,
+                              float* state, int blocks, int block, long long stride, long long delta, void* stream) {
+    return ss_window_push_groups(ring, src, src_off, rings, 1, window, elems, state, blocks, block, stride, delta, stream);
 }

@@ -66,6 +66,10 @@ class OnlineStitcher:
         """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc] (written to `out` if given)."""
         src = ops.mesh_normalize_views([mesh1, mesh2], self.bbox, self.h, self.w)[0]          # [2,63,2]
         T = ops.tps_solve_shared(src, self.nrigid)
+        return self._render_solved(hr1, hr2, src, T, out)
+
+    def _render_solved(self, hr1, hr2, src, T, out=None):
+        """src [2,63,2] normalised control points on this stream's canvas, T [2,2,66] their splines -> stitched frame."""
         if self.fusion_mode == 'AVERAGE':
             fp = None
             if pipeline.SKIP_OUTSIDE:        # same footprint skipping as the offline render (pipeline.render_frames)
@@ -213,3 +217,145 @@ class OnlineStitcher:
             self._init_static()              # from the next push on: static buffers (+ HIP graph)
             return frames
         return [self._render(hr1, hr2, m1[-1:], m2[-1:])]
+
+
+class MultiOnlineStitcher:
+    """S independent live video pairs advancing one frame per push as ONE batch (the sharding unit of the
+    path -- independent streams -- inside one GPU).  A single stream at batch 1 is launch-bound (~150 small launches per
+    pushed pair); S streams run the same launches on S-fold batches, so the aggregate frame rate grows almost linearly until
+    the kernels fill the chip.  Every stream keeps its own sliding window, cached TemporalNet features and FIXED canvas
+    (canvases may differ in size); per stream and push the arithmetic is the single-stream stitcher's (test_online_tra.py:
+    284-392 with k = t) -- the networks see the S pairs as one batch, the render goes stream by stream.
+
+        st = MultiOnlineStitcher(nets, 720, 1280, streams=8)
+        frames = st.push(hr1, hr2, lr1, lr2)      # hr* [S,3,H,W], lr* [S,3,360,480] -> S lists of new frames [3,Hc_s,Wc_s]
+
+    The first WINDOW pushes fill every stream's window through S single-stream stitchers (eager); from then on the step runs
+    on static buffers with a leading S and is captured into one HIP graph.  Results equal S single-stream stitchers up to the
+    conv engine's launch-size-dependent kernel choice (Winograd / implicit GEMM / split-K are picked per launch size, so a
+    batch of S sums in another order than S batches of one: motions differ by ~1e-5 px); within a batch every stream's result
+    is independent of its neighbours bit for bit (tests/test_gpu_round4.py)."""
+
+    def __init__(self, nets, height, width, streams, canvases=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
+                 use_graph=True):
+        self.nets = nets
+        self.spatial, self.temporal, self.smooth = nets
+        self.dev = next(self.spatial.parameters()).device
+        self.h, self.w, self.S = height, width, int(streams)
+        if self.S < 1:
+            raise ValueError('streams must be >= 1')
+        if canvases is not None and len(canvases) != self.S:
+            raise ValueError('one canvas per stream')
+        self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
+        self.single = [OnlineStitcher(nets, height, width, None if canvases is None else canvases[s], margin, warp_mode,
+                                      fusion_mode, use_graph=False) for s in range(self.S)]
+        self.use_graph = use_graph
+        self.static = None
+        self.graph = None
+        self.trunk_pair = None
+        self.trunk_versions = None
+        self.frames_in = 0
+
+    @property
+    def canvas_sizes(self):
+        """[(Hc, Wc)] per stream (None before the first window is complete)."""
+        return [(s.hc, s.wc) for s in self.single]
+
+    def _versions(self):
+        return (self.spatial.weights_version, self.temporal.weights_version, self.smooth.weights_version)
+
+    _STATE = ('prev_feat', 'pair_s', 'ring')
+
+    def _init_static(self):
+        """Batched steady-state buffers from the S single-stream states (each has just completed its first window):
+          pair_s / pair_t [2 views][prev, new][S][126], ring [4 kinds][S][7][126], prev_feat [2 views * S,45,60,128] view-major."""
+        d, S, e = self.dev, self.S, 126
+        one = [s.static for s in self.single]
+        st = {'hr1': torch.empty((S, 3, self.h, self.w), device=d), 'hr2': torch.empty((S, 3, self.h, self.w), device=d),
+              'lr1': torch.empty((S, 3, pipeline.LR_H, pipeline.LR_W), device=d),
+              'lr2': torch.empty((S, 3, pipeline.LR_H, pipeline.LR_W), device=d),
+              'prev_feat': torch.cat([torch.stack([o['prev_feat'][v] for o in one], 0) for v in range(2)], 0).contiguous(),
+              'pair_s': torch.stack([o['pair_s'] for o in one], 2).contiguous(),           # [2,2,S,126]
+              'pair_t': torch.zeros((2, 2, S, e), device=d),
+              'ring': torch.stack([o['ring'] for o in one], 1).contiguous(),               # [4,S,7,126]
+              'ts_out': torch.empty((2, 4 * S, e), device=d),
+              'bboxes': torch.stack([s.bbox for s in self.single], 0).contiguous(),        # [S,4] the streams' fixed canvases
+              'out': [torch.empty((3, s.hc, s.wc), device=d) for s in self.single]}
+        self.static = st
+        for s in self.single:                     # the per-stream buffers are not needed any more (bbox / canvas stay)
+            s.static = None
+
+    def _step_static(self):
+        st, S, e = self.static, self.S, 126
+        if self.trunk_pair is None:
+            self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
+            self.trunk_versions = self._versions()
+        f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)            # [2(net), 2S (view-major), 45,60,128]
+        off1, off_ref, off_tgt = self.spatial.forward_features(f2[0], S, pipeline.LR_H, pipeline.LR_W)
+        ps, pt = st['pair_s'], st['pair_t']
+        ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W,
+                           out=(ps[0, 1].view(S, 7, 9, 2), ps[1, 1].view(S, 7, 9, 2)))
+        feat = f2[1]
+        self.temporal.motions_from_features(st['prev_feat'], feat, out_slices=[(0, S, pt[0, 1]), (S, 2 * S, pt[1, 1])])
+        st['prev_feat'].copy_(feat)
+        # tsmotion of all streams and both views as ONE batch of 4 S frames laid out [view][prev, new][stream]: frame k pairs
+        # with frame k - S (its own stream's previous frame); the rows of the `prev` halves are computed and ignored
+        ops.tsmotion(ps.view(4 * S, 7, 9, 2), pt.view(4 * S, 7, 9, 2), pipeline.LR_H, pipeline.LR_W,
+                     out=(st['ts_out'][0], st['ts_out'][1]), lag=S)
+        # shift the 4 S rings, append this push's rows (smesh v0, smesh v1, tsm v0, tsm v1 of every stream), and make the
+        # current spatial motions the previous ones
+        ops.window_push(st['ring'], st['ts_out'], [1 * S * e, 3 * S * e, (4 * S + 1 * S) * e, (4 * S + 3 * S) * e], state=ps,
+                        blocks=2, block=S * e, stride=2 * S * e, delta=S * e, per=S)
+        r = st['ring'].view(4, S * WINDOW, 7, 9, 2)
+        outs, _ = self.smooth.run_windows(r[0], r[1], r[2], r[3], S, WINDOW, WINDOW, 1)       # S windows, one per stream
+        m1, m2 = outs['smooth_mesh1'], outs['smooth_mesh2']                                    # [S,7,7,9,2]
+        # every stream's newest smoothed mesh on its own canvas: one normalisation launch per view and ONE batched TPS solve for
+        # the 2 S splines (a solve is latency-bound, ~48 us whether it holds 2 systems or 16), then the render stream by stream
+        src = ops.mesh_normalize_views_boxes([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w)     # [S,2,63,2]
+        T = ops.tps_solve_shared(src.view(2 * S, 63, 2), self.single[0].nrigid).view(S, 2, 2, 66)
+        for s, one in enumerate(self.single):
+            one._render_solved(st['hr1'][s:s + 1], st['hr2'][s:s + 1], src[s], T[s], out=st['out'][s])
+
+    def _push_static(self, hr1, hr2, lr1, lr2):
+        st = self.static
+        if self.trunk_pair is not None and self.trunk_versions != self._versions():
+            self.trunk_pair = None           # a net was reloaded / moved: restack the twin trunk and recapture
+            self.graph = None
+        st['hr1'].copy_(hr1); st['hr2'].copy_(hr2); st['lr1'].copy_(lr1); st['lr2'].copy_(lr2)
+        if not self.use_graph:
+            self._step_static()
+        elif self.graph is None:
+            keep = {k: st[k].clone() for k in self._STATE}
+            side = _warmup_stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self._step_static()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            for k, v in keep.items():
+                st[k].copy_(v)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_static()
+            self.graph = g
+            for k, v in keep.items():
+                st[k].copy_(v)
+            self.graph.replay()
+        else:
+            self.graph.replay()
+        self.frames_in += 1
+        return [[o.clone()] for o in st['out']]
+
+    @torch.no_grad()
+    def push(self, hr1, hr2, lr1, lr2):
+        """One frame pair of every stream: hr* [S,3,H,W] (0..255), lr* [S,3,360,480] ([-1,1]), device tensors.
+        -> S lists of newly stitched frames (empty for the first 6 pushes, 7 frames each on the 7th, then one per push)."""
+        S = self.S
+        if hr1.shape[0] != S or hr2.shape[0] != S or lr1.shape[0] != S or lr2.shape[0] != S:
+            raise ValueError('expected %d streams per push' % S)
+        if self.static is not None:
+            return self._push_static(hr1, hr2, lr1, lr2)
+        outs = [one.push(hr1[s:s + 1], hr2[s:s + 1], lr1[s:s + 1], lr2[s:s + 1]) for s, one in enumerate(self.single)]
+        self.frames_in += 1
+        if self.single[0].static is not None:      # every stream's first window is complete: switch to the batched step
+            self._init_static()
+        return outs

@@ -476,8 +476,9 @@ def rigid_winv(img_h, img_w, device):
     return ent.get(device)
 
 
-def tsmotion(smotion, tmotion, img_h=360, img_w=480, out=None):
-    """smotion, tmotion [n,7,9,2] -> (smesh, tsmotion) [n,7,9,2] (out: the two preallocated result tensors)."""
+def tsmotion(smotion, tmotion, img_h=360, img_w=480, out=None, lag=1):
+    """smotion, tmotion [n,7,9,2] -> (smesh, tsmotion) [n,7,9,2] (out: the two preallocated result tensors).
+    lag: frame k pairs with frame k - lag (S interleaved streams advancing together: lag = S)."""
     n = smotion.shape[0]
     ws = torch.empty(int(H.lib().ss_tsmotion_workspace_floats(n)), device=smotion.device, dtype=torch.float32)
     if out is None:
@@ -487,26 +488,32 @@ def tsmotion(smotion, tmotion, img_h=360, img_w=480, out=None):
         smesh, tsm = out
         assert smesh.numel() == n * 126 and tsm.numel() == n * 126 and smesh.is_contiguous() and tsm.is_contiguous()
     winv = rigid_winv(img_h, img_w, smotion.device) if RIGID_INVERSE_CACHE else None
-    H.call('ss_tsmotion', H.dptr(_f(smotion)), H.dptr(_f(tmotion)), H.dptr(smesh), H.dptr(tsm), n, float(img_h),
+    H.call('ss_tsmotion_lag', H.dptr(_f(smotion)), H.dptr(_f(tmotion)), H.dptr(smesh), H.dptr(tsm), n, int(lag), float(img_h),
            float(img_w), H.dptr(winv, True, dtype=torch.float64), H.dptr(ws), H.stream())
     return smesh, tsm
 
 
-def window_push(ring, src, src_off, state=None, blocks=0, block=0, stride=0, delta=0):
+def window_push(ring, src, src_off, state=None, blocks=0, block=0, stride=0, delta=0, per=1):
     """Streaming mode: ring [R,W,...] (contiguous, fixed address) drops slot 0 of every ring and appends the row at
     src.flatten()[src_off[r]:][:E]; optionally moves `blocks` blocks of `block` floats inside `state` (block b at b * stride
-    <- the floats `delta` further) in the same launch (ss_window_push)."""
+    <- the floats `delta` further) in the same launch (ss_window_push).
+    per > 1: ring [G, per, W, ...] -- G ring kinds x `per` streams, ring (g, j) takes src.flatten()[src_off[g] + j * E:][:E]."""
     import ctypes
-    r, w = ring.shape[0], ring.shape[1]
-    e = ring[0, 0].numel()
+    if per > 1:
+        r, w = ring.shape[0], ring.shape[2]
+        e = ring[0, 0, 0].numel()
+        assert ring.shape[1] == per
+    else:
+        r, w = ring.shape[0], ring.shape[1]
+        e = ring[0, 0].numel()
     assert ring.is_contiguous() and src.is_contiguous() and len(src_off) == r
-    assert all(0 <= o and o + e <= src.numel() for o in src_off)
+    assert all(0 <= o and o + per * e <= src.numel() for o in src_off)
     if blocks:
         assert state.is_contiguous() and (blocks - 1) * stride + delta + block <= state.numel()
         assert delta >= block and (blocks == 1 or stride >= delta + block), 'window_push: overlapping state blocks'
     offs = (ctypes.c_longlong * r)(*src_off)
-    H.call('ss_window_push', H.dptr(ring), H.dptr(src), ctypes.cast(offs, ctypes.c_void_p), r, w, e, H.dptr(state, True),
-           blocks, block, stride, delta, H.stream())
+    H.call('ss_window_push_groups', H.dptr(ring), H.dptr(src), ctypes.cast(offs, ctypes.c_void_p), r, per, w, e,
+           H.dptr(state, True), blocks, block, stride, delta, H.stream())
     return ring
 
 
@@ -727,6 +734,18 @@ def mesh_normalize_views(meshes, bbox, img_h, img_w):
         m = _f(m)
         assert m.numel() == n * 126
         H.call('ss_mesh_normalize_views', H.dptr(m), H.dptr(bbox), H.dptr(out), n, k, v, float(img_h), float(img_w), H.stream())
+    return out
+
+
+def mesh_normalize_views_boxes(meshes, frame_stride, bboxes, img_h, img_w):
+    """Per-frame canvases: meshes = list of V tensors whose frame f starts `frame_stride` floats after frame f - 1 (the tensor
+    handed in starts at frame 0's mesh); bboxes [n,4] -> [n,V,63,2]."""
+    n, v = bboxes.shape[0], len(meshes)
+    out = torch.empty((n, v, 63, 2), device=bboxes.device, dtype=torch.float32)
+    for k, m in enumerate(meshes):
+        assert m.is_contiguous() and m.dtype == torch.float32
+        H.call('ss_mesh_normalize_views_boxes', H.dptr(m), int(frame_stride), H.dptr(bboxes), H.dptr(out), n, k, v, float(img_h),
+               float(img_w), H.stream())
     return out
 
 

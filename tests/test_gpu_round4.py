@@ -190,3 +190,72 @@ def test_bench_two_ranks_share_one_gpu():
     # whole-job value = frames of both ranks / slowest rank
     assert abs(d['value'] - 2 * 8 * 2 / max(d['per_rank_seconds'])) < 1e-2 * d['value']
     assert d['scaling'] == 'weak' and 'x 2 GPUs = configs[3]' in d['config']['workload']
+
+
+# ------------------------------------------------------------------ batch-of-streams streaming mode
+def _stream_inputs(S, n, h, w, dev, seeds):
+    hrs, lrs = [], []
+    for sd in seeds:
+        hr, lr = synth.make_clip_device(n, h, w, seed=sd, device=dev)
+        hrs.append(hr)
+        lrs.append(lr)
+    # [view][stream][frame] -> per push t: [S,3,H,W]
+    hr = [torch.stack([hrs[s][v] for s in range(S)], 0) for v in range(2)]          # [S,n,3,H,W]
+    lr = [torch.stack([lrs[s][v] for s in range(S)], 0) for v in range(2)]
+    return hr, lr
+
+
+def test_multi_stream_matches_single_streams(dev, hip_nets):
+    """MultiOnlineStitcher(streams=4) against four OnlineStitchers fed the same frames: the first window is the single-stream
+    code (bit-identical); in the steady state the networks see the four pairs as one batch, and the conv engine picks its
+    kernel (Winograd / implicit GEMM / split-K) by launch size -- another summation order, motions ~1e-5 px apart -- so the
+    frames are compared with a tolerance far below the path's parity gates.  Graph replay == eager, bit for bit."""
+    from stabstitch2_amd.online import MultiOnlineStitcher, OnlineStitcher
+    S, n, h, w = 4, 12, 360, 480
+    hr, lr = _stream_inputs(S, n, h, w, dev, seeds=[0, 1, 2, 3])
+    multi = MultiOnlineStitcher(hip_nets, h, w, streams=S)
+    eager = MultiOnlineStitcher(hip_nets, h, w, streams=S, use_graph=False)
+    single = [OnlineStitcher(hip_nets, h, w) for _ in range(S)]
+    worst = 0.0
+    for t in range(n):
+        args = (hr[0][:, t].contiguous(), hr[1][:, t].contiguous(), lr[0][:, t].contiguous(), lr[1][:, t].contiguous())
+        got = multi.push(*args)
+        ge = eager.push(*args)
+        for s in range(S):
+            want = single[s].push(args[0][s:s + 1], args[1][s:s + 1], args[2][s:s + 1], args[3][s:s + 1])
+            assert len(got[s]) == len(want) == len(ge[s])
+            for a, b, c in zip(got[s], want, ge[s]):
+                assert a.shape == b.shape
+                assert torch.equal(a, c), 'graph replay differs from eager'
+                if t < 7:
+                    assert torch.equal(a, b)
+                else:
+                    # (the reference's clamped sampler steps from full intensity to 0 across the last image row / column, A6: a
+                    # coordinate 1e-5 px apart can flip single edge pixels by a whole grey value -- counted, not bounded)
+                    d = (a - b).abs()
+                    worst = max(worst, float(d.median()))
+                    flips = float((d > 5e-2).float().mean())
+                    assert flips < 1e-4 and float(d.mean()) < 2e-3, (t, s, flips, float(d.mean()))
+    assert multi.canvas_sizes == [(x.hc, x.wc) for x in single]
+    if os.environ.get('SS_VERBOSE'):
+        print('multi vs single streams: worst median |diff| %.2e grey levels' % worst)
+
+
+def test_multi_stream_streams_are_independent(dev, hip_nets):
+    """Within a batch a stream's frames do not depend on its neighbours: duplicates of one stream give identical bytes, and
+    swapping the other streams changes nothing."""
+    from stabstitch2_amd.online import MultiOnlineStitcher
+    n, h, w = 10, 360, 480
+    hr, lr = _stream_inputs(3, n, h, w, dev, seeds=[5, 6, 5])
+    perm = [1, 0, 2]
+    a = MultiOnlineStitcher(hip_nets, h, w, streams=3)
+    b = MultiOnlineStitcher(hip_nets, h, w, streams=3)
+    for t in range(n):
+        x = [hr[0][:, t].contiguous(), hr[1][:, t].contiguous(), lr[0][:, t].contiguous(), lr[1][:, t].contiguous()]
+        ga = a.push(*x)
+        gb = b.push(*[v[perm].contiguous() for v in x])
+        for fa, fc in zip(ga[0], ga[2]):
+            assert torch.equal(fa, fc)
+        for s in range(3):
+            for fa, fb in zip(ga[perm[s]], gb[s]):
+                assert torch.equal(fa, fb)
