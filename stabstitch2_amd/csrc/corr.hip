@@ -18,13 +18,22 @@ extern "C" int ss_conv_nhwc(const float*, const float*, const float*, const floa
 template <int R>
 __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volume_kernel(
     const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ out, int h, int w, int c,
-    int out_cs, int n_fwd) {
+    int out_cs, int n_fwd, int n_img, int tiles_x, int tiles_y) {
     constexpr int KD = 2 * R + 1;
     constexpr int D = KD * KD;
     constexpr int NT = 64 * ((16 * KD + 63) / 64);      // threads per block (176 -> 192, 112 -> 128)
     constexpr int WH = CV_TY + 2 * R;
-    constexpr int WW = ((CV_TX + 2 * R + 3) / 4) * 4;   // 26 -> 28, 22 -> 24: rows stay 16-byte aligned
-    constexpr int WPIX = WH * WW;
+    // LDS layout of one channel plane of the x2 window (rows of 26 / 22 floats = 7 / 6 slots of 16 bytes).  A ds_read_b128 is
+    // served 16 lanes at a time (MI355X_MICROARCH.md, LDS: groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) over the 16 slots
+    // of a 256-byte bank row; with this kernel's lane map a group holds the chunks g .. g+3 of THREE window rows -- r, r+2, r+3 or
+    // r+1, r+2, r+4 (the fourth quad of lanes repeats one of them: a broadcast).  Under a plain row pitch of 28 / 24 floats two of
+    // those rows overlapped in two slots: every read took two LDS cycles (rocprofv3 r03: 0.42 of the kernel's LDS cycles were
+    // bank-conflict stalls).  Here row r starts at bank slot 4 r mod 16, so rows one, two and three apart are 4, 8 and 12 slots
+    // apart and a group's three 4-slot runs never meet; storage stays compact because rows r and r + 2 share one 16-slot line
+    // (slots 4r .. 4r+6 and 4r+8 .. 4r+14): line(r) = 2 (r >> 2) + (r & 1), address = 64 line + 4 ((4 r + chunk) & 15) floats.
+    constexpr int WLINES = 2 * ((WH + 3) / 4);
+    static_assert(CV_TX + 2 * R <= 28, "a window row must fit 7 slots");
+    constexpr int WPIX = WLINES * 64;
     constexpr int NV = 4 + 2 * R;                       // x2 values per thread per channel (14 / 10)
     constexpr int OUTF = CV_TY * CV_TX * (D + 3);       // staging for the epilogue
     // Channel planes in groups of four (one staged item = the 4 channels of a pixel, written by one lane in four instructions):
@@ -39,31 +48,44 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
     __shared__ __attribute__((aligned(16))) float s1f[(CV_CC / 4) * QP1];
 
     const int tid = threadIdx.x;
-    // blockIdx.z < n_fwd: cv(x1, x2) of image z; >= n_fwd: the OTHER direction cv(x2, x1) of image z - n_fwd, written behind the
+    // image n < n_fwd: cv(x1, x2) of image n; >= n_fwd: the OTHER direction cv(x2, x1) of image n - n_fwd, written behind the
     // n_fwd forward volumes (both directions of SpatialNet's stage 2, spatial_network.py:318,325, in one launch: 2 x 1536 workgroups
     // are exactly three rounds of the chip where two launches of 1.5 rounds each cost four)
-    int n = blockIdx.z;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  In the natural order the
+    // neighbouring tiles of an image -- which share most of their 14 x 26-pixel windows (5.7 window pixels are staged per
+    // output pixel) -- land on eight different L2s and every halo is fetched again from the MALL; here XCD k walks one
+    // contiguous eighth of the tile list, so a tile's neighbours are the same L2's recent work.
+    const int total = tiles_x * tiles_y * n_img;
+    const int per = (total + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || tile >= total) return;
+    const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y;
+    int n = tile / (tiles_x * tiles_y);
     if (n >= n_fwd) {
         const float* t = x1; x1 = x2; x2 = t;
         out += (long long)n_fwd * h * w * out_cs;
         n -= n_fwd;
     }
-    const int y0 = blockIdx.y * CV_TY, x0 = blockIdx.x * CV_TX;
+    const int y0 = by * CV_TY, x0 = bx * CV_TX;
     const bool active = tid < 16 * KD;
     const int pg = tid & 15, j = active ? tid >> 4 : 0;   // pixel group (py, 4g) and displacement row
     const int py = pg >> 2, g4 = (pg & 3) * 4;
-    // (Eight lanes of a 16-byte read = the four g4 of two ADJACENT window rows, one row pitch apart: 3 of the 4 chunks of the
-    // second row share banks with the first.  A lane map that pairs rows half a bank cycle apart instead -- 4 rows at R = 5,
-    // 2 at R = 3 -- removes those conflicts but needs 256 threads with 80 idle lanes at R = 5: measured 181-190 us against
-    // 166-168 for both directions of 32 pairs, equal at R = 3.  Not adopted.)
+    // (Eight lanes of a 16-byte read = the four g4 of two ADJACENT window rows.  Round 3 tried a lane map that pairs rows half a
+    // bank cycle apart -- 256 threads with 80 idle lanes at R = 5: slower.  Round 4 rotates the odd rows' chunks instead, above.)
     const float* x1n = x1 + (long long)n * h * w * c;
     const float* x2n = x2 + (long long)n * h * w * c;
 
-    float acc[4][KD];
+    // accumulators as PAIRS for v_pk_fma_f32 (two fp32 FMAs per issue slot): (p, 2 i2), (p, 2 i2 + 1) share a[p]; the odd last
+    // displacement pairs over p.  Each accumulator still receives its products in channel order: same bits as scalar FMAs.
+    typedef float cv_f2 __attribute__((ext_vector_type(2)));
+    constexpr int KP = KD / 2;
+    cv_f2 accp[4][KP], accl[2];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int i = 0; i < KD; ++i) acc[p][i] = 0.f;
+        for (int i = 0; i < KP; ++i) accp[p][i] = (cv_f2){0.f, 0.f};
+    accl[0] = (cv_f2){0.f, 0.f};
+    accl[1] = (cv_f2){0.f, 0.f};
 
     // staging items of this thread (fixed over the channel loop): x2 window [row][col][quad], x1 tile [pixel][quad];
     // element offset of channel 0 of the quad, or -1 outside the image.  The loads of chunk c0 + 16 are issued into
@@ -83,7 +105,7 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
         const int yy = y0 - R + wy, xx = x0 - R + wx;
         const bool in = e < WH * (CV_TX + 2 * R) * (CV_CC / 4);
         o2[k] = (in && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? (yy * w + xx) * c + q * 4 : -1;
-        l2[k] = in ? q * QP2 + wy * WW + wx : -1;
+        l2[k] = in ? q * QP2 + (2 * (wy >> 2) + (wy & 1)) * 64 + (((4 * wy + (wx >> 2)) & 15) << 2) + (wx & 3) : -1;
     }
 #pragma unroll
     for (int k = 0; k < N1; ++k) {
@@ -93,6 +115,13 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
         const bool in = e < CV_TY * CV_TX * (CV_CC / 4);
         o1[k] = (in && yy < h && xx < w) ? (yy * w + xx) * c + q * 4 : -1;
         l1[k] = in ? q * QP1 + pp : -1;
+    }
+    // the thread's window row py + j: float offsets of its chunks g .. g + 3
+    int roff[(NV + 3) / 4];
+    {
+        const int wr = py + j;
+#pragma unroll
+        for (int q = 0; q < (NV + 3) / 4; ++q) roff[q] = (2 * (wr >> 2) + (wr & 1)) * 64 + (((4 * wr + (g4 >> 2) + q) & 15) << 2);
     }
     float4 r2[N2], r1[N1];
     auto fetch = [&](int c0) {
@@ -129,21 +158,26 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
             for (int cc = 0; cc < CV_CC; ++cc) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&s1f[(cc >> 2) * QP1 + (cc & 3) * (CV_TY * CV_TX) + py * 16 + g4]);
                 const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-                const float* row = s2 + (cc >> 2) * QP2 + (cc & 3) * WPIX + (py + j) * WW + g4;
+                const float* row = s2 + (cc >> 2) * QP2 + (cc & 3) * WPIX;
                 float v[NV];
 #pragma unroll
                 for (int q = 0; q < NV / 4; ++q) {
-                    float4 t = *reinterpret_cast<const float4*>(row + 4 * q);
+                    float4 t = *reinterpret_cast<const float4*>(row + roff[q]);
                     v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
                 }
                 if (NV % 4) {
-                    float2 t = *reinterpret_cast<const float2*>(row + 4 * (NV / 4));
+                    float2 t = *reinterpret_cast<const float2*>(row + roff[NV / 4]);
                     v[NV - 2] = t.x; v[NV - 1] = t.y;
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4; ++p) {
+                    const cv_f2 ap = {a[p], a[p]};
 #pragma unroll
-                    for (int i = 0; i < KD; ++i) acc[p][i] = fmaf(a[p], v[p + i], acc[p][i]);
+                    for (int i = 0; i < KP; ++i)
+                        accp[p][i] = __builtin_elementwise_fma(ap, (cv_f2){v[p + 2 * i], v[p + 2 * i + 1]}, accp[p][i]);
+                }
+                accl[0] = __builtin_elementwise_fma((cv_f2){a[0], a[1]}, (cv_f2){v[KD - 1], v[KD]}, accl[0]);
+                accl[1] = __builtin_elementwise_fma((cv_f2){a[2], a[3]}, (cv_f2){v[KD + 1], v[KD + 2]}, accl[1]);
             }
         }
         __syncthreads();
@@ -155,7 +189,9 @@ __global__ __launch_bounds__(64 * ((16 * (2 * R + 1) + 63) / 64)) void cost_volu
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int i = 0; i < KD; ++i) {
-                float v = acc[p][i] / fc;
+                const float av = i < 2 * KP ? ((i & 1) ? accp[p][i >> 1].y : accp[p][i >> 1].x)
+                                            : ((p & 1) ? accl[p >> 1].y : accl[p >> 1].x);
+                float v = av / fc;
                 s2[(py * 16 + g4 + p) * (D + 3) + j * KD + i] = v > 0.f ? v : 0.1f * v;
             }
     }
@@ -174,10 +210,12 @@ extern "C" int ss_cost_volume(const float* x1, const float* x2, float* out, int 
     if (!x1 || !x2 || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return SS_ERR_ARG;
     int D = (2 * r + 1) * (2 * r + 1);
     if (out_cs < D) return SS_ERR_ARG;
-    dim3 g(ss_cdiv(w, CV_TX), ss_cdiv(h, CV_TY), n);
+    const int tx = ss_cdiv(w, CV_TX), ty = ss_cdiv(h, CV_TY);
+    if ((long long)tx * ty * n > (1ll << 30)) return SS_ERR_UNSUPPORTED;
+    dim3 g(8 * ss_cdiv((long long)tx * ty * n, 8));
     hipStream_t st = (hipStream_t)stream;
-    if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n);
-    else if (r == 3) hipLaunchKernelGGL((cost_volume_kernel<3>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n);
+    if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n, n, tx, ty);
+    else if (r == 3) hipLaunchKernelGGL((cost_volume_kernel<3>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n, n, tx, ty);
     else return SS_ERR_UNSUPPORTED;
     return ss_launch_status();
 }
@@ -188,10 +226,12 @@ extern "C" int ss_cost_volume_bidir(const float* x1, const float* x2, float* out
     if (!x1 || !x2 || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || 2 * n > 65535) return SS_ERR_ARG;
     int D = (2 * r + 1) * (2 * r + 1);
     if (out_cs < D) return SS_ERR_ARG;
-    dim3 g(ss_cdiv(w, CV_TX), ss_cdiv(h, CV_TY), 2 * n);
+    const int tx = ss_cdiv(w, CV_TX), ty = ss_cdiv(h, CV_TY);
+    if ((long long)tx * ty * 2 * n > (1ll << 30)) return SS_ERR_UNSUPPORTED;
+    dim3 g(8 * ss_cdiv((long long)tx * ty * 2 * n, 8));
     hipStream_t st = (hipStream_t)stream;
-    if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n);
-    else if (r == 3) hipLaunchKernelGGL((cost_volume_kernel<3>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n);
+    if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n, 2 * n, tx, ty);
+    else if (r == 3) hipLaunchKernelGGL((cost_volume_kernel<3>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n, 2 * n, tx, ty);
     else return SS_ERR_UNSUPPORTED;
     return ss_launch_status();
 }
