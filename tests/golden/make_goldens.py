@@ -273,8 +273,29 @@ def g10():
         ns.update(warp12_mesh1=m12_1.clone(), warp12_mesh2=m12_2.clone(), warp23_mesh1=m23_1.clone(),
                   warp23_mesh2=m23_2.clone(), img1_list=hr[0], img2_list=hr[1], img3_list=hr[2],
                   args=types.SimpleNamespace(warp_mode=wm, fusion_mode=fm))
+        if fm == 'LINEAR':
+            # record what the reference's blender sees and decides, per call (two chained calls per frame, threeview:498-501):
+            # the warped masks, the nonzero counts and centroids its weights hang on, and its mask1
+            calls = []
+            ref_blender = ns['linear_blender']
+
+            def spy(ref, tgt, ref_m, tgt_m, mask=False, _f=ref_blender, _calls=calls):
+                r1, c1 = torch.nonzero(ref_m[0, 0], as_tuple=True)
+                r2, c2 = torch.nonzero(tgt_m[0, 0], as_tuple=True)
+                _calls.append(dict(count=np.array([r1.numel(), r2.numel()]),
+                                   center=np.array([float(r1.float().mean()), float(c1.float().mean()),
+                                                    float(r2.float().mean()), float(c2.float().mean())]),
+                                   ref_m=cases.box_down(ref_m[0, 0].numpy()[..., None], 4)[..., 0],
+                                   tgt_m=cases.box_down(tgt_m[0, 0].numpy()[..., None], 4)[..., 0],
+                                   mask1=cases.box_down(_f(ref, tgt, ref_m, tgt_m, True)[0, 0].numpy()[..., None], 4)[..., 0]))
+                return _f(ref, tgt, ref_m, tgt_m, mask)
+            ns['linear_blender'] = spy
         exec(compile(body, 'threeview_345_505', 'exec'), ns)
         tag = fm.lower()
+        if fm == 'LINEAR':
+            assert len(calls) == 2 * n
+            for key in ('count', 'center', 'ref_m', 'tgt_m', 'mask1'):
+                res['lin_' + key] = np.stack([np.stack([calls[2 * i][key], calls[2 * i + 1][key]]) for i in range(n)])
         res['canvas_' + tag] = np.array([int(ns['out_height'].int()), int(ns['out_width'].int())])
         res['frames_' + tag] = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), 4)
                                          for f in ns['stable_list']])
@@ -311,8 +332,29 @@ def g12(nets):
                   warp23_mesh1=a23['smooth_mesh1'].clone(), warp23_mesh2=a23['smooth_mesh2'].clone(),
                   img1_list=hr[0], img2_list=hr[1], img3_list=hr[2],
                   args=types.SimpleNamespace(warp_mode=wm, fusion_mode=fm))
+        if fm == 'LINEAR':
+            # record what the reference's blender sees and decides, per call (two chained calls per frame, threeview:498-501):
+            # the warped masks, the nonzero counts and centroids its weights hang on, and its mask1
+            calls = []
+            ref_blender = ns['linear_blender']
+
+            def spy(ref, tgt, ref_m, tgt_m, mask=False, _f=ref_blender, _calls=calls):
+                r1, c1 = torch.nonzero(ref_m[0, 0], as_tuple=True)
+                r2, c2 = torch.nonzero(tgt_m[0, 0], as_tuple=True)
+                _calls.append(dict(count=np.array([r1.numel(), r2.numel()]),
+                                   center=np.array([float(r1.float().mean()), float(c1.float().mean()),
+                                                    float(r2.float().mean()), float(c2.float().mean())]),
+                                   ref_m=cases.box_down(ref_m[0, 0].numpy()[..., None], 4)[..., 0],
+                                   tgt_m=cases.box_down(tgt_m[0, 0].numpy()[..., None], 4)[..., 0],
+                                   mask1=cases.box_down(_f(ref, tgt, ref_m, tgt_m, True)[0, 0].numpy()[..., None], 4)[..., 0]))
+                return _f(ref, tgt, ref_m, tgt_m, mask)
+            ns['linear_blender'] = spy
         exec(compile(body, 'threeview_345_505', 'exec'), ns)
         tag = fm.lower()
+        if fm == 'LINEAR':
+            assert len(calls) == 2 * n
+            for key in ('count', 'center', 'ref_m', 'tgt_m', 'mask1'):
+                res['lin_' + key] = np.stack([np.stack([calls[2 * i][key], calls[2 * i + 1][key]]) for i in range(n)])
         res['canvas_' + tag] = np.array([int(ns['out_height'].int()), int(ns['out_width'].int())])
         res['frames_' + tag] = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), 4) for f in ns['stable_list']])
         res['iqr_' + tag] = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), 4) for f in ns['stable_list']])

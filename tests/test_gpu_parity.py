@@ -354,7 +354,7 @@ def test_three_view_vs_reference(dev, golden):
         # see tests/test_oracle_golden.py::test_g10_three_view for why AVERAGE is only loosely comparable
         # LINEAR: nonzero() centroids count the +-1e-3 out-of-range residues of the masks, so the blend weights move
         # by ~1e-3 between CPUs already (0.12 grey levels oracle-vs-golden across two x86 hosts)
-        tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
+        tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.1, 0.6)      # LINEAR observed 1.8e-2 (round 4: 0.5 -> 0.1)
         close_boxes(got, g['frames_' + fm.lower()], g['iqr_' + fm.lower()], tol, 'three-view ' + fm, k=4, cover=cover)
     # the fused 3-view kernel must equal the chained formula applied to the generic per-view warp, bit for bit
     from stabstitch2_amd import ops
@@ -790,7 +790,9 @@ def test_run_three_view_vs_oracle(dev, hip_nets, h, w, n):
     gl = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), k) for f in frl])
     rl = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), k) for f in ofl])
     il = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), k) for f in ofl])
-    close_boxes(gl, rl, il, 0.5, 'three-view LINEAR frames vs oracle', k=k, cover=0.5)
+    # (round 4: the blender's masks / centroids / mask1 are pinned on the reference's own values,
+    # test_three_view_linear_blender_internals_vs_reference: mask1 moves by <= 4.4e-3 -> 0.5 tightened to 0.3, observed 0.19)
+    close_boxes(gl, rl, il, 0.3, 'three-view LINEAR frames vs oracle', k=k, cover=0.5)
 
 
 def test_three_view_full_path_vs_reference(dev, golden, hip_nets):
@@ -817,7 +819,7 @@ def test_three_view_full_path_vs_reference(dev, golden, hip_nets):
         close(m3, g['mesh3'], 5e-3, 'mesh3 vs reference')
         assert [hc, wc] == list(g['canvas_' + fm.lower()])
         got = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), 4) for f in fr])
-        tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
+        tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.1, 0.6)      # LINEAR observed 1.8e-2 (round 4: 0.5 -> 0.1)
         close_boxes(got, g['frames_' + fm.lower()], g['iqr_' + fm.lower()], tol, 'G12 frames ' + fm, k=4, cover=cover)
 
 
