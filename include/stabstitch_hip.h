@@ -268,6 +268,9 @@ SS_API int ss_linear_blend(const float* ref, const float* tgt, const float* ref_
  * blend pass); ws: ss_linear_clip_workspace_floats(frames, views, hc, wc) floats.  Bit-identical, frame by frame, to
  * ss_tps_warp_views + ss_linear_blend (+ ss_mask_union + ss_linear_blend). */
 SS_API long long ss_linear_clip_workspace_floats(int frames, int views, int hc, int wc);
+/* form of the clip blend kernel (process-wide, for A/B runs and the equivalence test): rows = 0 the default (rolling pass,
+ * strips of 64 columns x 96 rows per wave), > 0 that many rows per strip, < 0 the 64 x 64-tile kernel; identical output. */
+SS_API int ss_linear_clip_set_rows(int rows);
 SS_API int ss_render_linear_clip(const float* const* views_base, const float* source, const float* T, float* out,
                           float* mask1_out, int frames, int views, int h, int w, int hc, int wc, int mode, float* ws,
                           void* stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     'ss_linear_blend_workspace_floats': (c_ll, [c_i, c_i]),
     'ss_linear_blend': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_st]),
     'ss_linear_clip_workspace_floats': (c_ll, [c_i, c_i, c_i, c_i]),
+    'ss_linear_clip_set_rows': (c_i, [c_i]),
     'ss_render_linear_clip': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_fp, c_st]),
     'ss_render_linear_clip_u8': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_fp, c_st]),
     'ss_mesh_bbox': (c_i, [c_fp, c_i, c_f, c_f, c_fp, c_i, c_st]),

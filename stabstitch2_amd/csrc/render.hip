@@ -1097,6 +1097,119 @@ __global__ __launch_bounds__(256) void lb_clip_blend_kernel(LbClipArgs a, int hc
     }
 }
 
+// The same blend as a ROLLING pass down the canvas (round 4, second version; the 64 x 64-tile kernel above stays as the
+// reference form and for the tests).  One WAVE owns a strip of 64 columns x `rs` rows of one frame and walks it row by row:
+//   row p:  X(p, c0-10 .. c0+73) from the masks (reflected columns; lanes 0..19 take a second column) -> 84 floats of LDS
+//           -> the lane's horizontal 21-tap sum hb(p) -> pushed into a 21-deep ring held in REGISTERS;
+//   once the ring is full, output row p-10 = the vertical 21-tap sum over the ring, mask1, blend, store.
+// No workgroup barrier, no tile halo in the row direction (only the 20 warm-up rows per strip), X / hb never in memory; the
+// loads of the next row are issued before the current row's arithmetic.  Same fmaf chains as the tile kernel and as
+// lb_blur_kernel: bit-identical output.  The tile kernel moved 2.2 GB per 32-frame clip at 2.7 TB/s (three phases between
+// barriers, 50 KB of LDS -> 3 workgroups per CU: its loads came in bursts); this one streams.
+template <bool UNION, bool U8OUT>
+__global__ __launch_bounds__(64) void lb_clip_blend_rows_kernel(LbClipArgs a, int hc, int wc, int rs, Gauss21 g) {
+    __shared__ float XL[96];
+    __shared__ LbCenters Ls;
+    __shared__ float prange[2];
+    const long long frame = blockIdx.z;
+    const long long ohw = (long long)hc * wc;
+    const float* __restrict__ m1a = a.m1a + frame * a.m_fs;
+    const float* __restrict__ m1b = UNION ? a.m1b + frame * a.m_fs : nullptr;
+    const float* __restrict__ m2 = a.m2 + frame * a.m_fs;
+    const float* __restrict__ ref = a.ref + frame * a.ref_fs;
+    const float* __restrict__ tgt = a.tgt + frame * a.tgt_fs;
+    float* mk_out = a.mask1_out ? a.mask1_out + frame * a.mask1_fs : nullptr;
+    const unsigned long long* s = a.scalars + frame * a.sc_fs;
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        Ls = lb_centers(s);
+        const unsigned* u = reinterpret_cast<const unsigned*>(s);
+        prange[0] = key2f(u[12]);
+        prange[1] = key2f(u[13]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const LbCenters L = Ls;
+    const float pmin = prange[0], pden = __fadd_rn(__fsub_rn(prange[1], prange[0]), 1e-3f);
+    const int c0 = blockIdx.x * 64, s0 = blockIdx.y * rs, s1 = min(s0 + rs, hc);
+    const int c = c0 + lane;
+    const bool cin = c < wc, second = lane < 20;
+    const int ca = min(max(reflect_idx(c0 - 10 + lane, wc), 0), wc - 1);
+    const int cb = min(max(reflect_idx(c0 + 54 + lane, wc), 0), wc - 1);
+    const int cc = min(c, wc - 1);
+    auto xval = [&](float ma, float mb, float b, int r, int col) -> float {
+        if (UNION) ma = __fsub_rn(__fadd_rn(ma, mb), __fmul_rn(ma, mb));
+        const float ovl = rintf(__fmul_rn(ma, b));
+        const float ref_only = __fsub_rn(ma, ovl);
+        float om = 0.f;
+        if (ovl != 0.f) om = __fsub_rn(lb_proj(L, r, col), pmin) / pden;
+        return __fadd_rn(ref_only, __fmul_rn(__fsub_rn(1.f, om), ma));
+    };
+    float ring[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) ring[k] = 0.f;
+    // masks of the row whose X comes next (columns ca / cb), requested one row ahead
+    float nxa1, nxa1b = 0.f, nxa2, nxb1 = 0.f, nxb1b = 0.f, nxb2 = 0.f;
+    auto row_of = [&](int p) { return min(max(reflect_idx(p, hc), 0), hc - 1); };
+    {
+        const long long i = (long long)row_of(s0 - 10) * wc;
+        nxa1 = m1a[i + ca]; nxa2 = m2[i + ca];
+        if (UNION) nxa1b = m1b[i + ca];
+        if (second) { nxb1 = m1a[i + cb]; nxb2 = m2[i + cb]; if (UNION) nxb1b = m1b[i + cb]; }
+    }
+    for (int p = s0 - 10; p < s1 + 10; ++p) {
+        const int r = row_of(p);
+        const float xa1 = nxa1, xa1b = nxa1b, xa2 = nxa2, xb1 = nxb1, xb1b = nxb1b, xb2 = nxb2;
+        if (p + 1 < s1 + 10) {                               // next row's masks
+            const long long i = (long long)row_of(p + 1) * wc;
+            nxa1 = m1a[i + ca]; nxa2 = m2[i + ca];
+            if (UNION) nxa1b = m1b[i + ca];
+            if (second) { nxb1 = m1a[i + cb]; nxb2 = m2[i + cb]; if (UNION) nxb1b = m1b[i + cb]; }
+        }
+        // this output row's planes (row p - 10), requested before the blur arithmetic
+        const int ro = p - 10;
+        const bool emit = ro >= s0;
+        float oma = 0.f, omb = 0.f, ob = 0.f, orf[3] = {0.f, 0.f, 0.f}, otg[3] = {0.f, 0.f, 0.f};
+        const long long io = (long long)max(ro, 0) * wc + cc;
+        if (emit) {
+            oma = m1a[io]; ob = m2[io];
+            if (UNION) omb = m1b[io];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { orf[ch] = ref[ch * ohw + io]; otg[ch] = tgt[ch * ohw + io]; }
+        }
+        XL[lane] = xval(xa1, xa1b, xa2, r, ca);
+        if (second) XL[64 + lane] = xval(xb1, xb1b, xb2, r, cb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float hb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) hb = fmaf(g.k[k], XL[lane + k], hb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the row buffer is rewritten next iteration
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 20; ++k) ring[k] = ring[k + 1];
+        ring[20] = hb;
+        if (emit && cin) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 21; ++k) acc = fmaf(g.k[k], ring[k], acc);
+            float ma = oma;
+            if (UNION) ma = __fsub_rn(__fadd_rn(ma, omb), __fmul_rn(ma, omb));
+            const float ovl = rintf(__fmul_rn(ma, ob));
+            const float ref_only = __fsub_rn(ma, ovl);
+            const float mk = fminf(fmaxf(__fadd_rn(__fmul_rn(acc, ma), ref_only), 0.f), 1.f);
+            if (mk_out) mk_out[io] = mk;
+            const float mk2 = __fmul_rn(__fsub_rn(1.f, mk), ob);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float v = __fadd_rn(__fmul_rn(orf[ch], mk), __fmul_rn(otg[ch], mk2));
+                if (U8OUT) reinterpret_cast<unsigned char*>(a.out)[(frame * ohw + io) * 3 + ch] = render_to_u8(v);
+                else a.out[(frame * 3 + ch) * ohw + io] = v;
+            }
+        }
+    }
+}
+
 static Gauss21 lb_gauss() {
     // 1-D kernel exp(-0.5 (t/sigma)^2) on linspace(-10,10,21), normalised, fp32 like torchvision (as ss_linear_blend)
     Gauss21 g;
@@ -1108,6 +1221,14 @@ static Gauss21 lb_gauss() {
     }
     for (int i = 0; i < 21; ++i) g.k[i] /= s;
     return g;
+}
+
+// rows per strip of the rolling blend kernel: 0 = default (96), > 0 = that many, < 0 = the 64 x 64-tile kernel instead
+// (ss_linear_clip_set_rows: an A/B and test knob; both forms give the same bits)
+static int g_lb_rows = 0;
+extern "C" int ss_linear_clip_set_rows(int rows) {
+    g_lb_rows = rows;
+    return SS_OK;
 }
 
 static int render_linear_clip_launch(const void* const* views_base, const float* source, const float* T, void* out,
@@ -1139,6 +1260,10 @@ static int render_linear_clip_launch(const void* const* views_base, const float*
     hipLaunchKernelGGL(lb_clip_reduce_kernel, dim3(frames * P), dim3(256), 0, st, (const unsigned*)partials, scalars, tiles, nbx, P);
     const Gauss21 g = lb_gauss();
     const dim3 gc(ss_cdiv(wc, LBC_T), ss_cdiv(hc, LBC_T), frames);
+    // rolling form: strips of 64 columns x rs rows, one wave each; rs so that a 720p canvas gives ~30 waves per CU
+    const int rs = g_lb_rows > 0 ? g_lb_rows : 96;
+    const dim3 gr(ss_cdiv(wc, 64), ss_cdiv(hc, rs), frames);
+    const bool rolling = g_lb_rows >= 0;
     LbClipArgs a;
     a.m_fs = views * 4 * ohw;
     a.ref = W; a.ref_fs = a.m_fs;
@@ -1148,19 +1273,30 @@ static int render_linear_clip_launch(const void* const* views_base, const float*
     a.scalars = scalars; a.sc_fs = P * 16;
     if (views == 2) {
         a.out = static_cast<float*>(out);
-        if (u8) hipLaunchKernelGGL((lb_clip_blend_kernel<false, true>), gc, dim3(256), 0, st, a, hc, wc, g);
-        else hipLaunchKernelGGL((lb_clip_blend_kernel<false, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+        if (rolling) {
+            if (u8) hipLaunchKernelGGL((lb_clip_blend_rows_kernel<false, true>), gr, dim3(64), 0, st, a, hc, wc, rs, g);
+            else hipLaunchKernelGGL((lb_clip_blend_rows_kernel<false, false>), gr, dim3(64), 0, st, a, hc, wc, rs, g);
+        } else {
+            if (u8) hipLaunchKernelGGL((lb_clip_blend_kernel<false, true>), gc, dim3(256), 0, st, a, hc, wc, g);
+            else hipLaunchKernelGGL((lb_clip_blend_kernel<false, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+        }
     } else {
         a.out = F;
-        hipLaunchKernelGGL((lb_clip_blend_kernel<false, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+        if (rolling) hipLaunchKernelGGL((lb_clip_blend_rows_kernel<false, false>), gr, dim3(64), 0, st, a, hc, wc, rs, g);
+        else hipLaunchKernelGGL((lb_clip_blend_kernel<false, false>), gc, dim3(256), 0, st, a, hc, wc, g);
         a.ref = F; a.ref_fs = 3 * ohw;
         a.tgt = W + 8 * ohw;
         a.m1b = W + 7 * ohw; a.m2 = W + 11 * ohw;
         a.mask1_out = mask1_out ? mask1_out + ohw : nullptr;
         a.scalars = scalars + 16;
         a.out = static_cast<float*>(out);
-        if (u8) hipLaunchKernelGGL((lb_clip_blend_kernel<true, true>), gc, dim3(256), 0, st, a, hc, wc, g);
-        else hipLaunchKernelGGL((lb_clip_blend_kernel<true, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+        if (rolling) {
+            if (u8) hipLaunchKernelGGL((lb_clip_blend_rows_kernel<true, true>), gr, dim3(64), 0, st, a, hc, wc, rs, g);
+            else hipLaunchKernelGGL((lb_clip_blend_rows_kernel<true, false>), gr, dim3(64), 0, st, a, hc, wc, rs, g);
+        } else {
+            if (u8) hipLaunchKernelGGL((lb_clip_blend_kernel<true, true>), gc, dim3(256), 0, st, a, hc, wc, g);
+            else hipLaunchKernelGGL((lb_clip_blend_kernel<true, false>), gc, dim3(256), 0, st, a, hc, wc, g);
+        }
     }
     return ss_launch_status();
 }

@@ -63,6 +63,16 @@ def test_linear_clip_equals_per_frame_chain(dev, hip_nets, views, size):
             if views == 3:
                 fq = ops.linear_blend(fq, wq[2, 0:3], ops.mask_union(wq[0, 3], wq[1, 3]), wq[2, 3])
             assert torch.equal(got8[i], ops.canvas_to_u8(fq[None])[0]), (mode, i)
+    # the blend kernel's other forms (64 x 64 tiles; rolling strips of another height): same bits
+    from stabstitch2_amd import _hip
+    base, bmk = ops.render_linear_clip(clips, src, T, hc, wc, 'NORMAL', want_masks=True)
+    try:
+        for rows in (-1, 17):
+            _hip.lib().ss_linear_clip_set_rows(rows)
+            alt, amk = ops.render_linear_clip(clips, src, T, hc, wc, 'NORMAL', want_masks=True)
+            assert torch.equal(alt, base) and torch.equal(amk, bmk), rows
+    finally:
+        _hip.lib().ss_linear_clip_set_rows(0)
     # pipeline level: tensors take the clip launches, lists of frames the per-frame chain
     a, _, _ = pipeline.render_frames(clips, meshes, 'NORMAL', 'LINEAR', prescaled=pres)
     b, _, _ = pipeline.render_frames([[c[i:i + 1] for i in range(n)] for c in clips], meshes, 'NORMAL', 'LINEAR', prescaled=pres)
