@@ -135,6 +135,11 @@ SS_API int ss_maxpool_nhwc_split(const float* in, float* out0, float* out1, int 
 /* K5: nn.Linear (+ReLU): y[m][nout] = x[m][k] . w[nout][k] + b  (spatial_network.py:170-178, 211-219) */
 SS_API int ss_linear(const float* x, const float* w, const float* b, float* y, int m, int k, int nout, int relu,
               void* stream);
+/* `groups` <= 8 fully connected layers of identical shape in one launch: x [groups][m][k] (group stride x_group_stride floats),
+ * w [groups][nout][k], b [groups][nout] or NULL; group g's [m][nout] result goes to y_groups[g] (HOST array of device pointers:
+ * each regressor head's output lands where its consumer reads it).  k % 4 == 0.  Row results equal ss_linear's bit for bit. */
+SS_API int ss_linear_grouped(const float* x, long long x_group_stride, const float* w, const float* b,
+                      float* const* y_groups, int groups, int m, int k, int nout, int relu, void* stream);
 
 /* ---- K3: contextual correlation layer (spatial_network.py:369-425) ---------------------------
  * f1, f2 nhwc [n][h][w][c]; flow out NCHW [n][2][h][w] (ch0 = dx, ch1 = dy).

@@ -41,6 +41,7 @@ SIGNATURES = {
     'ss_maxpool_nhwc': (c_i, [c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_maxpool_nhwc_split': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_linear': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
+    'ss_linear_grouped': (c_i, [c_fp, c_ll, c_fp, c_fp, ctypes.POINTER(c_fp), c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_ccl_workspace_floats': (c_ll, [c_i, c_i, c_i, c_i]),
     'ss_ccl': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp, c_st]),
     'ss_l2norm_nhwc': (c_i, [c_fp, c_fp, c_ll, c_i, c_st]),

@@ -787,6 +787,70 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
 }
 
+// G fully connected layers of identical shape in ONE launch (blockIdx.z = group): x [G][m][k] (group stride x_gs floats),
+// w [G][nout][k], b [G][nout] | null, group g's result [m][nout] at y.p[g] -- the regressors of SpatialNet's two stage-2
+// heads and TemporalNet's two views share every launch (layers.run_regressor_quad), and each head's last layer lands where
+// its consumer reads it.
+struct LinearOuts {
+    float* p[8];
+};
+template <int MT>
+__global__ __launch_bounds__(256) void linear_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, LinearOuts y, int m, int k,
+                                                             int nout, int relu, long long x_gs) {
+    const int g = blockIdx.z;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int o = blockIdx.x * 4 + wave;
+    if (o >= nout) return;
+    x += (long long)g * x_gs;
+    const float* wr = w + ((long long)g * nout + o) * k;
+    float* yg = g == 0 ? y.p[0] : g == 1 ? y.p[1] : g == 2 ? y.p[2] : g == 3 ? y.p[3] : g == 4 ? y.p[4] : g == 5 ? y.p[5] : g == 6 ? y.p[6] : y.p[7];
+    int m0 = blockIdx.y * MT;
+    float acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = 0.f;
+    int k4 = k >> 2;
+    for (int q = lane; q < k4; q += 64) {
+        float4 wv = reinterpret_cast<const float4*>(wr)[q];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (m0 + i < m) {
+                float4 xv = reinterpret_cast<const float4*>(x + (long long)(m0 + i) * k)[q];
+                acc[i] = fmaf(wv.x, xv.x, acc[i]);
+                acc[i] = fmaf(wv.y, xv.y, acc[i]);
+                acc[i] = fmaf(wv.z, xv.z, acc[i]);
+                acc[i] = fmaf(wv.w, xv.w, acc[i]);
+            }
+        }
+    }
+    float bias = b ? b[(long long)g * nout + o] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float v = ss_wave_sum(acc[i]);
+        if (lane == 0 && m0 + i < m) {
+            v += bias;
+            if (relu) v = fmaxf(v, 0.f);
+            yg[(long long)(m0 + i) * nout + o] = v;
+        }
+    }
+}
+
+extern "C" int ss_linear_grouped(const float* x, long long x_group_stride, const float* w, const float* b,
+                                 float* const* y_groups, int groups, int m, int k, int nout, int relu, void* stream) {
+    if (!x || !w || !y_groups || groups <= 0 || groups > 8 || m <= 0 || k <= 0 || (k & 3) || nout <= 0) return SS_ERR_ARG;
+    LinearOuts y;
+    for (int g = 0; g < 8; ++g) {
+        y.p[g] = g < groups ? y_groups[g] : nullptr;
+        if (g < groups && !y.p[g]) return SS_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // (the same accumulation order as linear_kernel<MT> for the same m: a row's result does not depend on the grouping)
+    if (m <= 1) hipLaunchKernelGGL((linear_grouped_kernel<1>), dim3(ss_cdiv(nout, 4), 1, groups), dim3(256), 0, st, x, w, b, y, m, k, nout, relu, x_group_stride);
+    else if (m <= 4) hipLaunchKernelGGL((linear_grouped_kernel<4>), dim3(ss_cdiv(nout, 4), 1, groups), dim3(256), 0, st, x, w, b, y, m, k, nout, relu, x_group_stride);
+    else hipLaunchKernelGGL((linear_grouped_kernel<8>), dim3(ss_cdiv(nout, 4), ss_cdiv(m, 8), groups), dim3(256), 0, st, x, w, b, y, m, k, nout, relu, x_group_stride);
+    return ss_launch_status();
+}
+
 extern "C" int ss_linear(const float* x, const float* w, const float* b, float* y, int m, int k, int nout, int relu,
                          void* stream) {
     if (!x || !w || !y || m <= 0 || k <= 0 || nout <= 0) return SS_ERR_ARG;

@@ -291,6 +291,58 @@ def run_regressor_pair(x, pp, chunk=None, outs=None):
     return [_fc_tail(x[k].reshape(n, -1), pp['fc'][k], None if outs is None else outs[k]) for k in range(g)]
 
 
+# --------------------------------------------------------------------------- four heads, one set of launches (round 4)
+# SpatialNet's two stage-2 regressors (regressNet2 ref / tgt, spatial_network.py:197-259) and TemporalNet's regressor applied
+# to two views (temporal_network.py:65-105) have the same architecture behind their first convolution (only its input width
+# differs: 121 / 49 displacement channels).  With equally many images per head -- S pairs per push in streaming mode, a chunk
+# of b pairs offline -- conv2 .. conv8 and the three FC layers of all four heads run as ONE grouped launch each instead of
+# two sets (11 launches fewer per pass; on the <= 11 x 15 maps the merged launches fill the chip where each set alone left
+# half of it idle).  Per image the arithmetic is the separate heads'; the conv engine's kernel choice follows the launch size.
+QUAD = os.environ.get('SS_QUAD_REGRESSOR', '1') == '1'
+
+
+def quad_regressors(pp_pair, p_temp):
+    """pp_pair: pair_regressors(r2_ref, r2_tgt); p_temp: TemporalNet's prepared regressor -> weights of the 4-head launches
+    (heads: ref, tgt, temporal view 1, temporal view 2; the temporal filters appear twice)."""
+    convs = [torch.cat((wp, wt[None], wt[None]), 0).contiguous() for wp, wt in zip(pp_pair['convs'][1:], p_temp['convs'][1:])]
+    fa, fb, ft = pp_pair['fc'][0], pp_pair['fc'][1], p_temp['fc']
+    fc = [(torch.stack((fa[l][0], fb[l][0], ft[l][0], ft[l][0]), 0).contiguous(),
+           torch.stack((fa[l][1], fb[l][1], ft[l][1], ft[l][1]), 0).contiguous()) for l in range(3)]
+    return {'conv1_pair': pp_pair['convs'][0], 'conv1_t': p_temp['convs'][0], 'convs': convs, 'fc': fc}
+
+
+def get_quad(spatial_net, temporal_net):
+    """The 4-head weights of a (SpatialNet, TemporalNet) pair, cached on SpatialNet's prepared dict and keyed on both nets'
+    weight versions (rebuilt when either was reloaded / moved)."""
+    sp, tp = spatial_net._prepared(), temporal_net._prepared()
+    ver = (spatial_net.weights_version, temporal_net.weights_version)
+    if sp.get('quad_version') != ver:
+        sp['quad'] = quad_regressors(sp['r2_pair'], tp['r2'])
+        sp['quad_version'] = ver
+    return sp['quad']
+
+
+def run_regressor_quad(cv_s, cv_t, q, outs):
+    """cv_s [2,b,h,w,124] (both directions of SpatialNet's stage 2), cv_t [2,b,h,w,52] (TemporalNet, two views);
+    outs: four contiguous destinations of b * 126 floats (offset_2_ref, offset_2_tgt, temporal motions of view 1 / view 2)."""
+    b = cv_s.shape[1]
+    assert cv_t.shape[0] == 2 and cv_t.shape[1] == b and b <= REG_CHUNK
+    y = torch.empty((4, b) + tuple(cv_s.shape[2:4]) + (q['conv1_pair'].shape[1],), device=cv_s.device, dtype=torch.float32)
+    ops.conv_grouped(cv_s, q['conv1_pair'], None, None, stride=1, pad=(0, 1, 1), relu=True, out=y[0:2])
+    ops.conv(cv_t.view((2 * b,) + tuple(cv_t.shape[2:])), q['conv1_t'], None, stride=1, pad=(0, 1, 1), relu=True,
+             out=y[2:4].view((2 * b,) + tuple(y.shape[2:])))
+    x = y
+    for i, w in enumerate(q['convs']):          # conv2 .. conv8: a 2x2 max-pool rides behind every second convolution
+        x = ops.conv_grouped(x, w, None, None, stride=1, pad=(0, 1, 1), relu=True, pool2=not (i & 1))
+    h = x.reshape(4, b, -1)
+    if h.shape[2] != q['fc'][0][0].shape[2]:
+        raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
+                         % (q['fc'][0][0].shape[2], h.shape[2]))
+    h = ops.linear_grouped(h, q['fc'][0][0], q['fc'][0][1], relu=True)
+    h = ops.linear_grouped(h, q['fc'][1][0], q['fc'][1][1], relu=True)
+    ops.linear_grouped(h, q['fc'][2][0], q['fc'][2][1], relu=False, outs=outs)
+
+
 # --------------------------------------------------------------------------- twin trunks (streaming mode)
 def _stack2(a, b):
     return None if a is None else torch.stack((a, b), 0).contiguous()

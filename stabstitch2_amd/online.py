@@ -32,6 +32,25 @@ def _warmup_stream(dev):
     return s
 
 
+def _spatial_temporal_heads(spatial, temporal, f64, prev_feat, feat, b, tm_out):
+    """SpatialNet behind its stage-1 trunk (f64 [2b,45,60,128], view 1 first) and TemporalNet's regressor on the cached /
+    current features (prev_feat, feat [2b,45,60,128], view-major) -> (offset_1, offset_2_ref, offset_2_tgt); the temporal
+    motions of view 1 / view 2 are written to tm_out = (t1 [b,126], t2 [b,126]).  With layers.QUAD the four regressor heads
+    share their launches (layers.run_regressor_quad), else they run as SpatialNet's pair and TemporalNet's own."""
+    if not L.QUAD:
+        off = spatial.forward_features(f64, b, pipeline.LR_H, pipeline.LR_W)
+        temporal.motions_from_features(prev_feat, feat, out_slices=[(0, b, tm_out[0]), (b, 2 * b, tm_out[1])])
+        return off
+    f32 = L.run_stage2(f64, spatial._prepared()['s2'])
+    off1, cv_s = spatial.forward_pair_cv(f64[:b], f64[b:], f32[:b], f32[b:], pipeline.LR_H, pipeline.LR_W)
+    cv_t = ops.cost_volume(prev_feat, feat, 3)
+    off_ref = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
+    off_tgt = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
+    L.run_regressor_quad(cv_s, cv_t.view((2, b) + tuple(cv_t.shape[1:])), L.get_quad(spatial, temporal),
+                         [off_ref, off_tgt, tm_out[0], tm_out[1]])
+    return off1, off_ref, off_tgt
+
+
 class OnlineStitcher:
     def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
                  use_graph=True):
@@ -113,12 +132,12 @@ class OnlineStitcher:
             self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
             self.trunk_versions = self._versions()
         f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)            # [2(net),2(view),45,60,128]
-        off1, off_ref, off_tgt = self.spatial.forward_features(f2[0], 1, pipeline.LR_H, pipeline.LR_W)
         ps, pt = st['pair_s'], st['pair_t']
+        feat = f2[1]
+        off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f2[0], st['prev_feat'], feat, 1,
+                                                         (pt[0, 1:2], pt[1, 1:2]))
         ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W,
                            out=(ps[0, 1].view(1, 7, 9, 2), ps[1, 1].view(1, 7, 9, 2)))
-        feat = f2[1]
-        self.temporal.motions_from_features(st['prev_feat'], feat, out_slices=[(0, 1, pt[0, 1:2]), (1, 2, pt[1, 1:2])])
         st['prev_feat'].copy_(feat)
         # tsmotion of both views as ONE batch of 4 frames (v0 prev, v0 new, v1 prev, v1 new): frame k pairs with frame k - 1,
         # rows 1 and 3 are this pair's; row 2 (view 1's previous frame against view 0's new one) is computed and ignored
@@ -291,12 +310,12 @@ class MultiOnlineStitcher:
             self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
             self.trunk_versions = self._versions()
         f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)            # [2(net), 2S (view-major), 45,60,128]
-        off1, off_ref, off_tgt = self.spatial.forward_features(f2[0], S, pipeline.LR_H, pipeline.LR_W)
         ps, pt = st['pair_s'], st['pair_t']
+        feat = f2[1]
+        off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f2[0], st['prev_feat'], feat, S,
+                                                         (pt[0, 1], pt[1, 1]))
         ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W,
                            out=(ps[0, 1].view(S, 7, 9, 2), ps[1, 1].view(S, 7, 9, 2)))
-        feat = f2[1]
-        self.temporal.motions_from_features(st['prev_feat'], feat, out_slices=[(0, S, pt[0, 1]), (S, 2 * S, pt[1, 1])])
         st['prev_feat'].copy_(feat)
         # tsmotion of all streams and both views as ONE batch of 4 S frames laid out [view][prev, new][stream]: frame k pairs
         # with frame k - S (its own stream's previous frame); the rows of the `prev` halves are computed and ignored

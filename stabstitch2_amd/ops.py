@@ -282,7 +282,7 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     return out
 
 
-def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, pool2=False):
+def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, pool2=False, out=None):
     """G independent convolutions of identical geometry in ONE launch: x [G,n,h,w,c], wgt [G,cout,kt,kh,kw,cin],
     bias [G,cout] | None, res [G,n,ho,wo,cout] | None -> [G,n,ho,wo,cout]; a 4-D x [n,h,w,c] is shared by all groups.  Used where the reference runs twin
     sub-networks (regressNet2 ref/tgt, the SpatialNet and TemporalNet trunks in streaming mode)."""
@@ -298,12 +298,14 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
     ho = (h + 2 * ph - kh) // stride + 1
     wo = (w + 2 * pw - kw) // stride + 1
     if pool2:      # conv + MaxPool2d(2, 2): one kernel on the Winograd path, two launches otherwise -> [g,n,ho//2,wo//2,cout]
-        assert res is None
+        assert res is None and out is None
         if pool2_is_fused(x, wgt, stride, pad):
             return conv_winograd(x, wgt, bias, None, relu, None, pool2=True)
         y = conv_grouped(x, wgt, bias, None, stride, pad, relu)
         return maxpool(y.view(g * n, ho, wo, cout), 2, 2, 0).view(g, n, ho // 2, wo // 2, cout)
-    out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    assert tuple(out.shape) == (g, n, ho, wo, cout) and out.is_contiguous()
     if _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n * g):
         return conv_winograd(x, wgt, bias, res, relu, out)
     global last_conv_path
@@ -345,6 +347,22 @@ def linear(x, w, b=None, relu=False, out=None):
 
 
 # ------------------------------------------------------------------ correlation
+def linear_grouped(x, w, b=None, relu=False, outs=None):
+    """G fully connected layers of identical shape in one launch: x [G,m,k], w [G,nout,k], b [G,nout] | None ->
+    [G,m,nout]; outs: list of G contiguous destination tensors of m * nout floats each (any addresses) instead."""
+    g, m, k = x.shape
+    nout = w.shape[1]
+    assert w.shape[0] == g and w.shape[2] == k and x.is_contiguous()
+    res = None
+    if outs is None:
+        res = torch.empty((g, m, nout), device=x.device, dtype=torch.float32)
+        outs = [res[i] for i in range(g)]
+    assert len(outs) == g and all(o.numel() == m * nout for o in outs)
+    arr = H.ptr_array(outs)
+    H.call('ss_linear_grouped', H.dptr(x), x[0].numel(), H.dptr(w), H.dptr(b, True), arr, g, m, k, nout, int(relu), H.stream())
+    return res
+
+
 def ccl(f1, f2, scale=10.0, want_nchw=True, want_nhwc4=True):
     """f1, f2 nhwc [n,h,w,c] -> (flow NCHW [n,2,h,w] | None, flow nhwc4 [n,h,w,4] | None)."""
     n, h, w, c = f1.shape

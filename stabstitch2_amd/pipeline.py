@@ -161,7 +161,9 @@ class JointEstimator:
         xa, xb = L.run_stem_shared([lr2] if cache1 is not None else [lr1, lr2], sp['stem_pair'])
         if cache1 is None and self.tmotion1 is not None:
             xb = xb[b:]                                     # TemporalNet continues on view 2 only
-        if JOINT_OVERLAP:
+        if L.QUAD and cache1 is None and self.tmotion1 is None and b <= L.REG_CHUNK:
+            self._quad(xa, xb, b, s, e)
+        elif JOINT_OVERLAP:
             # SpatialNet (main stream) and TemporalNet (side stream) are independent behind the shared stem: two chains of
             # launches whose partially filled last rounds top each other up
             main = torch.cuda.current_stream(xb.device)
@@ -176,6 +178,47 @@ class JointEstimator:
             self._spatial(xa, b, s, e, cache1)
             self._temporal(xb, b, s, e)
         self.pos = e
+
+    def _quad(self, xa, xb, b, s, e):
+        """Both nets of a 2-view chunk with the four regressor heads in shared launches (layers.run_regressor_quad): SpatialNet's
+        ref / tgt heads on the b pairs, TemporalNet's head on b consecutive-frame pairs per view -- the first chunk has b - 1
+        (frame 0 has no predecessor): its head runs on a zero cost volume in row 0, whose result lands on frame 0's motion
+        and is replaced by the zero motion of temporal_network.py:31-33."""
+        L, sp, tp = self.L, self.sp, self.tp
+        f64 = L.run_trunk_body(xa, sp['s1'])
+        f32 = L.run_stage2(f64, sp['s2'])
+        off1, cv_s = self.spatial_net.forward_pair_cv(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
+        if self.cache2 is not None:
+            self.cache2.append((f64[b:], f32[b:]))
+        f = L.run_trunk_body(xb, tp['s1'])                # TemporalNet features [2b,45,60,128], view-major
+        lead = 0 if s == 0 else 1
+        cv_t = torch.empty((2, b, f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
+        for i in range(2):
+            fi = f[i * b:(i + 1) * b]
+            if lead:
+                ops.cost_volume(self.carry[i], fi[0:1], 3, out=cv_t[i, 0:1])
+            else:
+                ops.fill(cv_t[i, 0])
+            if b > 1:
+                ops.cost_volume(fi[:b - 1], fi[1:], 3, out=cv_t[i, 1:])
+        off_ref = torch.empty((b, 126), device=f.device, dtype=torch.float32)
+        off_tgt = torch.empty((b, 126), device=f.device, dtype=torch.float32)
+        L.run_regressor_quad(cv_s, cv_t, L.get_quad(self.spatial_net, self.temporal_net),
+                             [off_ref, off_tgt, self.tm[0, e - b:e].view(b, -1), self.tm[1, e - b:e].view(b, -1)])
+        if not lead:
+            for i in range(2):
+                ops.fill(self.tm[i, 0])
+        ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W, out=(self.m1[s:e], self.m2[s:e]))
+        self._carry(f, b, 2, e)
+
+    def _carry(self, f, b, nv, e):
+        # the last frame's features of every view in a small buffer of their own: a slice of `f` would keep the whole chunk's
+        # [nv*b,45,60,128] features alive through the next push
+        if e < self.n:                                   # (the last chunk carries nothing)
+            if self.carry is None:
+                self.carry = [torch.empty((1,) + tuple(f.shape[1:]), device=f.device, dtype=torch.float32) for _ in range(nv)]
+            for i in range(nv):
+                self.carry[i].copy_(f[i * b + b - 1:(i + 1) * b])
 
     def _spatial(self, xa, b, s, e, cache1=None):
         L, sp = self.L, self.sp
@@ -208,13 +251,7 @@ class JointEstimator:
                     ops.cost_volume(fi[:b - 1], fi[1:], 3, out=cv[i * rows + lead:(i + 1) * rows])
                 slices.append((i * rows, (i + 1) * rows, self.tm[i, e - rows:e].view(rows, -1)))
             L.run_regressor(cv, tp['r2'], out_slices=slices)
-        # the last frame's features of every view in a small buffer of their own: a slice of `f` would keep the whole chunk's
-        # [nv*b,45,60,128] features alive through the next push
-        if e < self.n:                                   # (the last chunk carries nothing)
-            if self.carry is None:
-                self.carry = [torch.empty((1,) + tuple(f.shape[1:]), device=f.device, dtype=torch.float32) for _ in range(nv)]
-            for i in range(nv):
-                self.carry[i].copy_(f[i * b + b - 1:(i + 1) * b])
+        self._carry(f, b, nv, e)
 
     def result(self):
         """-> (smotion1, smotion2, tmotion1, tmotion2), each [N,7,9,2] (tmotion frame 0 = 0)."""

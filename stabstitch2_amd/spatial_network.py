@@ -89,8 +89,16 @@ class SpatialNet(L.PreparedMixin, nn.Module):
     @torch.no_grad()
     def forward_pair(self, f64_1, f64_2, f32_1, f32_2, img_h, img_w):
         """Both views' trunk features (each [B,...]) -> the three offsets (spatial_network.py:291-331)."""
+        offset_1, cv = self.forward_pair_cv(f64_1, f64_2, f32_1, f32_2, img_h, img_w)
+        offset_2_ref, offset_2_tgt = L.run_regressor_pair(cv, self._prepared()['r2_pair'])
+        return offset_1, offset_2_ref, offset_2_tgt
+
+    @torch.no_grad()
+    def forward_pair_cv(self, f64_1, f64_2, f32_1, f32_2, img_h, img_w):
+        """forward_pair up to the stage-2 cost volumes: -> (offset_1 [B,8], cv [2,B,h/8,w/8,124]: both directions).  The caller
+        runs regressNet2 ref / tgt on cv -- alone (`forward_pair`) or together with TemporalNet's regressor in shared
+        launches (layers.run_regressor_quad)."""
         p = self._prepared()
-        b = f64_1.shape[0]
         # stage 1: contextual correlation -> global homography offsets
         _, flow = ops.ccl(f32_1, f32_2, 10.0, want_nchw=False, want_nhwc4=True)
         offset_1 = L.run_regressor(flow, p['r1'])
@@ -100,9 +108,7 @@ class SpatialNet(L.PreparedMixin, nn.Module):
         w1 = ops.homo_warp_nhwc(f64_1, th_ref, fh, fw)
         w2 = ops.homo_warp_nhwc(f64_2, th_tgt, fh, fw)
         # stage 2: local cost volumes in both directions -> residual mesh motions
-        cv = ops.cost_volume_bidir(w1, w2, 5)                      # [2,b,fh,fw,124]: both directions, one launch
-        offset_2_ref, offset_2_tgt = L.run_regressor_pair(cv, p['r2_pair'])
-        return offset_1, offset_2_ref, offset_2_tgt
+        return offset_1, ops.cost_volume_bidir(w1, w2, 5)          # [2,b,fh,fw,124]: both directions, one launch
 
     @staticmethod
     def cost_volume(x1, x2, search_range, norm=True, fast=True):
