@@ -447,6 +447,16 @@ def other_configs(nets, dev, args):
                         sync, W, K, True)
     entry('720p 3-view fusion LINEAR', n, dt, K, o[1], o[2], sg)
     del o
+    # opt-in: TemporalNet's trunk on a second HIP stream beside SpatialNet's chain of small launches (pipeline.QUAD_OVERLAP)
+    old_ov = pipeline.QUAD_OVERLAP
+    pipeline.QUAD_OVERLAP = True
+    try:
+        dt, o, sg = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets), sync, W, K, True)
+        entry('720p 2-view, TemporalNet trunk beside the SpatialNet regressor chain on a second stream (opt-in SS_QUAD_OVERLAP=1)',
+              n, dt, K, o[1], o[2], sg, 'bit-identical frames; per-launch durations overlap, so the headline (and its roofline) run without it')
+    finally:
+        pipeline.QUAD_OVERLAP = old_ov
+    del o
     # opt-in arithmetic of the Winograd GEMMs: fp32 products formed exactly from three bf16 slices per operand (nine slice
     # products) on the bf16 matrix pipe, fp32 accumulation (ops.WINO_MATH, csrc/wino.hip SLICED).  NOT the headline.
     from stabstitch2_amd import ops

@@ -112,6 +112,12 @@ def temporal_stage_views(temporal_net, lrs):
 SHARED_STEM = os.environ.get('SS_SHARED_STEM', '1') == '1'
 # SpatialNet and TemporalNet behind the shared stem on two HIP streams (measured); off by default
 JOINT_OVERLAP = os.environ.get('SS_JOINT_OVERLAP', '0') == '1'
+# the 4-head path: TemporalNet's trunk beside SpatialNet's small-launch chain (second stream; fork AFTER SpatialNet's trunk:
+# forked before it, two full-chip trunks only get in each other's way, measured -2 %; forked behind it +1.1 % frames/s, bit-identical).
+# Opt-in (SS_QUAD_OVERLAP=1), not the headline: with kernels of two streams sharing the chip a launch's duration is no longer
+# its own, and the conv engine's roofline fraction -- flop / summed launch durations -- reads 0.59 instead of 0.64 for the
+# same work done sooner; bench.py reports the overlapped run under other_configs.
+QUAD_OVERLAP = os.environ.get('SS_QUAD_OVERLAP', '0') == '1'
 
 
 class JointEstimator:
@@ -185,22 +191,49 @@ class JointEstimator:
         (frame 0 has no predecessor): its head runs on a zero cost volume in row 0, whose result lands on frame 0's motion
         and is replaced by the zero motion of temporal_network.py:31-33."""
         L, sp, tp = self.L, self.sp, self.tp
-        f64 = L.run_trunk_body(xa, sp['s1'])
-        f32 = L.run_stage2(f64, sp['s2'])
-        off1, cv_s = self.spatial_net.forward_pair_cv(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
-        if self.cache2 is not None:
-            self.cache2.append((f64[b:], f32[b:]))
-        f = L.run_trunk_body(xb, tp['s1'])                # TemporalNet features [2b,45,60,128], view-major
         lead = 0 if s == 0 else 1
-        cv_t = torch.empty((2, b, f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
-        for i in range(2):
-            fi = f[i * b:(i + 1) * b]
-            if lead:
-                ops.cost_volume(self.carry[i], fi[0:1], 3, out=cv_t[i, 0:1])
-            else:
-                ops.fill(cv_t[i, 0])
-            if b > 1:
-                ops.cost_volume(fi[:b - 1], fi[1:], 3, out=cv_t[i, 1:])
+
+        def temporal_side():
+            f = L.run_trunk_body(xb, tp['s1'])                # TemporalNet features [2b,45,60,128], view-major
+            cv_t = torch.empty((2, b, f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
+            for i in range(2):
+                fi = f[i * b:(i + 1) * b]
+                if lead:
+                    ops.cost_volume(self.carry[i], fi[0:1], 3, out=cv_t[i, 0:1])
+                else:
+                    ops.fill(cv_t[i, 0])
+                if b > 1:
+                    ops.cost_volume(fi[:b - 1], fi[1:], 3, out=cv_t[i, 1:])
+            return f, cv_t
+
+        def spatial_trunk():
+            f64 = L.run_trunk_body(xa, sp['s1'])
+            f32 = L.run_stage2(f64, sp['s2'])
+            if self.cache2 is not None:
+                self.cache2.append((f64[b:], f32[b:]))
+            return f64, f32
+
+        def spatial_chain(f64, f32):
+            return self.spatial_net.forward_pair_cv(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
+
+        if QUAD_OVERLAP:
+            # SpatialNet's chain behind its trunk is a string of small dependent launches (CCL, regressNet1 on 23 x 30 .. 5 x 7
+            # maps, decomposition, feature warps) that leave most of the chip idle; TemporalNet's trunk -- full-chip launches
+            # with no dependence on them -- runs beside it on a second HIP stream (its own hardware queue: GPU_MAX_HW_QUEUES)
+            main = torch.cuda.current_stream(xb.device)
+            side = _side_stream(xb.device)
+            f64, f32 = spatial_trunk()                     # (both trunks are full-chip launches: one after the other)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                f, cv_t = temporal_side()
+            off1, cv_s = spatial_chain(f64, f32)
+            main.wait_stream(side)
+            xb.record_stream(side)                         # allocated on the main stream, read on the side stream
+            f.record_stream(main)                          # allocated on the side stream, read on the main stream from here on
+            cv_t.record_stream(main)
+        else:
+            off1, cv_s = spatial_chain(*spatial_trunk())
+            f, cv_t = temporal_side()
         off_ref = torch.empty((b, 126), device=f.device, dtype=torch.float32)
         off_tgt = torch.empty((b, 126), device=f.device, dtype=torch.float32)
         L.run_regressor_quad(cv_s, cv_t, L.get_quad(self.spatial_net, self.temporal_net),

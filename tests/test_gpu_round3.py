@@ -154,7 +154,8 @@ def test_steady_state_clip_launches_no_torch_kernels(dev, hip_nets):
     step()
     torch.cuda.synchronize()
     VIEW = ('view', 'reshape', 'permute', 'expand', 'slice', 'select', 'unsqueeze', 'squeeze', 'transpose', 'as_strided', 'alias',
-            'detach', 't.default', '_unsafe_view', 'unbind', 'split', 'empty', 'sym_', 'narrow', 'size', 'stride', 'is_', 'numel')
+            'detach', 't.default', '_unsafe_view', 'unbind', 'split', 'empty', 'sym_', 'narrow', 'size', 'stride', 'is_', 'numel',
+            'record_stream')
     seen = []
 
     class Log(TorchDispatchMode):
