@@ -161,6 +161,9 @@ SS_API int ss_cost_volume(const float* x1, const float* x2, float* out, int n, i
  * cost_volume(x1, x2), cost_volume(x2, x1) */
 SS_API int ss_cost_volume_bidir(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
                          int out_cs, void* stream);
+/* tile height of the cost-volume kernel (process-wide A/B knob): 0 = the library's choice, 4 or 8 output rows x 16 columns per
+ * workgroup; identical results. */
+SS_API int ss_cost_volume_set_tile(int ty);
 
 /* ---- K6: 4-point DLT, bidirectional decomposition, H -> mesh (fp64 on device) -----------------
  * ss_tensor_dlt: utils/torch_DLT.py:17-45; src, dst [n][4][2] -> H [n][3][3]. */
