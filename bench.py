@@ -122,7 +122,8 @@ class ConvProbe:
             def timed(x, wgt, *a, **k):
                 if not probe.active:
                     return orig(x, wgt, *a, **k)
-                if k.get('pool2') and not ops.pool2_is_fused(x, wgt, k.get('stride', 1), k.get('pad', (0, 1, 1))):
+                if k.get('pool2') and not (ops.pool2_is_fused(x, wgt, k.get('stride', 1), k.get('pad', (0, 1, 1))) or
+                                           ops.pool2_in_reduce(x, wgt, k.get('stride', 1), k.get('pad', (0, 1, 1)))):
                     return orig(x, wgt, *a, **k)      # two launches: the inner conv and the pool are probed on their own
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)

@@ -65,6 +65,13 @@ SS_API int ss_conv_nhwc(const float* in, const float* wgt, const float* bias, co
                  int pad_t, int pad_h, int pad_w, int relu, int out_cs,
                  int groups, long long in_gs, long long w_gs, long long out_gs,
                  float* ws, long long ws_floats, void* stream);
+/* Conv2d + bias + ReLU + MaxPool2d(2, 2) in the launches that run split-K (ss_conv_workspace_need(...) > 0, ws of that size):
+ * the pool rides in the split-K reduction (the regressors' conv, ReLU, MaxPool2d(2, 2) on small maps, spatial_network.py:147-259).
+ * out [groups][n][Ho/2][Wo/2][out_cs].  Launches that would not split return SS_ERR_UNSUPPORTED and launch nothing (the caller
+ * runs ss_conv_nhwc + ss_maxpool_nhwc).  Bit-identical to those two. */
+SS_API int ss_conv_pool2_nhwc(const float* in, const float* wgt, const float* bias, float* out, int n, int h, int w, int cin,
+                       int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu, int out_cs, int groups,
+                       long long in_gs, long long w_gs, long long out_gs, float* ws, long long ws_floats, void* stream);
 
 /* ---- the network stem: nn.Conv2d(3, 64, 7, stride 2, pad 3)(+BN)(+ReLU) of the ResNet-18 trunk (spatial_network.py:127-129,
  * temporal_network.py:47-49) on a 3-channel layout whose filter ROWS are contiguous: K = 7 x 24 = 168 instead of

@@ -25,6 +25,7 @@ SIGNATURES = {
     'ss_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_conv_workspace_need': (c_ll, [c_i] * 14),
     'ss_conv_nhwc': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 15 + [c_i, c_ll, c_ll, c_ll, c_fp, c_ll, c_st]),
+    'ss_conv_pool2_nhwc': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 13 + [c_ll, c_ll, c_ll, c_fp, c_ll, c_st]),
     'ss_nchw_to_nhwc3_padded': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_conv_stem3': (c_i, [c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_ll] * 3 + [c_st]),
     'ss_stem_pool_packed_floats': (c_ll, [c_i]),

@@ -53,6 +53,7 @@ struct ConvP {
     SsDiv32 divWo, divHo, divTo;     // output-row decomposition m -> (n, to, ho, wo)
     SsDiv32 divNt, divSplits;        // workgroup index decomposition (wave-uniform: scalar multiplies)
     int relu, out_cs;
+    int pool2;                       // split-K launches only: the reduce kernel also takes MaxPool2d(2, 2) (out is the pooled map)
     int splits, tiles_per_split;
     unsigned ntiles;                 // Cout tiles (grid.x = M tiles * ntiles)
     long long in_gs, w_gs, out_gs;
@@ -426,17 +427,69 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvP p) {
 #endif
 }
 
-// out[m][co] = relu(sum_s partial[s][m][co] + bias[co] + res[m][co]); fixed summation order
+// out[m][co] = relu(sum_s partial[s][m][co] + bias[co] + res[m][co]); fixed summation order.
+// pool2: out[n][hp][wp][co] = relu(max over the 2 x 2 window of the split sums + bias) = MaxPool2d(2, 2) of the above (bias add and
+// ReLU are monotone: same bits as pooling the stored map) -- the regressors' conv, ReLU, MaxPool2d(2, 2) on the small maps
+// that run split-K: one launch less per pair of layers.
 __global__ void splitk_reduce_kernel(ConvP p) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long per = (long long)p.M * p.Co;
     int grp = blockIdx.y;
+    if (p.pool2) {
+        const int hp = p.Ho >> 1, wp = p.Wo >> 1;
+        const long long nimg = (long long)p.M / ((long long)p.Ho * p.Wo);
+        const long long pper = nimg * hp * wp * p.Co;
+        if (idx >= pper) return;
+        const int co = (int)(idx % p.Co);
+        long long q = idx / p.Co;
+        const int x = (int)(q % wp); q /= wp;
+        const int y = (int)(q % hp);
+        const long long n = q / hp;
+        const float* part = p.partial + (long long)grp * p.splits * per;
+        // the window's four split sums, each in the fixed order s = 0, 1, ...; the loads of eight splits x four pixels are
+        // issued together (a loop that loaded and added one value at a time ran at one L2 round trip per value: the fused
+        // kernel took longer than the reduce + max-pool launches it replaced)
+        const long long m00 = (n * p.Ho + 2 * y) * p.Wo + 2 * x;
+        const float* pq = part + m00 * p.Co + co;
+        const long long rowo = (long long)p.Wo * p.Co;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < p.splits; s0 += 8) {
+            float t[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool ok = s0 + k < p.splits;
+                const float* qs = pq + (long long)(ok ? s0 + k : s0) * per;
+                t[k][0] = ok ? qs[0] : 0.f;
+                t[k][1] = ok ? qs[p.Co] : 0.f;
+                t[k][2] = ok ? qs[rowo] : 0.f;
+                t[k][3] = ok ? qs[rowo + p.Co] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s0 + k < p.splits) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += t[k][i];
+                }
+        }
+        float best = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (p.bias) best += p.bias[(long long)grp * p.Co + co];
+        if (p.relu) best = fmaxf(best, 0.f);
+        p.out[(long long)grp * p.out_gs + ((n * hp + y) * wp + x) * p.out_cs + co] = best;
+        return;
+    }
     if (idx >= per) return;
     int co = (int)(idx % p.Co);
     long long m = idx / p.Co;
     const float* part = p.partial + (long long)grp * p.splits * per + idx;
     float v = 0.f;
-    for (int s = 0; s < p.splits; ++s) v += part[(long long)s * per];
+    for (int s0 = 0; s0 < p.splits; s0 += 8) {          // eight loads in flight, added in the fixed order s = 0, 1, ...
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = s0 + k < p.splits ? part[(long long)(s0 + k) * per] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < p.splits) v += t[k];
+    }
     if (p.bias) v += p.bias[(long long)grp * p.Co + co];
     long long o = (long long)grp * p.out_gs + m * p.out_cs + co;
     if (p.res) v += p.res[o];
@@ -567,8 +620,43 @@ extern "C" int ss_conv_nhwc(const float* in, const float* wgt, const float* bias
     p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
     p.in_bytes = (unsigned)(in_elems * 4);
     p.w_bytes = (unsigned)(w_elems * 4);
-    p.relu = relu; p.out_cs = out_cs;
+    p.relu = relu; p.out_cs = out_cs; p.pool2 = 0;
     return conv_dispatch(p, K, M, groups, kt * kh * kw, ws, ws_floats, (hipStream_t)stream);
+}
+
+// conv + bias + ReLU + MaxPool2d(2, 2) for launches that run split-K (ss_conv_workspace_need(...) > 0 and a workspace of that
+// size): the pool rides in the split-K reduction; out [groups][n][Ho/2][Wo/2][out_cs].  Anything else: SS_ERR_UNSUPPORTED (the
+// caller then runs ss_conv_nhwc + ss_maxpool_nhwc).  2-D (t = kt = 1), no residual.
+extern "C" int ss_conv_pool2_nhwc(const float* in, const float* wgt, const float* bias, float* out, int n, int h, int w,
+                                  int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu, int out_cs,
+                                  int groups, long long in_gs, long long w_gs, long long out_gs, float* ws, long long ws_floats,
+                                  void* stream) {
+    if (!in || !wgt || !out || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || (cin & 3) || cout <= 0 || kh <= 0 || kw <= 0 ||
+        kh > 8 || kw > 8 || stride <= 0 || groups <= 0 || out_cs < cout)
+        return SS_ERR_ARG;
+    const long long need = ss_conv_workspace_need(n, 1, h, w, cin, cout, 1, kh, kw, stride, 0, pad_h, pad_w, groups);
+    if (need <= 0 || !ws || ws_floats < need || need >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
+    ConvP p;
+    p.in = in; p.wgt = wgt; p.bias = bias; p.res = nullptr; p.out = out; p.partial = nullptr;
+    p.T = 1; p.H = h; p.W = w; p.C = cin;
+    p.To = 1;
+    p.Ho = (h + 2 * pad_h - kh) / stride + 1;
+    p.Wo = (w + 2 * pad_w - kw) / stride + 1;
+    p.Co = cout;
+    if (p.Ho < 2 || p.Wo < 2) return SS_ERR_ARG;
+    p.kt = 1; p.kh = kh; p.kw = kw; p.s = stride; p.pt = 0; p.ph = pad_h; p.pw = pad_w;
+    long long K = (long long)kh * kw * cin;
+    long long M = (long long)n * p.Ho * p.Wo;
+    long long in_elems = (long long)n * h * w * cin;
+    long long w_elems = (long long)cout * K;
+    if (K >= 65536 || M >= (1ll << 31) || in_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
+    p.px_b = cin * 4;
+    p.row_b = w * cin * 4;
+    p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
+    p.in_bytes = (unsigned)(in_elems * 4);
+    p.w_bytes = (unsigned)(w_elems * 4);
+    p.relu = relu; p.out_cs = out_cs; p.pool2 = 1;
+    return conv_dispatch(p, K, M, groups, kh * kw, ws, ws_floats, (hipStream_t)stream);
 }
 
 // Tile choice, split-K plan and launch of a filled ConvP (shared by ss_conv_nhwc and ss_conv_stem3)
@@ -601,6 +689,11 @@ static int conv_dispatch(ConvP& p, long long K, long long M, int groups, int tap
     int best = 6;
     const int force = g_force_tile;   // tuning aid only
     if (force) best = force;
+    if (p.pool2) {                    // the pool lives in the split-K reduction: only launches that split (decided BEFORE anything is launched)
+        const int splits = conv_splits(M, cout, groups, nk);
+        const long long need = (long long)groups * splits * M * cout;
+        if (best != 6 || !(splits > 1 && ws && need <= ws_floats && need < (1ll << 31))) return SS_ERR_UNSUPPORTED;
+    }
     const bool tail = (K % 32) != 0 && (K % 32) < 16;
 #ifdef SS_TUNING
     if (best == 5) {
@@ -635,7 +728,7 @@ static int conv_dispatch(ConvP& p, long long K, long long M, int groups, int tap
         else
             launch_auto<2, 2, 1, 1, 1, 32, 1>(p, groups, st, taps, tail);   // loads pinned ahead of the MFMAs: +2-3 %
         if (p.splits > 1) {
-            long long per = M * cout;
+            long long per = p.pool2 ? (M / ((long long)p.Ho * p.Wo)) * (p.Ho / 2) * (p.Wo / 2) * cout : M * cout;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, st, p);
         }
     }
@@ -674,7 +767,7 @@ extern "C" int ss_conv_stem3(const float* in_padded, const float* wgt, const flo
     p.in_gs = in_gs; p.w_gs = w_gs; p.out_gs = out_gs;
     p.in_bytes = (unsigned)(in_elems * 4);
     p.w_bytes = (unsigned)(w_elems * 4);
-    p.relu = relu; p.out_cs = out_cs;
+    p.relu = relu; p.out_cs = out_cs; p.pool2 = 0;
     return conv_dispatch(p, K, M, groups, 7, nullptr, 0, (hipStream_t)stream);
 }
 

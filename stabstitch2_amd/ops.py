@@ -247,6 +247,48 @@ def pool2_is_fused(x, wgt, stride=1, pad=(0, 1, 1)):
     return bool(POOL_FUSED and WINO_MATH != 'bf16x9' and _uses_winograd(kt, kh, kw, stride, pad, cin, cout, h, w, n * groups))
 
 
+POOL_SPLITK = os.environ.get('SS_POOL_SPLITK', '1') == '1'      # the 2x2 max-pool inside the split-K reduction of small launches
+
+
+def pool2_in_reduce(x, wgt, stride=1, pad=(0, 1, 1)):
+    """Does a pool2 convolution of these operands that is NOT on the Winograd kernel take its pool inside the split-K reduction
+    (one conv launch + one reduce launch), rather than in a max-pool launch of its own?"""
+    cout, kt, kh, kw, cin = wgt.shape[-5:]
+    groups = wgt.shape[0] if wgt.dim() == 6 else 1
+    n, h, w, c = x.shape[-4:]
+    return bool(POOL_SPLITK and kt == 1 and pad[0] == 0 and
+                _conv_ws_need(n, 1, h, w, c, cout, 1, kh, kw, stride, 0, pad[1], pad[2], groups) > 0)
+
+
+def _conv_pool2_splitk(x, wgt, bias, stride, pad, relu, groups):
+    """conv + ReLU + MaxPool2d(2, 2) as ONE implicit-GEMM launch + its split-K reduction (which takes the pool), for launches
+    that split along K; None when this launch would not (the caller then pools in a launch of its own).
+    x [n,h,w,c] / [g,n,h,w,c] (or 4-D shared by g groups); wgt [cout,1,kh,kw,cin] / [g,cout,1,kh,kw,cin]."""
+    if not POOL_SPLITK:
+        return None
+    grouped = wgt.dim() == 6
+    cout, kt, kh, kw, cin = wgt.shape[-5:]
+    n, h, w, c = x.shape[-4:]
+    pt, ph, pw = pad
+    if kt != 1 or pt != 0:
+        return None
+    need = _conv_ws_need(n, 1, h, w, c, cout, 1, kh, kw, stride, 0, ph, pw, groups)
+    if need <= 0:
+        return None
+    ho = (h + 2 * ph - kh) // stride + 1
+    wo = (w + 2 * pw - kw) // stride + 1
+    shape = (groups, n, ho // 2, wo // 2, cout) if grouped else (n, ho // 2, wo // 2, cout)
+    out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    ws = conv_workspace(x.device, need)
+    shared = grouped and x.dim() == 4
+    global last_conv_path
+    last_conv_path = 'igemm'
+    H.call('ss_conv_pool2_nhwc', H.dptr(x), H.dptr(wgt), H.dptr(bias, True), H.dptr(out), n, h, w, c, cout, kh, kw, stride, ph, pw,
+           int(relu), cout, groups, 0 if (shared or not grouped) else x[0].numel(), wgt[0].numel() if grouped else 0,
+           out[0].numel() if grouped else 0, H.dptr(ws), ws.numel(), H.stream())
+    return out
+
+
 def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=None, pool2=False):
     """x nhwc [n,h,w,c] or [n,t,h,w,c]; wgt [cout,kt,kh,kw,cin] (cin == x channels).
     pool2: the convolution is followed by MaxPool2d(2, 2) -- inside the Winograd kernel where that kernel runs, else as a
@@ -255,7 +297,8 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
         assert x.dim() == 4 and out is None and res is None
         if pool2_is_fused(x, wgt, stride, pad):
             return conv_winograd(x, wgt, bias, None, relu, None, pool2=True)
-        return maxpool(conv(x, wgt, bias, None, stride, pad, relu), 2, 2, 0)
+        y = _conv_pool2_splitk(x, wgt, bias, stride, pad, relu, 1)
+        return y if y is not None else maxpool(conv(x, wgt, bias, None, stride, pad, relu), 2, 2, 0)
     five = x.dim() == 5
     if five:
         n, t, h, w, c = x.shape
@@ -301,6 +344,9 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
         assert res is None and out is None
         if pool2_is_fused(x, wgt, stride, pad):
             return conv_winograd(x, wgt, bias, None, relu, None, pool2=True)
+        y = _conv_pool2_splitk(x, wgt, bias, stride, pad, relu, g)
+        if y is not None:
+            return y
         y = conv_grouped(x, wgt, bias, None, stride, pad, relu)
         return maxpool(y.view(g * n, ho, wo, cout), 2, 2, 0).view(g, n, ho // 2, wo // 2, cout)
     if out is None:

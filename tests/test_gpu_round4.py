@@ -313,3 +313,31 @@ def test_three_view_linear_blender_internals_vs_reference(dev, golden, hip_nets)
     assert worst['count'] < 0.01, worst         # nonzero() counts include the residues outside the image: machine-dependent
     assert worst['center'] < 1.5, worst         # centroids [px]: 0.3 % of the count x the canvas span
     assert worst['mask1'] < 1e-2, worst         # the blend weight (0..1), 99.9 % of the boxes: x the local contrast = the frames' gap
+
+
+# ------------------------------------------------------------------ the 2x2 max-pool inside the split-K reduction
+@pytest.mark.parametrize('shape', [(2, 11, 15, 128, 128), (3, 5, 7, 128, 256), (1, 23, 30, 64, 64), (2, 10, 14, 64, 128)])
+def test_conv_pool2_in_splitk_reduce(dev, shape):
+    """ops.conv(..., pool2=True) on small maps that run split-K: the reduction kernel takes MaxPool2d(2, 2) itself
+    (ss_conv_pool2_nhwc) -- bit-identical to conv + ReLU followed by the max-pool launch, single and grouped."""
+    from stabstitch2_amd import ops
+    n, h, w, cin, cout = shape
+    torch.manual_seed(3)
+    x = torch.randn(n, h, w, cin, device=dev)
+    wgt = torch.randn(cout, 1, 3, 3, cin, device=dev) * 0.05
+    old = ops.WINOGRAD
+    ops.WINOGRAD = False                 # force the implicit-GEMM path (the Winograd kernel has its own fused pool)
+    try:
+        assert ops.pool2_in_reduce(x, wgt)
+        got = ops.conv(x, wgt, None, stride=1, pad=(0, 1, 1), relu=True, pool2=True)
+        want = ops.maxpool(ops.conv(x, wgt, None, stride=1, pad=(0, 1, 1), relu=True), 2, 2, 0)
+        assert torch.equal(got, want)
+        xg = torch.randn(2, n, h, w, cin, device=dev)
+        wg = torch.randn(2, cout, 1, 3, 3, cin, device=dev) * 0.05
+        bg = torch.randn(2, cout, device=dev)
+        gotg = ops.conv_grouped(xg, wg, bg, None, stride=1, pad=(0, 1, 1), relu=True, pool2=True)
+        y = ops.conv_grouped(xg, wg, bg, None, stride=1, pad=(0, 1, 1), relu=True)
+        wantg = ops.maxpool(y.view(2 * n, h, w, cout), 2, 2, 0).view(2, n, h // 2, w // 2, cout)
+        assert torch.equal(gotg, wantg)
+    finally:
+        ops.WINOGRAD = old
