@@ -8,7 +8,7 @@ import json
 import sys
 
 KEYS = (('conv_wino', 'conv_wino_kernel'), ('conv_igemm', 'conv_igemm_kernel'), ('render_average', 'render_average_kernel'), ('cost_volume', 'cost_volume_kernel'),
-        ('maxpool', 'maxpool_kernel'), ('linear_kernel', 'linear_kernel'), ('homo_warp', 'homo_warp_kernel'), ('stem_pool_kernel', 'stem_pool_kernel'))
+        ('maxpool', 'maxpool_kernel'), ('linear_kernel', 'linear_kernel'), ('linear_grouped', 'linear_grouped_kernel'), ('homo_warp', 'homo_warp_kernel'), ('stem_pool_kernel', 'stem_pool_kernel'))
 
 
 def load(path):
@@ -34,14 +34,15 @@ def durations(path):
 f, w = load(sys.argv[1]), load(sys.argv[2])
 dur = durations(sys.argv[1])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-out = {'steps_profiled': steps, 'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py --steps 3 '
-                  '--warmup 2 --no-cpu-baseline --no-other-configs (one pass per counter; `launches` = all launches of the run, `steps_profiled` clips)',
+cmd = sys.argv[4] if len(sys.argv) > 4 else 'python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs'
+out = {'steps_profiled': steps, 'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- ' + cmd +
+                  ' (one pass per counter; `launches` = all launches of the run, `steps_profiled` clips)',
        'units': 'counter value x 1000 = bytes.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-B '
                 'requests of a 16-B/lane stream at 64 B, so the conv engine (buffer_load_dwordx4) and maxpool/linear (float4 '
                 'loads, homography sampler: float4 taps) fetch bytes = 2 x FETCH_SIZE; dword gathers (render, cost volume) and WRITE_SIZE are used as reported.',
        'kernels': {}}
 for key in f:
-    corr = 2.0 if key in ('conv_wino_kernel', 'conv_igemm_kernel', 'maxpool_kernel', 'linear_kernel', 'homo_warp_kernel', 'stem_pool_kernel') else 1.0
+    corr = 2.0 if key in ('conv_wino_kernel', 'conv_igemm_kernel', 'maxpool_kernel', 'linear_kernel', 'linear_grouped_kernel', 'homo_warp_kernel', 'stem_pool_kernel') else 1.0
     fa, wa = sum(f[key]) / len(f[key]), sum(w[key]) / len(w[key])
     out['kernels'][key] = {'launches': len(f[key]), 'FETCH_SIZE_avg': round(fa, 1), 'WRITE_SIZE_avg': round(wa, 1),
                            'fetch_correction': corr, 'hbm_bytes_per_launch': round((corr * fa + wa) * 1000.0)}
