@@ -215,3 +215,51 @@ def test_default_switches_are_the_measured_configuration():
     assert pipeline.SKIP_OUTSIDE is True and pipeline.U8_FUSED is True
     src = open(os.path.join(ROOT, 'bench.py')).read()
     assert "'dtype': 'f32'" in src
+
+
+# ------------------------------------------------------------------ round 4: host placement, new entry points (no GPU needed)
+def test_hostbind_sysfs_parsing_and_opt_out(monkeypatch):
+    """stabstitch2_amd.hostbind: sysfs cpulist parsing, node discovery, and the switches that leave the process alone."""
+    from stabstitch2_amd import hostbind
+    assert hostbind.parse_cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11]
+    assert hostbind.parse_cpulist('') == [] and hostbind.parse_cpulist(None) == []
+    nodes = hostbind.numa_nodes()
+    assert isinstance(nodes, dict) and all(isinstance(k, int) and isinstance(v, list) for k, v in nodes.items())
+    before = os.sched_getaffinity(0)
+    monkeypatch.setenv('SS_NUMA_BIND', '0')
+    rep = hostbind.bind_to_gpu('cpu')                       # no GPU here: nothing is bound, the report says why
+    assert rep['skipped'] == 'SS_NUMA_BIND=0' and os.sched_getaffinity(0) == before
+    monkeypatch.delenv('SS_NUMA_BIND')
+    rep = hostbind.bind_to_gpu('cpu')                       # no PCI function behind 'cpu' -> no node -> skipped, affinity untouched
+    assert 'skipped' in rep and os.sched_getaffinity(0) == before
+    assert hostbind.report('cpu') is rep
+    # MPOL_DEFAULT round trip through the raw syscall (harmless; checks the ctypes plumbing)
+    assert hostbind.set_mempolicy(hostbind.MPOL_DEFAULT) == 0
+
+
+def test_package_import_raises_the_hw_queue_budget():
+    """Importing the package sets GPU_MAX_HW_QUEUES (the host-fed runners need a hardware queue per stream) unless the user
+    set it; checked in a fresh interpreter because this process may have it already."""
+    env = dict(os.environ)
+    env.pop('GPU_MAX_HW_QUEUES', None)
+    out = subprocess.run([sys.executable, '-c', 'import os, stabstitch2_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'],
+                         capture_output=True, text=True, cwd=ROOT, env=env, check=True).stdout.strip()
+    assert out == '16'
+    env['GPU_MAX_HW_QUEUES'] = '6'
+    out = subprocess.run([sys.executable, '-c', 'import os, stabstitch2_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'],
+                         capture_output=True, text=True, cwd=ROOT, env=env, check=True).stdout.strip()
+    assert out == '6'
+
+
+def test_round4_entry_points_validate_arguments(built_lib):
+    """Argument validation of the round-4 entry points happens before any device work."""
+    L = built_lib
+    assert L.ss_linear_clip_workspace_floats(32, 2, 740, 1882) == 32 * (2 * 4 * 740 * 1882 + 32 + 30 * 93 * 4 * 8)
+    assert L.ss_linear_clip_workspace_floats(1, 4, 100, 100) == 0
+    assert L.ss_render_linear_clip(None, None, None, None, None, 1, 2, 8, 8, 32, 32, 0, None, None) == -1
+    assert L.ss_linear_grouped(None, 0, None, None, None, 4, 1, 8, 8, 0, None) == -1
+    assert L.ss_conv_pool2_nhwc(None, None, None, None, *([1] * 13), 0, 0, 0, None, 0, None) == -1
+    assert L.ss_tsmotion_lag(None, None, None, None, 4, 0, 360.0, 480.0, None, None, None) == -1
+    assert L.ss_cost_volume_set_tile(5) == -1 and L.ss_cost_volume_set_tile(0) == 0
+    assert L.ss_linear_clip_set_rows(0) == 0
+    assert L.ss_version() >= 400

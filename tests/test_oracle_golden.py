@@ -274,12 +274,35 @@ def test_g12_three_view_full_path(golden, nets):
     close(m1, g['mesh1'], 2e-3, 'mesh1')
     close(mid, g['middle'], 2e-3, 'middle')
     close(m3, g['mesh3'], 2e-3, 'mesh3')
+    calls = []
+    blender = P.linear_blender
+
+    def spy(ref, tgt, ref_m, tgt_m, mask=False):
+        # what the oracle's blender sees and decides, per chained call -- compared below with the reference's own (G12 lin_*)
+        r1, c1 = torch.nonzero(ref_m[0, 0], as_tuple=True)
+        r2, c2 = torch.nonzero(tgt_m[0, 0], as_tuple=True)
+        calls.append((np.array([r1.numel(), r2.numel()]),
+                      np.array([float(r1.float().mean()), float(c1.float().mean()), float(r2.float().mean()), float(c2.float().mean())]),
+                      cases.box_down(blender(ref, tgt, ref_m, tgt_m, True)[0, 0].numpy()[..., None], 4)[..., 0]))
+        return blender(ref, tgt, ref_m, tgt_m, mask)
     for fm in ('AVERAGE', 'LINEAR'):
-        frames, ow, oh = P.three_view_render(hr[0], hr[1], hr[2], m1, mid, m3, 'NORMAL', fm)
+        P.linear_blender = spy
+        try:
+            frames, ow, oh = P.three_view_render(hr[0], hr[1], hr[2], m1, mid, m3, 'NORMAL', fm)
+        finally:
+            P.linear_blender = blender
         assert [int(oh), int(ow)] == list(g['canvas_' + fm.lower()])
         got = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), 4) for f in frames])
         tol, cover = (3.0, 0.3) if fm == 'AVERAGE' else (0.5, 0.6)
         close_boxes(got, g['frames_' + fm.lower()], g['iqr_' + fm.lower()], tol, 'G12 ' + fm, k=4, cover=cover)
+    # round 4: the LINEAR chain's internals against the reference's (two blender calls per frame, threeview:498-501)
+    assert len(calls) == 2 * n
+    for i in range(n):
+        for p_ in range(2):
+            cnt, ctr, mk = calls[2 * i + p_]
+            assert np.all(np.abs(cnt - g['lin_count'][i, p_]) <= 0.01 * g['lin_count'][i, p_]), (i, p_, cnt, g['lin_count'][i, p_])
+            assert np.abs(ctr - g['lin_center'][i, p_]).max() < 1.5, (i, p_, ctr, g['lin_center'][i, p_])
+            assert np.quantile(np.abs(mk - g['lin_mask1'][i, p_]), 0.999) < 1e-2, (i, p_)
 
 
 def test_g11_psnr_ssim(golden):
