@@ -626,6 +626,8 @@ def render_frames_u8(frame_lists, meshes, warp_mode='NORMAL', out=None, bbox=Non
     n = meshes[0].shape[1]
     img_h, img_w = frame_lists[0].shape[1], frame_lists[0].shape[2]
     hc, wc, src, T = render_plan(meshes, img_h, img_w, prescaled, bbox=bbox, size=size)
+    if callable(out):                                   # a buffer provider (HostClipRunner's ring of result buffers)
+        out = out((n, hc, wc, 3))
     if out is None or tuple(out.shape) != (n, hc, wc, 3) or not out.is_contiguous():
         out = torch.empty((n, hc, wc, 3), device=meshes[0].device, dtype=torch.uint8)
     if fusion_mode == 'LINEAR':
@@ -702,15 +704,65 @@ class HostClipRunner:
     uint8 tensor [N,Hc,Wc,3], Hc, Wc) one clip late at most; a yielded tensor stays valid until `depth` more clips
     have been yielded."""
 
-    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', depth=2, streams=None):
+    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', depth=2, streams=None, prefetch=2):
         self.nets, self.dev = nets, torch.device(device)
         self.warp_mode, self.fusion_mode, self.depth = warp_mode, fusion_mode, depth
         self.up, self.comp, self.down = streams if streams is not None else io_streams(self.dev)
         # depth + 2 pinned result slots: the download of clip k + depth + 1 is enqueued before clip k + depth is yielded, so a
         # tensor yielded for clip k is only overwritten after `depth` more clips have been handed out
         self._host = [None] * (depth + 2)
+        # clips uploaded ahead of the one being computed.  One is enough when H2D runs at its 55 GB/s (3.2 of a clip's 8.5 ms),
+        # but beside the compute the copy rate of single clips drops to 15-30 GB/s now and then (bench: run totals 3070-3570
+        # frames/s at an unchanged 3745 steady state); with two the next clip's frames have two clip periods to arrive
+        self.prefetch = prefetch
         self.timed = False                   # True: HIP events around every upload / download (copy_stats)
         self._copies = {'h2d': [], 'd2h': []}
+        # Device staging owned by the runner (round 4): rings of `prefetch + 2` uploaded clips and 3 result buffers.  Taking
+        # them from the caching allocator per clip meant blocks of three streams' pools, released only when the recorded
+        # events had passed: now and then a clip needed a fresh 88-130 MB hipMalloc inside a run (10-20 ms each -- the
+        # 3070-3570 frames/s spread of the bench's run totals at an unchanged steady state).
+        self._in, self._in_free, self._in_k = [], [], 0
+        self._out, self._out_done, self._out_k = [], [], 0
+
+    class _Staged(list):
+        slot = None
+
+    def _in_slot(self, shapes):
+        nbuf = self.prefetch + 2
+        ok = bool(self._in) and len(self._in[0]) == len(shapes) and all(
+            tuple(b.shape[1:]) == tuple(sh[1:]) and b.shape[0] >= sh[0] for b, sh in zip(self._in[0], shapes))
+        if not ok:
+            torch.cuda.synchronize(self.dev)             # new frame geometry (or a longer clip): nothing of the old ring is in flight
+            same = bool(self._in) and len(self._in[0]) == len(shapes) and all(
+                tuple(b.shape[1:]) == tuple(sh[1:]) for b, sh in zip(self._in[0], shapes))
+            cap = max([sh[0] for sh in shapes] + ([self._in[0][0].shape[0]] if same else []))
+            self._in = [[torch.empty((cap,) + tuple(sh[1:]), dtype=torch.uint8, device=self.dev) for sh in shapes]
+                        for _ in range(nbuf)]
+            self._in_free = [None] * nbuf
+        j = self._in_k % len(self._in)
+        self._in_k += 1
+        return j
+
+    def consumed(self, d, ev):
+        """The compute that reads the uploaded clip `d` has been enqueued; `ev` (recorded behind it) frees d's staging slot."""
+        self._in_free[d.slot] = ev
+
+    def out_buffer(self, shape):
+        """The next result buffer of the ring (uint8 [n,Hc,Wc,3]); the compute stream waits for the download that last read it."""
+        ok = bool(self._out) and tuple(self._out[0].shape[1:]) == tuple(shape[1:]) and self._out[0].shape[0] >= shape[0]
+        if not ok:
+            torch.cuda.synchronize(self.dev)
+            same = bool(self._out) and tuple(self._out[0].shape[1:]) == tuple(shape[1:])
+            cap = max(shape[0], self._out[0].shape[0] if same else 0)
+            self._out = [torch.empty((cap,) + tuple(shape[1:]), dtype=torch.uint8, device=self.dev) for _ in range(3)]
+            self._out_done = [None] * 3
+        j = self._out_k % 3
+        self._out_k += 1
+        if self._out_done[j] is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._out_done[j])
+        buf = self._out[j][:shape[0]]
+        buf._ss_slot = j
+        return buf
 
     def _timed_copy(self, kind, stream, nbytes, fn):
         if not self.timed:
@@ -737,10 +789,17 @@ class HostClipRunner:
         return out
 
     def _upload(self, clip):
+        """uint8 frames of every view (host tensors / arrays [m,H,W,3]) -> (staged device tensors, ready event); the staging
+        slot is reused once `consumed` has been told which event ends its last reader."""
+        src = [(torch.from_numpy(f) if not torch.is_tensor(f) else f) for f in clip]
+        j = self._in_slot([tuple(t.shape) for t in src])
         with torch.cuda.stream(self.up):
-            src = [(torch.from_numpy(f) if not torch.is_tensor(f) else f) for f in clip]
-            d = self._timed_copy('h2d', self.up, sum(t.numel() * t.element_size() for t in src),
-                                 lambda: [t.to(self.dev, non_blocking=True) for t in src])
+            if self._in_free[j] is not None:
+                self.up.wait_event(self._in_free[j])
+            d = self._Staged(buf[:t.shape[0]] for buf, t in zip(self._in[j], src))
+            d.slot = j
+            self._timed_copy('h2d', self.up, sum(t.numel() * t.element_size() for t in src),
+                             lambda: [dst.copy_(t, non_blocking=True) for dst, t in zip(d, src)])
             ev = torch.cuda.Event()
             ev.record(self.up)
         return d, ev
@@ -748,22 +807,20 @@ class HostClipRunner:
     def _compute(self, d, ev):
         self.comp.wait_event(ev)
         with torch.cuda.stream(self.comp):
-            for t in d:
-                t.record_stream(self.comp)
-            d = [t if t.is_contiguous() else t.contiguous() for t in d]
             if _u8_fused(self.fusion_mode):
                 _, lr1 = ops.ingest_u8(d[0], want_hr=False)
                 _, lr2 = ops.ingest_u8(d[1], want_hr=False)
                 acc = estimate_meshes(self.nets, lr1, lr2)
-                u8, hc, wc = render_frames_u8(d, [acc['smooth_mesh1'], acc['smooth_mesh2']], self.warp_mode,
-                                              fusion_mode=self.fusion_mode)
+                u8, hc, wc = render_frames_u8(list(d), [acc['smooth_mesh1'], acc['smooth_mesh2']], self.warp_mode,
+                                              out=self.out_buffer, fusion_mode=self.fusion_mode)
             else:
                 hr1, lr1 = ops.ingest_u8(d[0])
                 hr2, lr2 = ops.ingest_u8(d[1])
                 frames, hc, wc, _, _ = run_two_view(hr1, hr2, lr1, lr2, self.nets, self.warp_mode, self.fusion_mode)
-                u8 = ops.canvas_to_u8(frames)
+                u8 = ops.canvas_to_u8(frames, out=self.out_buffer(tuple(frames.shape[0:1]) + (hc, wc, 3)))
             ev2 = torch.cuda.Event()
             ev2.record(self.comp)
+        self.consumed(d, ev2)
         return u8, hc, wc, ev2
 
     def _download(self, k, u8, ev):
@@ -777,27 +834,36 @@ class HostClipRunner:
         dst = self._host[k % len(self._host)][:m]
         self.down.wait_event(ev)
         with torch.cuda.stream(self.down):
-            u8.record_stream(self.down)
+            slot = getattr(u8, '_ss_slot', None)
+            if slot is None:
+                u8.record_stream(self.down)                # a tensor of the caller's, not of the ring
             self._timed_copy('d2h', self.down, u8.numel(), lambda: dst.copy_(u8, non_blocking=True))
             done = torch.cuda.Event()
             done.record(self.down)
+            if slot is not None:
+                self._out_done[slot] = done
         return dst, done
 
     @torch.no_grad()
     def run(self, clips):
+        from collections import deque
         it = iter(clips)
-        try:
-            nxt = self._upload(next(it))
-        except StopIteration:
+        ahead = deque()                      # uploads in flight: `prefetch` clips beyond the one being computed
+
+        def top_up():
+            while len(ahead) < self.prefetch + 1:
+                try:
+                    ahead.append(self._upload(next(it)))
+                except StopIteration:
+                    return
+        top_up()
+        if not ahead:
             return
         pending = None
         k = 0
-        while nxt is not None:
-            cur = nxt
-            try:
-                nxt = self._upload(next(it))
-            except StopIteration:
-                nxt = None
+        while ahead:
+            cur = ahead.popleft()
+            top_up()
             u8, hc, wc, ev = self._compute(*cur)
             host, done = self._download(k, u8, ev)
             if pending is not None:
@@ -870,9 +936,6 @@ class LongVideoStitcher:
         for s, e, d, ev in self._uploads(views):
             comp.wait_event(ev)
             with torch.cuda.stream(comp):
-                for t in d:
-                    t.record_stream(comp)
-                d = [t if t.is_contiguous() else t.contiguous() for t in d]
                 img_h, img_w = d[0].shape[1], d[0].shape[2]
                 if est is None:
                     est = JointEstimator(spatial_net, temporal_net, n, self.dev, cache2=mid_cache)
@@ -882,6 +945,9 @@ class LongVideoStitcher:
                 est.push(lrs[0], lrs[1])
                 if est23 is not None:
                     est23.push(None, lrs[2], mid_cache.pop())
+                used = torch.cuda.Event()
+                used.record(comp)
+            self.io.consumed(d, used)
         with torch.cuda.stream(comp):
             self.acc = smooth_stage(smooth_net, *est.result())
             if est23 is None:
@@ -910,20 +976,18 @@ class LongVideoStitcher:
         for s, e, d, ev in self._uploads(views):
             io.comp.wait_event(ev)
             with torch.cuda.stream(io.comp):
-                for t in d:
-                    t.record_stream(io.comp)
-                d = [t if t.is_contiguous() else t.contiguous() for t in d]
                 ms = [m[:, s:e].contiguous() for m in self.meshes]
                 if _u8_fused(self.fusion_mode):
-                    u8, _, _ = render_frames_u8(d, ms, self.warp_mode, bbox=self.bbox, size=(self.hc, self.wc),
-                                                prescaled=self.prescaled, fusion_mode=self.fusion_mode)
+                    u8, _, _ = render_frames_u8(list(d), ms, self.warp_mode, out=io.out_buffer, bbox=self.bbox,
+                                                size=(self.hc, self.wc), prescaled=self.prescaled, fusion_mode=self.fusion_mode)
                 else:
                     hrs = [ops.ingest_u8(t)[0] for t in d]
                     fr, _, _ = render_frames(hrs, ms, self.warp_mode, self.fusion_mode, prescaled=self.prescaled,
                                              bbox=self.bbox, size=(self.hc, self.wc))
-                    u8 = ops.canvas_to_u8(fr)
+                    u8 = ops.canvas_to_u8(fr, out=io.out_buffer((e - s, self.hc, self.wc, 3)))
                 ev2 = torch.cuda.Event()
                 ev2.record(io.comp)
+            io.consumed(d, ev2)
             host, done = io._download(k, u8, ev2)
             if pending is not None:
                 pending[0].synchronize()
