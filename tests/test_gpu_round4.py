@@ -341,3 +341,68 @@ def test_conv_pool2_in_splitk_reduce(dev, shape):
         assert torch.equal(gotg, wantg)
     finally:
         ops.WINOGRAD = old
+
+
+# ------------------------------------------------------------------ four heads in shared launches, stream overlap, host runner
+def test_quad_regressor_matches_separate_heads(dev, hip_nets):
+    """layers.run_regressor_quad (SpatialNet's ref / tgt heads + TemporalNet's head on two views as 4-group launches) against the
+    separate heads: same arithmetic per image, the conv engine's kernel choice follows the launch size -> motions within 1e-4 px
+    (the parity gate of the networks' outputs); chunked and single-chunk feeding, and the opt-in stream overlap bit for bit."""
+    from stabstitch2_amd import pipeline, layers
+    n = 20
+    _, lr = synth.make_clip_device(n, 360, 480, seed=7, device=dev)
+    old = layers.QUAD
+    try:
+        layers.QUAD = False
+        ref = pipeline.joint_stage(hip_nets[0], hip_nets[1], lr[0], lr[1], chunk=8)
+        layers.QUAD = True
+        got = pipeline.joint_stage(hip_nets[0], hip_nets[1], lr[0], lr[1], chunk=8)
+        one = pipeline.joint_stage(hip_nets[0], hip_nets[1], lr[0], lr[1], chunk=32)
+        pipeline.QUAD_OVERLAP = True
+        ovl = pipeline.joint_stage(hip_nets[0], hip_nets[1], lr[0], lr[1], chunk=8)
+    finally:
+        layers.QUAD = old
+        pipeline.QUAD_OVERLAP = False
+    for name, a, b, c, d in zip(('smotion1', 'smotion2', 'tmotion1', 'tmotion2'), ref, got, one, ovl):
+        close(b, a, 1e-4, 'quad vs separate heads: ' + name)
+        close(c, a, 1e-4, 'quad, one chunk vs separate heads: ' + name)
+        assert torch.equal(d, b), name                         # the second stream changes the schedule, not the arithmetic
+    assert float(got[2][0].abs().max()) == 0.0 and float(got[3][0].abs().max()) == 0.0      # frame 0: zero temporal motion
+
+
+def test_host_clip_runner_equals_resident(dev, hip_nets):
+    """HostClipRunner (pinned host uint8 in -> pinned host uint8 out through the staging rings, three streams) delivers the
+    bytes of run_two_view_u8 on the resident clip, clip after clip, AVERAGE and LINEAR; clips of different lengths reuse the
+    rings (a shorter clip takes slices)."""
+    from stabstitch2_amd import pipeline
+    h, w = 360, 480
+    clips = []
+    for sd, n in ((0, 12), (1, 12), (2, 9), (3, 12), (4, 12)):
+        hr, _ = synth.make_clip_device(n, h, w, seed=sd, device=dev)
+        clips.append([hr[v].permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).contiguous().cpu().pin_memory() for v in range(2)])
+    for fusion in ('AVERAGE', 'LINEAR'):
+        runner = pipeline.HostClipRunner(hip_nets, dev, fusion_mode=fusion)
+        got = [(v.clone(), hc, wc) for v, hc, wc in runner.run((c[0], c[1]) for c in clips)]
+        assert len(got) == len(clips)
+        for c, (v, hc, wc) in zip(clips, got):
+            want, whc, wwc, _, _ = pipeline.run_two_view_u8(c[0].to(dev), c[1].to(dev), hip_nets, fusion_mode=fusion, device=dev)
+            assert (hc, wc) == (whc, wwc) and torch.equal(v, want.cpu()), fusion
+
+
+@pytest.mark.parametrize('warp_mode,fusion_mode', [('FAST', 'LINEAR')])
+def test_multi_stream_other_modes(dev, hip_nets, warp_mode, fusion_mode):
+    """MultiOnlineStitcher with warp FAST / fusion LINEAR: graph replay equals eager, streams with equal inputs give equal bytes."""
+    from stabstitch2_amd.online import MultiOnlineStitcher
+    n, h, w = 9, 360, 480
+    hr, lr = _stream_inputs(2, n, h, w, dev, seeds=[8, 8])
+    a = MultiOnlineStitcher(hip_nets, h, w, streams=2, warp_mode=warp_mode, fusion_mode=fusion_mode)
+    b = MultiOnlineStitcher(hip_nets, h, w, streams=2, warp_mode=warp_mode, fusion_mode=fusion_mode, use_graph=False)
+    for t in range(n):
+        x = [hr[0][:, t].contiguous(), hr[1][:, t].contiguous(), lr[0][:, t].contiguous(), lr[1][:, t].contiguous()]
+        ga, gb = a.push(*x), b.push(*x)
+        for s in range(2):
+            assert len(ga[s]) == len(gb[s])
+            for fa, fb in zip(ga[s], gb[s]):
+                assert torch.equal(fa, fb)
+        for f0, f1 in zip(ga[0], ga[1]):
+            assert torch.equal(f0, f1)
