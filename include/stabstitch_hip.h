@@ -142,7 +142,8 @@ SS_API int ss_maxpool_nhwc_split(const float* in, float* out0, float* out1, int 
 /* K5: nn.Linear (+ReLU): y[m][nout] = x[m][k] . w[nout][k] + b  (spatial_network.py:170-178, 211-219) */
 SS_API int ss_linear(const float* x, const float* w, const float* b, float* y, int m, int k, int nout, int relu,
               void* stream);
-/* `groups` <= 8 fully connected layers of identical shape in one launch: x [groups][m][k] (group stride x_group_stride floats),
+/* regressNet2_part2_ref / _tgt (spatial_network.py:233-259) and TemporalNet's regressNet2_part2 on two views
+ * (temporal_network.py:87-105) share their launches: `groups` <= 8 fully connected layers of identical shape in one launch: x [groups][m][k] (group stride x_group_stride floats),
  * w [groups][nout][k], b [groups][nout] or NULL; group g's [m][nout] result goes to y_groups[g] (HOST array of device pointers:
  * each regressor head's output lands where its consumer reads it).  k % 4 == 0.  Row results equal ss_linear's bit for bit. */
 SS_API int ss_linear_grouped(const float* x, long long x_group_stride, const float* w, const float* b,
@@ -168,7 +169,7 @@ SS_API int ss_cost_volume(const float* x1, const float* x2, float* out, int n, i
  * cost_volume(x1, x2), cost_volume(x2, x1) */
 SS_API int ss_cost_volume_bidir(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
                          int out_cs, void* stream);
-/* tile height of the cost-volume kernel (process-wide A/B knob): 0 = the library's choice, 4 or 8 output rows x 16 columns per
+/* tile height of the cost-volume kernel (spatial_network.py:333-358; process-wide A/B knob): 0 = the library's choice, 4 or 8 output rows x 16 columns per
  * workgroup; identical results. */
 SS_API int ss_cost_volume_set_tile(int ty);
 
@@ -283,7 +284,7 @@ SS_API int ss_linear_blend(const float* ref, const float* tgt, const float* ref_
  * blend pass); ws: ss_linear_clip_workspace_floats(frames, views, hc, wc) floats.  Bit-identical, frame by frame, to
  * ss_tps_warp_views + ss_linear_blend (+ ss_mask_union + ss_linear_blend). */
 SS_API long long ss_linear_clip_workspace_floats(int frames, int views, int hc, int wc);
-/* form of the clip blend kernel (process-wide, for A/B runs and the equivalence test): rows = 0 the default (rolling pass,
+/* form of the clip blend kernel (the blur + blend of linear_blender, test_online_tra.py:52-58; process-wide, for A/B runs and the equivalence test): rows = 0 the default (rolling pass,
  * strips of 64 columns x 96 rows per wave), > 0 that many rows per strip, < 0 the 64 x 64-tile kernel; identical output. */
 SS_API int ss_linear_clip_set_rows(int rows);
 SS_API int ss_render_linear_clip(const float* const* views_base, const float* source, const float* T, float* out,
@@ -320,7 +321,7 @@ SS_API int ss_three_view_finish(const float* n1, const float* n3, const float* m
  * out [frames][views][63][2] (one call per view assembles it; test_online_tra.py:129-136) */
 SS_API int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,
                             float img_h, float img_w, void* stream);
-/* the same with ONE CANVAS BOX PER FRAME (bboxes [frames][4]) and frame f's mesh at mesh + f * mesh_frame_stride floats: S live
+/* the same (test_online_tra.py:129-136) with ONE CANVAS BOX PER FRAME (bboxes [frames][4]) and frame f's mesh at mesh + f * mesh_frame_stride floats: S live
  * streams, each with its own fixed canvas, normalised in one launch per view (batch-of-streams streaming mode) */
 SS_API int ss_mesh_normalize_views_boxes(const float* mesh, long long mesh_frame_stride, const float* bboxes, float* out,
                                   int frames, int view, int views, float img_h, float img_w, void* stream);
@@ -359,7 +360,7 @@ SS_API int ss_smooth_stitch(const float* smesh1, const float* smesh2, const floa
  * floats `delta` (>= block) further.  (window - 1) * elems <= 2048. */
 SS_API int ss_window_push(float* ring, const float* src, const long long* src_off, int rings, int window, int elems,
                    float* state, int blocks, int block, long long stride, long long delta, void* stream);
-/* S streams advancing together (batch-of-streams streaming mode): groups x per rings, ring g * per + j takes the row at
+/* S streams advancing together (batch-of-streams streaming mode; per stream the window bookkeeping of test_online_tra.py:359-392): groups x per rings, ring g * per + j takes the row at
  * src + src_off[g] + j * elems (src_off: HOST array of `groups` <= 8 offsets, one per ring KIND; per = S).  With more than one
  * state block, stride >= delta + block (the blocks move without ordering between them). */
 SS_API int ss_window_push_groups(float* ring, const float* src, const long long* src_off, int groups, int per, int window,
