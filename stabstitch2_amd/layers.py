@@ -301,40 +301,43 @@ def run_regressor_pair(x, pp, chunk=None, outs=None):
 QUAD = os.environ.get('SS_QUAD_REGRESSOR', '1') == '1'
 
 
-def quad_regressors(pp_pair, p_temp):
-    """pp_pair: pair_regressors(r2_ref, r2_tgt); p_temp: TemporalNet's prepared regressor -> weights of the 4-head launches
-    (heads: ref, tgt, temporal view 1, temporal view 2; the temporal filters appear twice)."""
-    convs = [torch.cat((wp, wt[None], wt[None]), 0).contiguous() for wp, wt in zip(pp_pair['convs'][1:], p_temp['convs'][1:])]
+def quad_regressors(pp_pair, p_temp, gt=2):
+    """pp_pair: pair_regressors(r2_ref, r2_tgt); p_temp: TemporalNet's prepared regressor -> weights of the (2 + gt)-head
+    launches (heads: ref, tgt, then TemporalNet's on gt = 2 views -- its filters appear gt times -- or on one view)."""
+    convs = [torch.cat((wp,) + (wt[None],) * gt, 0).contiguous() for wp, wt in zip(pp_pair['convs'][1:], p_temp['convs'][1:])]
     fa, fb, ft = pp_pair['fc'][0], pp_pair['fc'][1], p_temp['fc']
-    fc = [(torch.stack((fa[l][0], fb[l][0], ft[l][0], ft[l][0]), 0).contiguous(),
-           torch.stack((fa[l][1], fb[l][1], ft[l][1], ft[l][1]), 0).contiguous()) for l in range(3)]
+    fc = [(torch.stack((fa[l][0], fb[l][0]) + (ft[l][0],) * gt, 0).contiguous(),
+           torch.stack((fa[l][1], fb[l][1]) + (ft[l][1],) * gt, 0).contiguous()) for l in range(3)]
     return {'conv1_pair': pp_pair['convs'][0], 'conv1_t': p_temp['convs'][0], 'convs': convs, 'fc': fc}
 
 
-def get_quad(spatial_net, temporal_net):
-    """The 4-head weights of a (SpatialNet, TemporalNet) pair, cached on SpatialNet's prepared dict and keyed on both nets'
-    weight versions (rebuilt when either was reloaded / moved)."""
+def get_quad(spatial_net, temporal_net, gt=2):
+    """The (2 + gt)-head weights of a (SpatialNet, TemporalNet) pair, cached on SpatialNet's prepared dict and keyed on both
+    nets' weight versions (rebuilt when either was reloaded / moved)."""
     sp, tp = spatial_net._prepared(), temporal_net._prepared()
     ver = (spatial_net.weights_version, temporal_net.weights_version)
     if sp.get('quad_version') != ver:
-        sp['quad'] = quad_regressors(sp['r2_pair'], tp['r2'])
+        sp['quad'] = {}
         sp['quad_version'] = ver
-    return sp['quad']
+    if gt not in sp['quad']:
+        sp['quad'][gt] = quad_regressors(sp['r2_pair'], tp['r2'], gt)
+    return sp['quad'][gt]
 
 
 def run_regressor_quad(cv_s, cv_t, q, outs):
-    """cv_s [2,b,h,w,124] (both directions of SpatialNet's stage 2), cv_t [2,b,h,w,52] (TemporalNet, two views);
-    outs: four contiguous destinations of b * 126 floats (offset_2_ref, offset_2_tgt, temporal motions of view 1 / view 2)."""
-    b = cv_s.shape[1]
-    assert cv_t.shape[0] == 2 and cv_t.shape[1] == b and b <= REG_CHUNK
-    y = torch.empty((4, b) + tuple(cv_s.shape[2:4]) + (q['conv1_pair'].shape[1],), device=cv_s.device, dtype=torch.float32)
+    """cv_s [2,b,h,w,124] (both directions of SpatialNet's stage 2), cv_t [gt,b,h,w,52] (TemporalNet, gt = 2 views or 1);
+    outs: 2 + gt contiguous destinations of b * 126 floats (offset_2_ref, offset_2_tgt, temporal motions per view)."""
+    b, gt = cv_s.shape[1], cv_t.shape[0]
+    g = 2 + gt
+    assert cv_t.shape[1] == b and b <= REG_CHUNK and q['convs'][0].shape[0] == g and len(outs) == g
+    y = torch.empty((g, b) + tuple(cv_s.shape[2:4]) + (q['conv1_pair'].shape[1],), device=cv_s.device, dtype=torch.float32)
     ops.conv_grouped(cv_s, q['conv1_pair'], None, None, stride=1, pad=(0, 1, 1), relu=True, out=y[0:2])
-    ops.conv(cv_t.view((2 * b,) + tuple(cv_t.shape[2:])), q['conv1_t'], None, stride=1, pad=(0, 1, 1), relu=True,
-             out=y[2:4].view((2 * b,) + tuple(y.shape[2:])))
+    ops.conv(cv_t.view((gt * b,) + tuple(cv_t.shape[2:])), q['conv1_t'], None, stride=1, pad=(0, 1, 1), relu=True,
+             out=y[2:g].view((gt * b,) + tuple(y.shape[2:])))
     x = y
     for i, w in enumerate(q['convs']):          # conv2 .. conv8: a 2x2 max-pool rides behind every second convolution
         x = ops.conv_grouped(x, w, None, None, stride=1, pad=(0, 1, 1), relu=True, pool2=not (i & 1))
-    h = x.reshape(4, b, -1)
+    h = x.reshape(g, b, -1)
     if h.shape[2] != q['fc'][0][0].shape[2]:
         raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
                          % (q['fc'][0][0].shape[2], h.shape[2]))

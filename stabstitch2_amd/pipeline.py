@@ -167,8 +167,8 @@ class JointEstimator:
         xa, xb = L.run_stem_shared([lr2] if cache1 is not None else [lr1, lr2], sp['stem_pair'])
         if cache1 is None and self.tmotion1 is not None:
             xb = xb[b:]                                     # TemporalNet continues on view 2 only
-        if L.QUAD and cache1 is None and self.tmotion1 is None and b <= L.REG_CHUNK:
-            self._quad(xa, xb, b, s, e)
+        if L.QUAD and (cache1 is None) == (self.tmotion1 is None) and b <= L.REG_CHUNK:
+            self._quad(xa, xb, b, s, e, cache1)
         elif JOINT_OVERLAP:
             # SpatialNet (main stream) and TemporalNet (side stream) are independent behind the shared stem: two chains of
             # launches whose partially filled last rounds top each other up
@@ -185,18 +185,21 @@ class JointEstimator:
             self._temporal(xb, b, s, e)
         self.pos = e
 
-    def _quad(self, xa, xb, b, s, e):
-        """Both nets of a 2-view chunk with the four regressor heads in shared launches (layers.run_regressor_quad): SpatialNet's
+    def _quad(self, xa, xb, b, s, e, cache1=None):
+        """Both nets of a 2-view chunk with the regressor heads in shared launches (layers.run_regressor_quad): SpatialNet's
         ref / tgt heads on the b pairs, TemporalNet's head on b consecutive-frame pairs per view -- the first chunk has b - 1
         (frame 0 has no predecessor): its head runs on a zero cost volume in row 0, whose result lands on frame 0's motion
-        and is replaced by the zero motion of temporal_network.py:31-33."""
+        and is replaced by the zero motion of temporal_network.py:31-33.  With `cache1` (second pair of a three-view clip:
+        view 1's trunk features and temporal motions come from the first pair) only view 2 goes through the trunks and
+        TemporalNet's head runs on ONE view: three heads per launch."""
         L, sp, tp = self.L, self.sp, self.tp
         lead = 0 if s == 0 else 1
+        nv = len(self.views)
 
         def temporal_side():
-            f = L.run_trunk_body(xb, tp['s1'])                # TemporalNet features [2b,45,60,128], view-major
-            cv_t = torch.empty((2, b, f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
-            for i in range(2):
+            f = L.run_trunk_body(xb, tp['s1'])                # TemporalNet features [nv*b,45,60,128], view-major
+            cv_t = torch.empty((nv, b, f.shape[1], f.shape[2], 52), device=f.device, dtype=torch.float32)
+            for i in range(nv):
                 fi = f[i * b:(i + 1) * b]
                 if lead:
                     ops.cost_volume(self.carry[i], fi[0:1], 3, out=cv_t[i, 0:1])
@@ -210,10 +213,12 @@ class JointEstimator:
             f64 = L.run_trunk_body(xa, sp['s1'])
             f32 = L.run_stage2(f64, sp['s2'])
             if self.cache2 is not None:
-                self.cache2.append((f64[b:], f32[b:]))
+                self.cache2.append((f64[b:], f32[b:]) if cache1 is None else (f64, f32))
             return f64, f32
 
         def spatial_chain(f64, f32):
+            if cache1 is not None:                           # view 1's features from the earlier pair, view 2's from this pass
+                return self.spatial_net.forward_pair_cv(cache1[0], f64, cache1[1], f32, LR_H, LR_W)
             return self.spatial_net.forward_pair_cv(f64[:b], f64[b:], f32[:b], f32[b:], LR_H, LR_W)
 
         if QUAD_OVERLAP:
@@ -236,13 +241,13 @@ class JointEstimator:
             f, cv_t = temporal_side()
         off_ref = torch.empty((b, 126), device=f.device, dtype=torch.float32)
         off_tgt = torch.empty((b, 126), device=f.device, dtype=torch.float32)
-        L.run_regressor_quad(cv_s, cv_t, L.get_quad(self.spatial_net, self.temporal_net),
-                             [off_ref, off_tgt, self.tm[0, e - b:e].view(b, -1), self.tm[1, e - b:e].view(b, -1)])
+        L.run_regressor_quad(cv_s, cv_t, L.get_quad(self.spatial_net, self.temporal_net, nv),
+                             [off_ref, off_tgt] + [self.tm[i, e - b:e].view(b, -1) for i in range(nv)])
         if not lead:
-            for i in range(2):
+            for i in range(nv):
                 ops.fill(self.tm[i, 0])
         ops.spatial_meshes(off1, off_ref, off_tgt, LR_H, LR_W, out=(self.m1[s:e], self.m2[s:e]))
-        self._carry(f, b, 2, e)
+        self._carry(f, b, nv, e)
 
     def _carry(self, f, b, nv, e):
         # the last frame's features of every view in a small buffer of their own: a slice of `f` would keep the whole chunk's
