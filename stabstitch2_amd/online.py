@@ -323,7 +323,8 @@ class MultiOnlineStitcher:
                      out=(st['ts_out'][0], st['ts_out'][1]), lag=S)
         # shift the 4 S rings, append this push's rows (smesh v0, smesh v1, tsm v0, tsm v1 of every stream), and make the
         # current spatial motions the previous ones
-        ops.window_push(st['ring'], st['ts_out'], [1 * S * e, 3 * S * e, (4 * S + 1 * S) * e, (4 * S + 3 * S) * e], state=ps,
+        ops.window_push(st['ring'] if S > 1 else st['ring'].view(4, WINDOW, e), st['ts_out'],
+                        [1 * S * e, 3 * S * e, (4 * S + 1 * S) * e, (4 * S + 3 * S) * e], state=ps,
                         blocks=2, block=S * e, stride=2 * S * e, delta=S * e, per=S)
         r = st['ring'].view(4, S * WINDOW, 7, 9, 2)
         outs, _ = self.smooth.run_windows(r[0], r[1], r[2], r[3], S, WINDOW, WINDOW, 1)       # S windows, one per stream

@@ -406,3 +406,17 @@ def test_multi_stream_other_modes(dev, hip_nets, warp_mode, fusion_mode):
                 assert torch.equal(fa, fb)
         for f0, f1 in zip(ga[0], ga[1]):
             assert torch.equal(f0, f1)
+
+
+def test_multi_stream_of_one_equals_single_stream(dev, hip_nets):
+    """MultiOnlineStitcher(streams=1) launches what OnlineStitcher launches (same batch sizes, same kernel choices): bit-identical."""
+    from stabstitch2_amd.online import MultiOnlineStitcher, OnlineStitcher
+    n, h, w = 10, 360, 480
+    hr, lr = _stream_inputs(1, n, h, w, dev, seeds=[9])
+    a, b = MultiOnlineStitcher(hip_nets, h, w, streams=1), OnlineStitcher(hip_nets, h, w)
+    for t in range(n):
+        x = [hr[0][:, t].contiguous(), hr[1][:, t].contiguous(), lr[0][:, t].contiguous(), lr[1][:, t].contiguous()]
+        ga, gb = a.push(*x)[0], b.push(*x)
+        assert len(ga) == len(gb)
+        for fa, fb in zip(ga, gb):
+            assert torch.equal(fa, fb), t
