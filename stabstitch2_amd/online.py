@@ -299,7 +299,12 @@ class MultiOnlineStitcher:
               'ring': torch.stack([o['ring'] for o in one], 1).contiguous(),               # [4,S,7,126]
               'ts_out': torch.empty((2, 4 * S, e), device=d),
               'bboxes': torch.stack([s.bbox for s in self.single], 0).contiguous(),        # [S,4] the streams' fixed canvases
-              'out': [torch.empty((3, s.hc, s.wc), device=d) for s in self.single]}
+              'out': None, 'out_all': None}
+        if len({(s.hc, s.wc) for s in self.single}) == 1:       # equal canvas sizes: one render launch for all streams
+            st['out_all'] = torch.empty((S, 3, self.single[0].hc, self.single[0].wc), device=d)
+            st['out'] = [st['out_all'][s] for s in range(S)]
+        else:
+            st['out'] = [torch.empty((3, s.hc, s.wc), device=d) for s in self.single]
         self.static = st
         for s in self.single:                     # the per-stream buffers are not needed any more (bbox / canvas stay)
             s.static = None
@@ -333,6 +338,15 @@ class MultiOnlineStitcher:
         # the 2 S splines (a solve is latency-bound, ~48 us whether it holds 2 systems or 16), then the render stream by stream
         src = ops.mesh_normalize_views_boxes([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w)     # [S,2,63,2]
         T = ops.tps_solve_shared(src.view(2 * S, 63, 2), self.single[0].nrigid).view(S, 2, 2, 66)
+        if st['out_all'] is not None:
+            # all streams render onto canvases of ONE size (e.g. the caller fixed them): the S current frames are a clip
+            hc, wc = self.single[0].hc, self.single[0].wc
+            if self.fusion_mode == 'AVERAGE':
+                fp = ops.render_footprints(src, T, self.h, self.w, hc, wc) if pipeline.SKIP_OUTSIDE else None
+                ops.render_average_clip([st['hr1'], st['hr2']], src, T, hc, wc, self.warp_mode, out=st['out_all'], footprint=fp)
+            else:
+                ops.render_linear_clip([st['hr1'], st['hr2']], src, T, hc, wc, self.warp_mode, out=st['out_all'])
+            return
         for s, one in enumerate(self.single):
             one._render_solved(st['hr1'][s:s + 1], st['hr2'][s:s + 1], src[s], T[s], out=st['out'][s])
 

@@ -420,3 +420,22 @@ def test_multi_stream_of_one_equals_single_stream(dev, hip_nets):
         assert len(ga) == len(gb)
         for fa, fb in zip(ga, gb):
             assert torch.equal(fa, fb), t
+
+
+def test_multi_stream_shared_canvas_size_renders_as_one_clip(dev, hip_nets):
+    """Streams whose canvases have one size (the caller fixed them) render in ONE launch per push (the S current frames are a
+    clip): same bytes as the per-stream launches of single-stream stitchers with the same canvases' inputs."""
+    from stabstitch2_amd.online import MultiOnlineStitcher
+    n, h, w = 10, 360, 480
+    hr, lr = _stream_inputs(3, n, h, w, dev, seeds=[1, 2, 3])
+    canvas = (-120.0, 600.0, -10.0, 372.0)
+    a = MultiOnlineStitcher(hip_nets, h, w, streams=3, canvases=[canvas] * 3)                 # one size -> batched render
+    b = MultiOnlineStitcher(hip_nets, h, w, streams=3, canvases=[canvas, (-121.0, 600.0, -10.0, 372.0), canvas])   # sizes differ -> per stream
+    for t in range(n):
+        x = [hr[0][:, t].contiguous(), hr[1][:, t].contiguous(), lr[0][:, t].contiguous(), lr[1][:, t].contiguous()]
+        ga, gb = a.push(*x), b.push(*x)
+        for s in (0, 2):                                   # streams 0 and 2 have the same canvas in both stitchers
+            assert len(ga[s]) == len(gb[s])
+            for fa, fb in zip(ga[s], gb[s]):
+                assert torch.equal(fa, fb), (t, s)
+    assert a.static['out_all'] is not None and b.static['out_all'] is None

@@ -12,7 +12,9 @@ dev = torch.device('cuda:0'); torch.set_grad_enabled(False)
 nets, _ = bench.build_nets(dev)
 hr, lr = synth.make_clip_device(max(S, 2), 720, 1280, seed=0, device=dev)
 a = [hr[0][:S].contiguous(), hr[1][:S].contiguous(), lr[0][:S].contiguous(), lr[1][:S].contiguous()]
-st = MultiOnlineStitcher(nets, 720, 1280, streams=S) if S > 1 else None
+shared = len(sys.argv) > 3 and sys.argv[3] == 'shared'
+canv = [(-20.0, 1880.0, -15.0, 745.0)] * S if shared else None          # one canvas size for all streams: one render launch per push
+st = MultiOnlineStitcher(nets, 720, 1280, streams=S, canvases=canv) if S > 1 else None
 if S == 1:
     one = OnlineStitcher(nets, 720, 1280)
     push = lambda: one.push(*a)
@@ -26,4 +28,4 @@ for _ in range(pushes):
     push()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print('S=%d: %.3f ms per push, %.0f frames/s aggregate' % (S, dt / pushes * 1e3, S * pushes / dt))
+print('S=%d%s: %.3f ms per push, %.0f frames/s aggregate' % (S, ' shared canvas size' if S > 1 and shared else '', dt / pushes * 1e3, S * pushes / dt))
