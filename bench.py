@@ -573,6 +573,22 @@ def other_configs(nets, dev, args):
     entry('720p 2-view streaming, %d streams per push (aggregate over the streams)' % S, 40 * S, time.perf_counter() - t0, 1, hc_, wc_,
           note='MultiOnlineStitcher: S independent live pairs advance one frame per push as one batch (one HIP graph); '
                'steady state, 40 pushes of %d pairs' % S)
+    del stm
+    # the same with 16 streams whose canvases the caller fixed to ONE size (a rig of identical cameras): one render launch per push
+    S2 = 16
+    mh1, mh2 = hr[0][:S2].contiguous(), hr[1][:S2].contiguous()
+    ml1, ml2 = lr[0][:S2].contiguous(), lr[1][:S2].contiguous()
+    stm = MultiOnlineStitcher(nets, 720, 1280, streams=S2, canvases=[(-20.0, 1880.0, -15.0, 745.0)] * S2)
+    for _ in range(7 + 8):
+        stm.push(mh1, mh2, ml1, ml2)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        stm.push(mh1, mh2, ml1, ml2)
+    sync()
+    entry('720p 2-view streaming, %d streams per push on canvases of one size (aggregate)' % S2, 40 * S2, time.perf_counter() - t0, 1,
+          stm.canvas_sizes[0][0], stm.canvas_sizes[0][1], note='one clip-style render launch per push; steady state, 40 pushes of %d pairs' % S2)
+    del stm
     return res
 
 
@@ -815,6 +831,11 @@ def main():
     base = world == 1 and args.views == 2 and not args.online and args.io == 'f32' and not args.force_collective and not args.share_device
     if base and not args.no_other_configs:
         result['other_configs'] = other_configs(nets, dev, args)
+        for k, v in result['other_configs'].items():          # the reference's fps definition (D2H inside the clock) beside the resident path
+            if 'host->host' in k:
+                ref_fps = result['other_configs']['720p 2-view fusion LINEAR']['fps'] if 'LINEAR' in k else fps
+                v['frac_of_resident_path'] = round(v['fps'] / ref_fps, 3)
+                v['frac_of_resident_path_steady'] = round(v['fps_steady'] / ref_fps, 3)
     if base and not args.no_cpu_baseline:
         ncpu = os.cpu_count() or 1
         if args.cpu_threads > 0:
