@@ -547,7 +547,22 @@ def other_configs(nets, dev, args):
                 out = got[-1]
         return out, st.hc, st.wc
     dt, o, sg = measure(stream_once, sync, 1, 4, True)
-    entry('720p 2-view streaming (batch 1, one pair per push)', pushes, dt, 4, o[1], o[2], sg)
+    entry('720p 2-view streaming (batch 1, one pair per push)', pushes, dt, 4, o[1], o[2], sg,
+          note='fps = 96-push streams INCLUDING the 7 eager window-fill pushes and the graph capture (the figure of rounds 1-3); '
+               'fps_steady = graph replays only')
+    st1 = OnlineStitcher(nets, 720, 1280)
+    for t in range(12):
+        st1.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
+    sync()
+    t0 = time.perf_counter()
+    for t in range(200):
+        i = t % n
+        st1.push(hr[0][i:i + 1], hr[1][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1])
+    sync()
+    dts = time.perf_counter() - t0
+    res['720p 2-view streaming (batch 1, one pair per push)']['fps_steady'] = round(200 / dts, 1)
+    res['720p 2-view streaming (batch 1, one pair per push)']['ms_per_push_steady'] = round(dts / 200 * 1e3, 4)
+    del st1
     # batch of S independent live streams advancing together (one graph launch per push of S pairs)
     from stabstitch2_amd.online import MultiOnlineStitcher
     S = 8
