@@ -203,12 +203,31 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
                 }
         }
         __syncthreads();
-        for (int e = tid; e < 4 * CV_TX * out_cs; e += NT) {
-            int ch = e % out_cs;
-            int p = e / out_cs;
-            int yy = y0 + half * 4 + (p >> 4), xx = x0 + (p & 15);
-            if (yy < h && xx < w)
-                out[(((long long)n * h + yy) * w + xx) * out_cs + ch] = ch < D ? s2[p * (D + 3) + ch] : 0.f;
+        if (out_cs == D + 3) {
+            // the usual layout (channels padded to a multiple of 4 = the staging pitch): 16-byte stores, compile-time divisor.
+            // (The generic loop below divides by the RUNTIME out_cs twice per 4-byte store, 41 times per thread: ~2000 integer
+            // instructions beside the 7000 of the channel loop -- a quarter of the kernel, found in round 4 after the LDS
+            // conflicts, the FMA count, the occupancy and the tile order had each turned out not to be the limiter.)
+            constexpr int Q = (D + 3) / 4;
+            for (int e = tid; e < 4 * CV_TX * Q; e += NT) {
+                const int p = e / Q, q = e - p * Q;
+                const int yy = y0 + half * 4 + (p >> 4), xx = x0 + (p & 15);
+                if (yy < h && xx < w) {
+                    float4 v = *reinterpret_cast<const float4*>(&s2[p * (D + 3) + 4 * q]);
+                    if (4 * q + 1 >= D) v.y = 0.f;
+                    if (4 * q + 2 >= D) v.z = 0.f;
+                    if (4 * q + 3 >= D) v.w = 0.f;
+                    *reinterpret_cast<float4*>(&out[(((long long)n * h + yy) * w + xx) * (D + 3) + 4 * q]) = v;
+                }
+            }
+        } else {
+            for (int e = tid; e < 4 * CV_TX * out_cs; e += NT) {
+                int ch = e % out_cs;
+                int p = e / out_cs;
+                int yy = y0 + half * 4 + (p >> 4), xx = x0 + (p & 15);
+                if (yy < h && xx < w)
+                    out[(((long long)n * h + yy) * w + xx) * out_cs + ch] = ch < D ? s2[p * (D + 3) + ch] : 0.f;
+            }
         }
     }
 }

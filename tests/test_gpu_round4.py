@@ -439,3 +439,24 @@ def test_multi_stream_shared_canvas_size_renders_as_one_clip(dev, hip_nets):
             for fa, fb in zip(ga[s], gb[s]):
                 assert torch.equal(fa, fb), (t, s)
     assert a.static['out_all'] is not None and b.static['out_all'] is None
+
+
+def test_cost_volume_output_pitch_paths(dev):
+    """The cost volume's epilogue has a vectorised path for the usual output pitch (channels padded to a multiple of 4) and a
+    generic one for any other pitch: same values, zeros in the padding; both tile heights."""
+    from stabstitch2_amd import _hip as H, ops
+    torch.manual_seed(0)
+    for r, d in ((5, 121), (3, 49)):
+        a = torch.randn(2, 13, 21, 32, device=dev)
+        b = torch.randn(2, 13, 21, 32, device=dev)
+        ref = ops.cost_volume(a, b, r)                                # pitch d + 3
+        assert ref.shape[-1] == d + 3 and float(ref[..., d:].abs().max()) == 0.0
+        for ty in (4, 8):
+            H.lib().ss_cost_volume_set_tile(ty)
+            try:
+                wide = torch.full((2, 13, 21, d + 7), 7.0, device=dev)
+                H.call('ss_cost_volume', H.dptr(a), H.dptr(b), H.dptr(wide), 2, 13, 21, 32, r, d + 7, H.stream())
+                assert torch.equal(ops.cost_volume(a, b, r), ref)
+            finally:
+                H.lib().ss_cost_volume_set_tile(0)
+            assert torch.equal(wide[..., :d], ref[..., :d]) and float(wide[..., d:].abs().max()) == 0.0
