@@ -299,14 +299,14 @@ extern "C" int ss_l2norm_nhwc(const float* in, float* out, long long n_pixels, i
 
 // one wave per query position p
 __global__ void ccl_softmax_kernel(const float* __restrict__ Dm, float* __restrict__ flow_nchw,
-                                   float* __restrict__ flow_nhwc4, int h, int w, float scale) {
+                                   float* __restrict__ flow_nhwc4, int h, int w, float scale, SsFastDiv divW) {
     const int P = h * w;
     int n = blockIdx.y;
     int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (p >= P) return;
     const float* Db = Dm + (long long)n * P * P;
-    int py = p / w, pxx = p - py * w;
+    int py = (int)ss_fastdiv((uint32_t)p, divW), pxx = p - py * w;      // (k / w by multiply-shift: 24 runtime divisions per lane otherwise)
     float g[12];   // P <= 768
     float mx = -INFINITY;
 #pragma unroll
@@ -314,7 +314,7 @@ __global__ void ccl_softmax_kernel(const float* __restrict__ Dm, float* __restri
         int k = lane + 64 * cnt;
         g[cnt] = -INFINITY;
         if (k >= P) continue;
-        int ky = k / w, kx = k - ky * w;
+        int ky = (int)ss_fastdiv((uint32_t)k, divW), kx = k - ky * w;
         float s = 0.f;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
@@ -336,7 +336,7 @@ __global__ void ccl_softmax_kernel(const float* __restrict__ Dm, float* __restri
     for (int cnt = 0; cnt < 12; ++cnt) {
         int k = lane + 64 * cnt;
         if (k >= P) continue;
-        int ky = k / w, kx = k - ky * w;
+        int ky = (int)ss_fastdiv((uint32_t)k, divW), kx = k - ky * w;
         float e = expf(g[cnt] - mx);
         se += e;
         sx = fmaf(e, (float)(kx - pxx), sx);
@@ -379,6 +379,6 @@ extern "C" int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float*
                       (long long)P * c, (long long)P * P, nullptr, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(ccl_softmax_kernel, dim3(ss_cdiv(P, 4), n), dim3(256), 0, st, (const float*)Dm, flow_nchw,
-                       flow_nhwc4, h, w, softmax_scale);
+                       flow_nhwc4, h, w, softmax_scale, ss_fastdiv_make((uint32_t)w));
     return ss_launch_status();
 }
