@@ -79,17 +79,21 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
     const float* x1n = x1 + (long long)n * h * w * c;
     const float* x2n = x2 + (long long)n * h * w * c;
 
-    // accumulators as PAIRS for v_pk_fma_f32 (two fp32 FMAs per issue slot): (p, 2 i2), (p, 2 i2 + 1) share a[p]; the odd last
-    // displacement pairs over p.  Each accumulator still receives its products in channel order: same bits as scalar FMAs.
+    // accumulators as PAIRS for v_pk_fma_f32 (two fp32 FMAs per issue slot).  acc(p, i) += a[p] * v[p + i]: the window values
+    // arrive as aligned register pairs (v[2t], v[2t+1]), so pixel p pairs its displacements (i, i + 1) with p + i EVEN -- even p:
+    // (0,1) .. (KD-3, KD-2), left over i = KD - 1; odd p: (1,2) .. (KD-2, KD-1), left over i = 0 -- and a[p] is broadcast by
+    // op_sel: no register moves (the first packed version paired (2t, 2t+1) for every p and the compiler spent 26 v_mov per 44
+    // packed FMAs re-aligning the odd pixels' operands).  Each accumulator still receives its products in channel order.
     typedef float cv_f2 __attribute__((ext_vector_type(2)));
     constexpr int KP = KD / 2;
-    cv_f2 accp[4][KP], accl[2];
+    cv_f2 accp[4][KP];
+    float accs[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 4; ++p) {
 #pragma unroll
         for (int i = 0; i < KP; ++i) accp[p][i] = (cv_f2){0.f, 0.f};
-    accl[0] = (cv_f2){0.f, 0.f};
-    accl[1] = (cv_f2){0.f, 0.f};
+        accs[p] = 0.f;
+    }
 
     // staging items of this thread (fixed over the channel loop): x2 window [row][col][quad], x1 tile [pixel][quad];
     // element offset of channel 0 of the quad, or -1 outside the image.  The loads of chunk c0 + 16 are issued into
@@ -158,8 +162,8 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
         __syncthreads();
         if (c0 + CV_CC < c) fetch(c0 + CV_CC);
         if (active) {
-#pragma unroll 2
-            for (int cc = 0; cc < CV_CC; ++cc) {
+#pragma unroll 4
+            for (int cc = 0; cc < CV_CC; ++cc) {      // (fully unrolled the kernel needs 204-230 registers: two waves per SIMD)
                 const float4 a4 = *reinterpret_cast<const float4*>(&s1f[(cc >> 2) * QP1 + (cc & 3) * (CV_TY * CV_TX) + py * 16 + g4]);
                 const float a[4] = {a4.x, a4.y, a4.z, a4.w};
                 const float* row = s2 + (cc >> 2) * QP2 + (cc & 3) * WPIX;
@@ -176,12 +180,12 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const cv_f2 ap = {a[p], a[p]};
+                    const int o = p + (p & 1);                    // first v index of the pixel's pairs (even)
 #pragma unroll
                     for (int i = 0; i < KP; ++i)
-                        accp[p][i] = __builtin_elementwise_fma(ap, (cv_f2){v[p + 2 * i], v[p + 2 * i + 1]}, accp[p][i]);
+                        accp[p][i] = __builtin_elementwise_fma(ap, (cv_f2){v[o + 2 * i], v[o + 2 * i + 1]}, accp[p][i]);
+                    accs[p] = fmaf(a[p], (p & 1) ? v[p] : v[p + KD - 1], accs[p]);
                 }
-                accl[0] = __builtin_elementwise_fma((cv_f2){a[0], a[1]}, (cv_f2){v[KD - 1], v[KD]}, accl[0]);
-                accl[1] = __builtin_elementwise_fma((cv_f2){a[2], a[3]}, (cv_f2){v[KD + 1], v[KD + 2]}, accl[1]);
             }
         }
         __syncthreads();
@@ -196,8 +200,8 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int i = 0; i < KD; ++i) {
-                    const float av = i < 2 * KP ? ((i & 1) ? accp[p][i >> 1].y : accp[p][i >> 1].x)
-                                                : ((p & 1) ? accl[p >> 1].y : accl[p >> 1].x);
+                    const int ii = i - (p & 1);                 // position in the pixel's pair list (odd pixels start at i = 1)
+                    const float av = (ii < 0 || ii >= 2 * KP) ? accs[p] : ((ii & 1) ? accp[p][ii >> 1].y : accp[p][ii >> 1].x);
                     float v = av / fc;
                     s2[((py & 3) * 16 + g4 + p) * (D + 3) + j * KD + i] = v > 0.f ? v : 0.1f * v;
                 }
