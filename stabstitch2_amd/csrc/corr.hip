@@ -136,13 +136,17 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
         const bool cok = c0 + myq4 < c;
 #pragma unroll
         for (int k = 0; k < N2; ++k) {
-            r2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o2[k] >= 0 && cok) r2[k] = *reinterpret_cast<const float4*>(x2n + o2[k] + c0);
+            // branch free: an invalid item reads element 0 of the image (always mapped) and is zeroed by a select -- with an
+            // `if` around every load the compiler emitted ten exec-mask branches per chunk
+            const bool ok = o2[k] >= 0 && cok;
+            const float4 t = *reinterpret_cast<const float4*>(x2n + (ok ? o2[k] + c0 : 0));
+            r2[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int k = 0; k < N1; ++k) {
-            r1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o1[k] >= 0 && cok) r1[k] = *reinterpret_cast<const float4*>(x1n + o1[k] + c0);
+            const bool ok = o1[k] >= 0 && cok;
+            const float4 t = *reinterpret_cast<const float4*>(x1n + (ok ? o1[k] + c0 : 0));
+            r1[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     fetch(0);
