@@ -75,7 +75,7 @@ def _measured_limiters():
     try:
         with open(os.path.join(ROOT, 'profiles', 'r04_pmc_lds.json')) as f:
             l = json.load(f)['cost_volume']
-        out['cost_volume_kernel'] = {'unit': 'latency (no unit saturated)', 'lds_active_frac': l['lds_busy_frac'],
+        out['cost_volume_kernel'] = {'unit': 'valu issue (packed fp32 FMA + operand moves)', 'lds_active_frac': l['lds_busy_frac'],
                                      'lds_bank_conflict_frac': l['lds_bank_conflict_frac'],
                                      'source': 'profiles/r04_pmc_lds.json (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT)'}
         with open(os.path.join(ROOT, 'profiles', 'r04_pmc_mfma.json')) as f:
