@@ -847,17 +847,20 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     for (int i = 0; i < MT; ++i) acc[i] = 0.f;
     if ((k & 3) == 0) {
         int k4 = k >> 2;
+        const float4* xr[MT];           // rows past m re-read row m - 1, dropped at the store: no branches around the loads
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xr[i] = reinterpret_cast<const float4*>(x + (long long)(m0 + i < m ? m0 + i : m - 1) * k);
         for (int q = lane; q < k4; q += 64) {
             float4 wv = reinterpret_cast<const float4*>(wr)[q];
+            float4 xv[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xv[i] = xr[i][q];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if (m0 + i < m) {
-                    float4 xv = reinterpret_cast<const float4*>(x + (long long)(m0 + i) * k)[q];
-                    acc[i] = fmaf(wv.x, xv.x, acc[i]);
-                    acc[i] = fmaf(wv.y, xv.y, acc[i]);
-                    acc[i] = fmaf(wv.z, xv.z, acc[i]);
-                    acc[i] = fmaf(wv.w, xv.w, acc[i]);
-                }
+                acc[i] = fmaf(wv.x, xv[i].x, acc[i]);
+                acc[i] = fmaf(wv.y, xv[i].y, acc[i]);
+                acc[i] = fmaf(wv.z, xv[i].z, acc[i]);
+                acc[i] = fmaf(wv.w, xv[i].w, acc[i]);
             }
         }
     } else {
@@ -903,17 +906,22 @@ __global__ __launch_bounds__(256) void linear_grouped_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = 0.f;
     int k4 = k >> 2;
+    // rows past m re-read row m - 1 (results dropped at the store): no branch around the loads -- with `if (m0 + i < m)` the
+    // compiler put every row's load and its four FMAs into an exec-mask region of its own, MT load latencies in series per step
+    const float4* xr[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xr[i] = reinterpret_cast<const float4*>(x + (long long)(m0 + i < m ? m0 + i : m - 1) * k);
     for (int q = lane; q < k4; q += 64) {
         float4 wv = reinterpret_cast<const float4*>(wr)[q];
+        float4 xv[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xv[i] = xr[i][q];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            if (m0 + i < m) {
-                float4 xv = reinterpret_cast<const float4*>(x + (long long)(m0 + i) * k)[q];
-                acc[i] = fmaf(wv.x, xv.x, acc[i]);
-                acc[i] = fmaf(wv.y, xv.y, acc[i]);
-                acc[i] = fmaf(wv.z, xv.z, acc[i]);
-                acc[i] = fmaf(wv.w, xv.w, acc[i]);
-            }
+            acc[i] = fmaf(wv.x, xv[i].x, acc[i]);
+            acc[i] = fmaf(wv.y, xv[i].y, acc[i]);
+            acc[i] = fmaf(wv.z, xv[i].z, acc[i]);
+            acc[i] = fmaf(wv.w, xv[i].w, acc[i]);
         }
     }
     float bias = b ? b[(long long)g * nout + o] : 0.f;

@@ -299,6 +299,7 @@ def run_regressor_pair(x, pp, chunk=None, outs=None):
 # two sets (11 launches fewer per pass; on the <= 11 x 15 maps the merged launches fill the chip where each set alone left
 # half of it idle).  Per image the arithmetic is the separate heads'; the conv engine's kernel choice follows the launch size.
 QUAD = os.environ.get('SS_QUAD_REGRESSOR', '1') == '1'
+FC_GEMM_ROWS = int(os.environ.get('SS_FC_GEMM_ROWS', '16'))      # rows per head from which FC1 / FC2 of the heads run on the conv engine
 
 
 def quad_regressors(pp_pair, p_temp, gt=2):
@@ -341,8 +342,15 @@ def run_regressor_quad(cv_s, cv_t, q, outs):
     if h.shape[2] != q['fc'][0][0].shape[2]:
         raise ValueError('regressor expects %d features, got %d: the reference hard-wires 360x480 inputs'
                          % (q['fc'][0][0].shape[2], h.shape[2]))
-    h = ops.linear_grouped(h, q['fc'][0][0], q['fc'][0][1], relu=True)
-    h = ops.linear_grouped(h, q['fc'][1][0], q['fc'][1][1], relu=True)
+    for l in (0, 1):
+        w, bias = q['fc'][l]
+        if b >= FC_GEMM_ROWS:
+            # enough rows for a matrix-core tile: the grouped product as a 1x1 convolution on the conv engine (tools/ab_fc_grouped.py,
+            # 4 heads x 32 rows: 1536 -> 1024 in 14.9 us against 34.8 for the one-wave-per-neuron kernel, 1024 -> 512 in 9.0 against 13.9)
+            h = ops.conv_grouped(h.view(g, 1, 1, b, h.shape[2]), w.view(g, w.shape[1], 1, 1, 1, w.shape[2]), bias, None, stride=1,
+                                 pad=(0, 0, 0), relu=True).view(g, b, w.shape[1])
+        else:
+            h = ops.linear_grouped(h, w, bias, relu=True)
     ops.linear_grouped(h, q['fc'][2][0], q['fc'][2][1], relu=False, outs=outs)
 
 
