@@ -305,7 +305,11 @@ extern "C" int ss_l2norm_nhwc(const float* in, float* out, long long n_pixels, i
     return ss_launch_status();
 }
 
-// one wave per query position p
+// one wave per query position p; a lane owns 4 consecutive k (k = 256 * cnt + 4 * lane + j), so a tap of the 3 x 3 patch
+// correlation is ONE 16-byte load per lane (only 4-byte aligned: the tap shifts the column by dy * w + dx) and a wave reads
+// a row of D in 1 KB pieces: 27 loads per lane where the scalar mapping had 108.
+struct __attribute__((packed, aligned(4))) CclF4 { float v[4]; };
+
 __global__ void ccl_softmax_kernel(const float* __restrict__ Dm, float* __restrict__ flow_nchw,
                                    float* __restrict__ flow_nhwc4, int h, int w, float scale, SsFastDiv divW) {
     const int P = h * w;
@@ -314,41 +318,62 @@ __global__ void ccl_softmax_kernel(const float* __restrict__ Dm, float* __restri
     int lane = threadIdx.x & 63;
     if (p >= P) return;
     const float* Db = Dm + (long long)n * P * P;
-    int py = (int)ss_fastdiv((uint32_t)p, divW), pxx = p - py * w;      // (k / w by multiply-shift: 24 runtime divisions per lane otherwise)
+    int py = (int)ss_fastdiv((uint32_t)p, divW), pxx = p - py * w;      // (k / w by multiply-shift)
     float g[12];   // P <= 768
+    int gy[12], gx[12];
     float mx = -INFINITY;
 #pragma unroll
-    for (int cnt = 0; cnt < 12; ++cnt) {
-        int k = lane + 64 * cnt;
-        g[cnt] = -INFINITY;
-        if (k >= P) continue;
-        int ky = (int)ss_fastdiv((uint32_t)k, divW), kx = k - ky * w;
-        float s = 0.f;
+    for (int cnt = 0; cnt < 3; ++cnt) {
+        const int k0 = 256 * cnt + 4 * lane;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                int qy = py + dy, qx = pxx + dx, ry = ky + dy, rx = kx + dx;
-                if ((unsigned)qy < (unsigned)h && (unsigned)qx < (unsigned)w && (unsigned)ry < (unsigned)h &&
-                    (unsigned)rx < (unsigned)w)
-                    s += Db[(long long)(qy * w + qx) * P + (ry * w + rx)];
-            }
+        for (int j = 0; j < 4; ++j) {
+            g[4 * cnt + j] = -INFINITY;
+            gy[4 * cnt + j] = gx[4 * cnt + j] = 0;
         }
-        s *= scale;
-        g[cnt] = s;
-        mx = fmaxf(mx, s);
+        if (256 * cnt >= P) continue;                                   // wave uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(k0 + j, P - 1);
+            gy[4 * cnt + j] = (int)ss_fastdiv((uint32_t)k, divW);
+            gx[4 * cnt + j] = k - gy[4 * cnt + j] * w;
+        }
+        // the nine taps, branch free: all nine loads are issued before the first add (with an `if` around each the compiler
+        // serialised load -> wait -> add: one L2 round trip per tap).  A tap whose query pixel is outside the image reads
+        // entry 0; one whose column leaves [0, P) reads the neighbouring row (or the slack ss_ccl_workspace_floats adds
+        // after the last one); the per-element select drops both.  Same order of the adds as the per-tap form.
+        CclF4 tv[9];
+        bool qok[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const int qy = py + dy, qx = pxx + dx;
+            qok[t] = (unsigned)qy < (unsigned)h && (unsigned)qx < (unsigned)w && k0 < P;
+            const long long at = qok[t] ? (long long)(qy * w + qx) * P + (k0 + dy * w + dx) : 0ll;
+            tv[t] = *reinterpret_cast<const CclF4*>(Db + at);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ky = gy[4 * cnt + j], kx = gx[4 * cnt + j];
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool ok = qok[t] && (unsigned)(ky + dy) < (unsigned)h && (unsigned)(kx + dx) < (unsigned)w;
+                s += ok ? tv[t].v[j] : 0.f;
+            }
+            s = k0 + j < P ? s * scale : -INFINITY;
+            g[4 * cnt + j] = s;
+            mx = fmaxf(mx, s);
+        }
     }
     mx = ss_wave_max(mx);
     float se = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
-    for (int cnt = 0; cnt < 12; ++cnt) {
-        int k = lane + 64 * cnt;
-        if (k >= P) continue;
-        int ky = (int)ss_fastdiv((uint32_t)k, divW), kx = k - ky * w;
-        float e = expf(g[cnt] - mx);
+    for (int i = 0; i < 12; ++i) {
+        float e = expf(g[i] - mx);                                       // exp(-inf) = 0 past P
         se += e;
-        sx = fmaf(e, (float)(kx - pxx), sx);
-        sy = fmaf(e, (float)(ky - py), sy);
+        sx = fmaf(e, (float)(gx[i] - pxx), sx);
+        sy = fmaf(e, (float)(gy[i] - py), sy);
     }
     se = ss_wave_sum(se); sx = ss_wave_sum(sx); sy = ss_wave_sum(sy);
     if (lane == 0) {
@@ -364,7 +389,7 @@ __global__ void ccl_softmax_kernel(const float* __restrict__ Dm, float* __restri
 
 extern "C" long long ss_ccl_workspace_floats(int n, int h, int w, int c) {
     long long P = (long long)h * w;
-    return (long long)n * P * (2ll * c + P);
+    return (long long)n * P * (2ll * c + P) + 64;      // + slack: the softmax reads D in 16-byte pieces at shifted columns
 }
 
 extern "C" int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float* flow_nhwc4, int n, int h, int w,
