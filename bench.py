@@ -142,7 +142,7 @@ class ConvProbe:
                 nbytes = 4 * (x.numel() + wgt.numel() + out.numel() + (res.numel() if res is not None else 0))
                 stride = k.get('stride', 1)
                 # executed / direct-convolution flop of the kernel the engine actually launched (ops records its dispatch)
-                probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes, 16.0 / 36.0 if ops.last_conv_path == 'wino' else 1.0))
+                probe.records.append((e0, e1, m, cout, kt * kh * kw, cin, nbytes, {'wino': 16.0 / 36.0, 'wino43': 36.0 / 144.0}.get(ops.last_conv_path, 1.0)))
                 return out
             return timed
         ops.conv = wrap(ops.conv, False)

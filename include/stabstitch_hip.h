@@ -131,6 +131,19 @@ SS_API int ss_conv3x3_wino_pool2_nhwc(const float* in, const float* packed, cons
                                int cin, int cout, int relu, int out_cs, int groups, long long in_gs, long long u_gs,
                                long long out_gs, void* stream);
 
+/* The same stride-1 3x3 convolution as fused Winograd F(4x4,3x3): 36 instead of 64 (F(2x2,3x3)) or 144 (direct) products per
+ * 4x4 outputs and (cin, cout) pair -- 1.78x fewer MFMA flops than ss_conv3x3_wino_nhwc for a costlier input transform, run once
+ * per workgroup (csrc/wino43.hip).  Same layers of the reference (the ResNet-18 bodies: spatial_network.py:132-136,
+ * temporal_network.py:65-93); results agree with the other two forms to fp32 rounding of the larger transform constants
+ * (per layer ~2e-5 relative; end to end inside the gates of tests/: tools/sim_wino43.py).  cin % 16 == 0, cout % 64 == 0, else
+ * SS_ERR_UNSUPPORTED.  ss_wino43_pack: wgt [groups][cout][1][3][3][cin] -> packed [groups][ss_wino43_packed_floats].  All other
+ * arguments as ss_conv3x3_wino_nhwc. */
+SS_API long long ss_wino43_packed_floats(int cout, int cin);
+SS_API int ss_wino43_pack(const float* wgt, float* packed, int cout, int cin, int groups, void* stream);
+SS_API int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
+                                  int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
+                                  long long in_gs, long long u_gs, long long out_gs, void* stream);
+
 /* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */
 SS_API int ss_maxpool_nhwc(const float* in, float* out, int n, int h, int w, int c, int k, int stride, int pad,
                     void* stream);

@@ -38,6 +38,9 @@ SIGNATURES = {
     'ss_conv_uses_winograd': (c_i, [c_i] * 9),
     'ss_conv3x3_wino_nhwc': (c_i, [c_fp] * 5 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
     'ss_conv3x3_wino3_nhwc': (c_i, [c_fp] * 5 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
+    'ss_wino43_packed_floats': (c_ll, [c_i, c_i]),
+    'ss_wino43_pack': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
+    'ss_conv3x3_wino43_nhwc': (c_i, [c_fp] * 5 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
     'ss_conv3x3_wino_pool2_nhwc': (c_i, [c_fp] * 4 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
     'ss_maxpool_nhwc': (c_i, [c_fp, c_fp] + [c_i] * 7 + [c_st]),
     'ss_maxpool_nhwc_split': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 7 + [c_st]),

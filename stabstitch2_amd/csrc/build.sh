@@ -16,6 +16,6 @@ fi
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden $DEFS \
     "$HERE/conv.hip" "$HERE/wino.hip" "$HERE/corr.hip" "$HERE/geom.hip" "$HERE/render.hip" "$HERE/smooth.hip" "$HERE/metrics.hip" \
-    "$HERE/frameio.hip" "$HERE/stem.hip" \
+    "$HERE/frameio.hip" "$HERE/stem.hip" "$HERE/wino43.hip" \
     -o "$OUT"
 echo "built $OUT"

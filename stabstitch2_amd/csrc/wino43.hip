@@ -1,0 +1,460 @@
+// 3x3 / stride-1 / pad-1 convolution as FUSED Winograd F(4x4,3x3) on the fp32 matrix cores (gfx950).
+//
+// F(4x4,3x3) computes a 4x4 output tile from a 6x6 input tile with 36 multiplications per (cin, cout) pair where
+// F(2x2,3x3) (wino.hip) spends 64 and the direct form 144:  Y = A^T [ (G g G^T) .* (B^T d B) ] A  (Lavin & Gray 2015),
+// 36 independent GEMMs over cin, 1.78x fewer MFMA flops than wino.hip.  The price is the input transform: B^T has
+// entries 4, -5, 2 instead of +-1 and every VALU instruction takes ~4 clocks of the SIMD the matrix pipe shares
+// (tools/micro/mfma_valu: at ANY occupancy), so the transform is organised to run ONCE per workgroup and value:
+//
+//   workgroup = 512 threads = 8 waves, ONE per CU (144 KB of LDS); tile = 2 x 15 output tiles of 4x4 pixels (8 rows x 60
+//   columns of ONE image: the maps of this network are 60 / 120 wide; slots 15 and 31 of the MFMA's 32 rows idle) x 64
+//   output channels x all 36 positions.  Wave (a, b, blk) owns the 3 x 3 block of positions (3a .. 3a+2, 3b .. 3b+2) for
+//   the 32-channel block `blk`: 9 accumulator tiles of v_mfma_f32_32x32x2_f32 = 144 registers.
+//   K loop over cin in chunks of 16:
+//     stage 1 (cooperative, once per workgroup): thread (pixel column x, tile row ty, channel quad) loads its 6 raw rows
+//       (16-byte buffer loads, halo / image border through the descriptor's bounds check) one chunk ahead, applies the
+//       ROW transform B^T d (12 fma/add per channel) and writes V1[channel][ty][i][x] to LDS (two buffers, one barrier
+//       per chunk);
+//     stage 2 (per wave): lane (tile, k half) reads the 6 floats of row 3a+g of its tile's window (two conflict-free
+//       16-byte LDS reads) and forms the 3 A operands of its column block (6 fma/add) -- one channel per step;
+//     72 MFMAs per wave and chunk: B operand = transformed filters PRE-PACKED in the instruction's register layout (global ->
+//       VGPR, 1 KB coalesced loads, two groups of 12 MFMAs ahead).
+//   epilogue: the accumulators of one 32-channel block at a time go to LDS ([position][tile][cout]); every thread then owns
+//   (tile, cout) items: 36 LDS reads, A^T m A (100 fma/add), bias (folded BatchNorm), residual, ReLU, 16 dword stores
+//   (a wave writes 128-byte runs of 32 channels).
+// Results differ from wino.hip / the direct form by fp32 rounding of the larger transform constants; simulated end to end
+// against the reference goldens in tools/sim_wino43.py (profiles/r03_f43_simulation.txt) and gated in tests/.
+#include "common.h"
+#include <type_traits>
+
+typedef float x_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned x_u32x4 __attribute__((ext_vector_type(4)));
+typedef float x_f32x16 __attribute__((ext_vector_type(16)));
+typedef float x_f32x2 __attribute__((ext_vector_type(2)));
+
+struct W43P {
+    const float* in;
+    const float* U;          // packed transformed filters, see wino43_pack_kernel
+    const float* bias;
+    const float* res;
+    float* out;
+    int N, H, W, C, Co;      // C = input channels (multiple of 16), Co = output channels (multiple of 64)
+    int nchunk;              // C / 16
+    int relu, out_cs;
+    SsDiv32 divBx, divBy, divNcb;
+    unsigned nbx, nby, ncb;  // tile blocks per image row / column; 64-channel output blocks
+    long long in_gs, u_gs, out_gs;
+    unsigned in_bytes, out_bytes, u_bytes;
+#ifdef SS_TUNING
+    unsigned long long* dbg;            // per-workgroup phase stamps (tools/diag_wino43.py)
+#endif
+};
+
+#ifdef SS_TUNING
+#define X_STAMP(i) do { if (p.dbg) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X_STAMP(i) do { } while (0)
+#endif
+
+namespace {
+constexpr int X_TXU = 15;                    // tiles per tile row that carry pixels (slot 15 idles)
+constexpr int X_BH = 8, X_BW = 4 * X_TXU;    // output pixels of a block
+constexpr int X_RW = X_BW + 2;               // raw columns (62)
+constexpr int X_RWP = 64;                    // row pitch of V1 (dwords): tile row stride 6 * 64 = 0 (mod 64 banks)
+constexpr int X_TYS = 6 * X_RWP;             // tile-row stride
+constexpr int X_PL = 2 * X_TYS + 4;          // channel plane; = 4 (mod 8): the four channel quads of a pixel 2 lanes per bank
+constexpr int X_V1F = 16 * X_PL;             // dwords of one V1 buffer
+constexpr int X_DUMPF = 36 * 32 * 32;        // epilogue stage: [position][tile][cout of one 32-channel block]
+constexpr int X_SMEMF = X_DUMPF > 2 * X_V1F ? X_DUMPF : 2 * X_V1F;
+constexpr unsigned X_UPOS = 2048u;           // bytes of one packed position (2 halves x 64 lanes x 16 B)
+constexpr unsigned X_UCHUNK = 36u * X_UPOS;  // bytes per (32-cout block, chunk)
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const float* base, unsigned bytes) {
+    unsigned long long a = (unsigned long long)base;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* ub = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <bool RES>
+__global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = wave & 1;                              // 32-channel half of the workgroup's 64 output channels
+    const int pa = wave >> 2, pbb = (wave >> 1) & 1;        // position block: rows 3 pa .., columns 3 pbb ..
+#ifdef SS_TUNING
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    X_STAMP(0);
+
+    // XCD-aware block order (as wino.hip): every XCD gets one contiguous run of tile blocks
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x;
+        if (nwg >= 16) {
+            const unsigned q = nwg / 8, r = nwg % 8, xcd = lin % 8, idx = lin / 8;
+            lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+    }
+    const unsigned mb = ss_div32(lin, p.divNcb);
+    const unsigned cbk = lin - mb * p.ncb;                  // 64-channel output block
+    const unsigned t1 = ss_div32(mb, p.divBx);
+    const int bx = (int)(mb - t1 * p.nbx);
+    const unsigned img = ss_div32(t1, p.divBy);
+    const int by = (int)(t1 - img * p.nby);
+    const int oy0 = by * X_BH, ox0 = bx * X_BW;
+    const int grp = blockIdx.z;
+
+    const __amdgpu_buffer_rsrc_t rin = x_rsrc(p.in + (long long)grp * p.in_gs, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t ru = x_rsrc(p.U + (long long)grp * p.u_gs, p.u_bytes);
+
+    // ---- stage 1 item of this thread: (channel quad q, raw column xx, tile row ty); threads 496..511 carry no pixel: their
+    // loads are out of range (zeros) and their writes land in the two pad columns of V1
+    const int s1_q = tid & 3;
+    const int s1_pix = tid >> 2;
+    const bool s1_real = s1_pix < 2 * X_RW;
+    const int s1_ty = s1_real ? (s1_pix >= X_RW ? 1 : 0) : ((s1_pix >> 1) & 1);
+    const int s1_xx = s1_real ? s1_pix - s1_ty * X_RW : X_RW + (s1_pix & 1);
+    const int s1_iy0 = oy0 - 1 + 4 * s1_ty, s1_ix = ox0 - 1 + s1_xx;
+    const unsigned rowstep = (unsigned)p.W * (unsigned)p.C * 4u;
+    const unsigned rbase = ((((unsigned)img * p.H + (unsigned)s1_iy0) * p.W + (unsigned)s1_ix) * (unsigned)p.C + 4u * s1_q) * 4u;
+    // rows of the item that lie inside the image (bit r); v_bfe_i32 turns a bit into the all-ones "out of range" mask
+    int rmask = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+        rmask |= (s1_real && (unsigned)(s1_iy0 + r) < (unsigned)p.H && (unsigned)s1_ix < (unsigned)p.W) ? 0 : (1 << r);
+    const int s1_lds = (4 * s1_q) * X_PL + s1_ty * X_TYS + s1_xx;
+
+    // ---- this lane in the GEMMs (v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5]): tile lane & 31, channels
+    // 8 kh .. 8 kh + 7 of the chunk; 16-lane groups of a 16-byte LDS read hold tiles of both tile rows: rows are 0 (mod 64) apart
+    const int kh = lane >> 5;
+    const int m_tile = lane & 31;
+    const int t_src = (8 * kh) * X_PL + (m_tile >> 4) * X_TYS + (3 * pa) * X_RWP + 4 * (m_tile & 15);
+
+    const unsigned u_lane = (unsigned)lane * 16u;
+    // packed filters: [cout/32][chunk][pos 36][half][lane][4]
+    const unsigned u_wave = (cbk * 2u + (unsigned)blk) * (unsigned)p.nchunk * X_UCHUNK + (unsigned)((3 * pa) * 6 + 3 * pbb) * X_UPOS;
+
+    x_f32x16 acc[3][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][s][r] = 0.f;
+
+    x_f32x4 rr[6];
+    auto raw_issue = [&](int c) {
+        const unsigned coff = (unsigned)c * 64u;
+        int rm = rmask;
+        asm volatile("" : "+v"(rm));         // (left alone, hipcc hoists the six masks out of the K loop and spills them)
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            rr[r] = __builtin_bit_cast(x_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase + (unsigned)r * rowstep + coff) | (unsigned)__builtin_amdgcn_sbfe(rm, r, 1), 0, 0));
+    };
+    // row transform B^T d of channel k of the quad, written to V1 rows 0..5
+    auto s1_piece = [&](float* buf, int k) {
+        const float d0 = rr[0][k], d1 = rr[1][k], d2 = rr[2][k], d3 = rr[3][k], d4 = rr[4][k], d5 = rr[5][k];
+        float t1 = __builtin_fmaf(-4.f, d2, d4);
+        asm("" : "+v"(t1));
+        const float t2 = __builtin_fmaf(-4.f, d1, d3);
+        float t3 = d4 - d2;
+        asm("" : "+v"(t3));
+        const float t4 = d3 - d1;
+        float* w = buf + s1_lds + k * X_PL;
+        w[0 * X_RWP] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+        w[1 * X_RWP] = t1 + t2;
+        w[2 * X_RWP] = t1 - t2;
+        w[3 * X_RWP] = __builtin_fmaf(2.f, t4, t3);
+        w[4 * X_RWP] = __builtin_fmaf(-2.f, t4, t3);
+        w[5 * X_RWP] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    };
+    auto lds_barrier = [&]() {       // __syncthreads() minus its global-memory fence (it would drain every prefetch in flight)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+
+    // filters of one GROUP = (chunk, half h, position row g): three positions x 16 bytes (MFMA steps 4 h .. 4 h + 3)
+    x_f32x4 u[3][3];
+    auto u_issue = [&](int set, int c, int G) {
+        const int h = G / 3, g = G % 3;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int so = (int)__builtin_amdgcn_readfirstlane(u_wave + (unsigned)c * X_UCHUNK + (unsigned)(g * 6 + s) * X_UPOS + (unsigned)h * 1024u);
+            u[set][s] = __builtin_bit_cast(x_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane, so, 0));
+        }
+    };
+
+    // ---- prologue: chunk 0 row-transformed in LDS, chunk 1's rows and the first two filter groups in flight
+    raw_issue(0);
+    u_issue(0, 0, 0);
+    u_issue(1, 0, 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s1_piece(smem, k);
+    lds_barrier();
+    X_STAMP(1);
+    raw_issue(p.nchunk > 1 ? 1 : 0);
+
+    auto kloop = [&](auto bc) {
+        constexpr int B = decltype(bc)::value;          // column block of this wave (compile time: the column transform differs)
+        x_f32x4 rd[2][2];
+        float av[2][3];
+        // step m of a chunk = (half h = m / 12, position row g = (m / 4) % 3, channel e = m % 4)
+        auto rd_issue = [&](const float* buf, int m, int slot) {
+            const int h = m / 12, g = (m / 4) % 3, e = m % 4;
+            const float* src = buf + t_src + (4 * h + e) * X_PL + g * X_RWP;
+            rd[slot][0] = *reinterpret_cast<const x_f32x4*>(src);
+            rd[slot][1] = *reinterpret_cast<const x_f32x4*>(src + 4);
+        };
+        auto xf = [&](int slot) {
+            const float x0 = rd[slot][0][0], x1 = rd[slot][0][1], x2 = rd[slot][0][2], x3 = rd[slot][0][3];
+            const float x4 = rd[slot][1][0], x5 = rd[slot][1][1];
+            if constexpr (B == 0) {
+                float s1 = __builtin_fmaf(-4.f, x2, x4);
+                asm("" : "+v"(s1));                     // keeps hipcc from pairing s1 / s2 into v_pk_fma_f32 (+ 2 v_mov each): packed
+                const float s2 = __builtin_fmaf(-4.f, x1, x3);     // fp32 does not co-issue with the matrix pipe
+                av[slot][0] = __builtin_fmaf(4.f, x0, __builtin_fmaf(-5.f, x2, x4));
+                av[slot][1] = s1 + s2;
+                av[slot][2] = s1 - s2;
+            } else {
+                const float s3 = x4 - x2, s4 = x3 - x1;
+                av[slot][0] = __builtin_fmaf(2.f, s4, s3);
+                av[slot][1] = __builtin_fmaf(-2.f, s4, s3);
+                av[slot][2] = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));
+            }
+        };
+        rd_issue(smem, 0, 0);
+        rd_issue(smem, 1, 1);
+        xf(0);
+        // one chunk = 24 steps.  MORE (compile time): a chunk follows -- its row transform, its first two steps' operands and its
+        // filters are produced inside this one.  The last chunk is a second copy without them: branches inside the stream cost
+        // more than the code (tried: +19 % K-loop time), and nothing stays in flight in front of the epilogue's barrier.
+        auto chunk = [&](int c, auto more_c) {
+            constexpr bool MORE = decltype(more_c)::value;
+            float* bc_ = smem + (c & 1) * X_V1F;                // V1 of chunk c
+            float* bn = smem + ((c + 1) & 1) * X_V1F;           // chunk c + 1 (written during this chunk)
+            const int c2 = c + 2 < p.nchunk ? c + 2 : c + 1;    // (the last but one chunk re-requests its successor's rows: unused)
+#pragma unroll
+            for (int m = 0; m < 24; ++m) {
+                const int G = m / 4, g = G % 3, e = m % 4;
+                __builtin_amdgcn_sched_barrier(0);
+                if (m + 2 < 24) rd_issue(bc_, m + 2, m & 1);            // (slot m & 1 was consumed by the previous step's xf)
+                else if (MORE) rd_issue(bn, m + 2 - 24, m & 1);
+                if (m + 1 < 24 || MORE) xf((m + 1) & 1);
+                if (e == 0) {                                    // first step of a group: the filters of group G + 2
+                    if (G + 2 < 6) u_issue((G + 2) % 3, c, G + 2);
+                    else if (MORE) u_issue((G + 2) % 3, c + 1, G + 2 - 6);
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    acc[g][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m & 1][s], u[G % 3][s][e], acc[g][s], 0, 0, 0);
+                if constexpr (MORE) {
+                    // stage 1 of chunk c + 1 between the MFMAs of steps 8..14 (its rows were requested a chunk ago)
+                    if (m == 8) s1_piece(bn, 0);
+                    if (m == 10) s1_piece(bn, 1);
+                    if (m == 12) s1_piece(bn, 2);
+                    if (m == 14) s1_piece(bn, 3);
+                    // behind step 16's filter loads: buffer loads return in order, the next filter wait (8 steps on) covers these too
+                    if (m == 17) raw_issue(c2);
+                    // every V1 read of chunk c has been issued (step 23's, two steps ahead); behind the barrier chunk c + 1 is read
+                    if (m == 21) { __builtin_amdgcn_sched_barrier(0); lds_barrier(); }
+                }
+            }
+        };
+        for (int c = 0; c + 1 < p.nchunk; ++c) chunk(c, std::true_type{});
+        chunk(p.nchunk - 1, std::false_type{});
+    };
+    if (pbb == 0) kloop(std::integral_constant<int, 0>{});
+    else kloop(std::integral_constant<int, 1>{});
+    X_STAMP(2);
+
+    // ---------------------------------------------------------------- epilogue: Y = A^T M A, bias, residual, ReLU
+    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    const __amdgpu_buffer_rsrc_t rout = x_rsrc(out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = x_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
+    const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+    const int e_n = tid & 31;
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        __syncthreads();                                    // V1 (phase 0) / the previous phase's stage is free
+        if (blk == ph) {
+            float* d = smem + ((3 * pa) * 6 + 3 * pbb) * 1024 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        d[(g * 6 + s) * 1024 + tile * 32] = acc[g][s][r];
+                    }
+        }
+        __syncthreads();
+        X_STAMP(3 + ph);
+        const float bias = p.bias ? p.bias[(long long)grp * p.Co + cbk * 64 + ph * 32 + e_n] : 0.f;
+        // this thread's two items: tiles (0, tx) and (1, tx) for output channel e_n, as the halves of packed registers (nothing
+        // multiplies here: v_pk_add_f32 / v_pk_fma_f32 do two items' work per issue slot); their stage entries are 512 floats apart
+        const int tx = tid >> 5;
+        const float* s0 = smem + tx * 32 + e_n;
+        // pixel offsets: row part per (item, a) -- 0xFFFF0000 (past every buffer the launcher admits) for rows outside the image --
+        // plus y * pixel pitch, or-ed with the column's out-of-range mask (columns past the image, the idle tile slot)
+        const int oxb = ox0 + 4 * tx;
+        const unsigned pixb = (unsigned)p.out_cs * 4u, rowb = pixb * (unsigned)p.W;
+        const unsigned base = ((((unsigned)img * p.H + oy0) * p.W + oxb) * (unsigned)p.out_cs + cbk * 64 + ph * 32 + e_n) * 4u;
+        unsigned roff[8], cinv[4];
+#pragma unroll
+        for (int a2 = 0; a2 < 8; ++a2) roff[a2] = oy0 + a2 < p.H ? base + (unsigned)a2 * rowb : 0xFFFF0000u;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) cinv[y] = (tx < X_TXU && oxb + y < p.W) ? 0u : 0xFFFFFFFFu;
+        x_f32x2 rv[2][4];
+        auto res_issue = [&](int y, x_f32x2 (&dst)[4]) {
+            if constexpr (RES) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    dst[a][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (roff[a] + (unsigned)y * pixb) | cinv[y], 0, 0));
+                    dst[a][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (roff[4 + a] + (unsigned)y * pixb) | cinv[y], 0, 0));
+                }
+            }
+        };
+        res_issue(0, rv[0]);
+        // rows of M -> T[i][y] = sum_j M[i][j] A[j][y]
+        const x_f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f}, bias2 = {bias, bias};
+        x_f32x2 t[6][4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            x_f32x2 m[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[j] = (x_f32x2){s0[(i * 6 + j) * 1024], s0[(i * 6 + j) * 1024 + 512]};
+            const x_f32x2 p12 = m[1] + m[2], q12 = m[1] - m[2], p34 = m[3] + m[4], q34 = m[3] - m[4];
+            t[i][0] = (m[0] + p12) + p34;
+            t[i][1] = __builtin_elementwise_fma(c2, q34, q12);
+            t[i][2] = __builtin_elementwise_fma(c4, p34, p12);
+            t[i][3] = __builtin_elementwise_fma(c8, q34, q12) + m[5];
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            if (y + 1 < 4) res_issue(y + 1, rv[(y + 1) & 1]);
+            const x_f32x2 p12 = t[1][y] + t[2][y], q12 = t[1][y] - t[2][y], p34 = t[3][y] + t[4][y], q34 = t[3][y] - t[4][y];
+            x_f32x2 o[4];
+            o[0] = (t[0][y] + p12) + p34;
+            o[1] = __builtin_elementwise_fma(c2, q34, q12);
+            o[2] = __builtin_elementwise_fma(c4, p34, p12);
+            o[3] = __builtin_elementwise_fma(c8, q34, q12) + t[5][y];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                x_f32x2 v = o[a] + bias2;
+                if (RES) v = v + rv[y & 1][a];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[0], relu_lo)), rout, (roff[a] + (unsigned)y * pixb) | cinv[y], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[1], relu_lo)), rout, (roff[4 + a] + (unsigned)y * pixb) | cinv[y], 0, 0);
+            }
+        }
+    }
+#ifdef SS_TUNING
+    if (p.dbg && tid == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 5; ++i) d[i] = ts[i];
+        d[5] = __builtin_amdgcn_s_memtime();
+        d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+#endif
+}
+
+// Packed transformed filters in the MFMA B-operand register layout (one 16-byte load per lane = 4 MFMA steps):
+//   U[cout/32][chunk][pos 36][half][lane][e] = (G g G^T)[pos] of (cout = 32 cb + (lane & 31), cin = 16 chunk + 8 (lane >> 5) + 4 half + e)
+// fp64 accumulation, rounded once.   wgt: [cout][1][3][3][cin] (BN folded).
+__global__ void wino43_pack_kernel(const float* __restrict__ wgt, float* __restrict__ U, int cout, int cin, int nchunk,
+                                   long long w_gs, long long u_gs) {
+    const long long per = (long long)(cout / 32) * nchunk * 36 * 2 * 64;   // float4 slots per group
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per) return;
+    const int grp = blockIdx.y;
+    const int lane = (int)(idx & 63);
+    const int half = (int)((idx >> 6) & 1);
+    const long long pc = idx >> 7;
+    const int pos = (int)(pc % 36);
+    const long long cc = pc / 36;
+    const int chunk = (int)(cc % nchunk);
+    const int cb = (int)(cc / nchunk);
+    const int co = cb * 32 + (lane & 31);
+    const int i = pos / 6, j = pos % 6;
+    const double G[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    float v[4];
+    for (int e = 0; e < 4; ++e) {
+        const int ci = chunk * 16 + 8 * (lane >> 5) + 4 * half + e;
+        double acc = 0.0;
+        if (ci < cin) {
+            const float* g = wgt + (long long)grp * w_gs + (long long)co * 9 * cin + ci;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) acc += G[i][a] * (double)g[(a * 3 + b) * cin] * G[j][b];
+        }
+        v[e] = (float)acc;
+    }
+    reinterpret_cast<float4*>(U + (long long)grp * u_gs)[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+extern "C" long long ss_wino43_packed_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || (cout & 31) || (cin & 15)) return 0;
+    return (long long)(cout / 32) * (cin / 16) * 36 * 2 * 64 * 4;
+}
+
+extern "C" int ss_wino43_pack(const float* wgt, float* packed, int cout, int cin, int groups, void* stream) {
+    if (!wgt || !packed || cout <= 0 || cin <= 0 || (cout & 31) || (cin & 15) || groups <= 0) return SS_ERR_ARG;
+    const int nchunk = cin / 16;
+    const long long per = (long long)(cout / 32) * nchunk * 36 * 2 * 64;
+    hipLaunchKernelGGL(wino43_pack_kernel, dim3(ss_cdiv(per, 256), groups), dim3(256), 0, (hipStream_t)stream, wgt, packed,
+                       cout, cin, nchunk, (long long)cout * 9 * cin, per * 4);
+    return ss_launch_status();
+}
+
+extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
+                                      int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
+                                      long long in_gs, long long u_gs, long long out_gs, void* stream) {
+    if (!in || !packed || !out || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || groups <= 0 || out_cs < cout)
+        return SS_ERR_ARG;
+    if ((cin & 15) || (cout & 63)) return SS_ERR_UNSUPPORTED;
+    const long long in_elems = (long long)n * h * w * cin;
+    const long long out_elems = (long long)n * h * w * out_cs;
+    const long long u_floats = ss_wino43_packed_floats(cout, cin);
+    if (in_elems * 4 >= (1ll << 32) || out_elems * 4 >= 0xFFFF0000ll || (long long)out_cs * 16 >= 65536 || u_floats * 4 >= (1ll << 31))
+        return SS_ERR_UNSUPPORTED;
+    W43P p;
+    p.in = in; p.U = packed; p.bias = bias; p.res = res; p.out = out;
+    p.N = n; p.H = h; p.W = w; p.C = cin; p.Co = cout;
+    p.nchunk = cin / 16;
+    p.relu = relu; p.out_cs = out_cs;
+    p.nbx = (unsigned)ss_cdiv(w, X_BW);
+    p.nby = (unsigned)ss_cdiv(h, X_BH);
+    p.ncb = (unsigned)(cout / 64);
+    p.divBx = ss_div32_make(p.nbx);
+    p.divBy = ss_div32_make(p.nby);
+    p.divNcb = ss_div32_make(p.ncb);
+    p.in_gs = in_gs; p.u_gs = u_gs; p.out_gs = out_gs;
+    p.in_bytes = (unsigned)(in_elems * 4);
+    p.out_bytes = (unsigned)(out_elems * 4);
+    p.u_bytes = (unsigned)(u_floats * 4);
+#ifdef SS_TUNING
+    p.dbg = ss_tuning_dbg;
+#endif
+    const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
+    if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
+    constexpr unsigned lds = (unsigned)X_SMEMF * 4u;
+    static bool attr_set = false;
+    if (!attr_set) {        // more than the 64 KB a kernel gets by default
+        if (hipFuncSetAttribute((const void*)conv_wino43_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_wino43_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return SS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 g((unsigned)wgs, 1, groups);
+    hipStream_t st = (hipStream_t)stream;
+    if (res) hipLaunchKernelGGL((conv_wino43_kernel<true>), g, dim3(512), lds, st, p);
+    else hipLaunchKernelGGL((conv_wino43_kernel<false>), g, dim3(512), lds, st, p);
+    return ss_launch_status();
+}

@@ -155,6 +155,26 @@ def _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups):
 WINOGRAD = os.environ.get('SS_WINOGRAD', '1') == '1'
 
 
+# Winograd F(4x4,3x3) (csrc/wino43.hip) where its 8 x 60-pixel tile blocks fit the map and the launch is deep enough:
+# 'auto' = the rule below, '0' = never, '1' = wherever the kernel's geometry constraints hold (tests / A-B runs)
+WINO43 = os.environ.get('SS_WINO43', 'auto')
+WINO43_MIN_CIN = int(os.environ.get('SS_WINO43_MIN_CIN', '64'))
+
+
+def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
+    if WINO43 == '0' or not WINOGRAD or WINO_MATH != 'f32':
+        return False
+    if (kt, kh, kw) != (1, 3, 3) or stride != 1 or tuple(pad) != (0, 1, 1) or cin % 16 or cout % 64:
+        return False
+    if WINO43 == '1':
+        return True
+    nby, nbx = -(-ho // 8), -(-wo // 60)
+    eff = ho * wo / float(nby * 8 * nbx * 60)
+    # one workgroup per CU: at least two full rounds of the chip, tile slots >= 85 % used, K long enough to carry the
+    # un-overlapped prologue / epilogue (cin >= 128: tools/bench_wino43.py)
+    return eff >= 0.85 and images * nby * nbx * (cout // 64) * groups >= 512 and cin >= WINO43_MIN_CIN
+
+
 def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
     return bool(WINOGRAD and kt == 1 and tuple(pad) == (0, 1, 1) and
                 H.lib().ss_conv_uses_winograd(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho),
@@ -174,6 +194,8 @@ def conv_executed_flop_ratio(kt, kh, kw, stride, cin, cout, out_shape):
     else:
         images = out_shape[0]
     ho, wo = out_shape[-3], out_shape[-2]
+    if _uses_wino43(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, images):
+        return 36.0 / 144.0
     return 16.0 / 36.0 if _uses_winograd(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, images) else 1.0
 
 
@@ -201,6 +223,44 @@ def wino_packed(wgt, groups, sliced=False):
         ent = _Built(build, wgt.device, 'the Winograd filter pack', tag)
         setattr(wgt, attr, ent)
     return ent.get(wgt.device)
+
+
+def wino43_packed(wgt, groups):
+    """F(4x4,3x3) transformed + packed filters of a 3x3 weight tensor (kept on the tensor like wino_packed)."""
+    ent = getattr(wgt, '_wino43_packed', None)
+    tag = (wgt._version, wgt.data_ptr())
+    if ent is None or ent.tag != tag:
+        cout, cin = wgt.shape[-5], wgt.shape[-1]
+        per = int(H.lib().ss_wino43_packed_floats(cout, cin))
+        assert per > 0, (cout, cin)
+
+        def build():
+            pk = torch.empty((groups, per), device=wgt.device, dtype=torch.float32)
+            H.call('ss_wino43_pack', H.dptr(wgt), H.dptr(pk), cout, cin, groups, H.stream())
+            return pk
+        ent = _Built(build, wgt.device, 'the F(4x4,3x3) filter pack', tag)
+        setattr(wgt, '_wino43_packed', ent)
+    return ent.get(wgt.device)
+
+
+def conv_winograd43(x, wgt, bias=None, res=None, relu=False, out=None):
+    """3x3 / stride 1 / pad 1 convolution on the fused Winograd F(4x4,3x3) kernel (csrc/wino43.hip), unconditionally.
+    x nhwc [n,h,w,c] (or [g,n,h,w,c] with wgt [g,cout,1,3,3,c]); cin % 16 == 0, cout % 64 == 0."""
+    grouped = wgt.dim() == 6
+    g = wgt.shape[0] if grouped else 1
+    cout, cin = wgt.shape[-5], wgt.shape[-1]
+    assert tuple(wgt.shape[-4:-1]) == (1, 3, 3) and x.shape[-1] == cin, (wgt.shape, x.shape)
+    shared = grouped and x.dim() == 4
+    n, h, w = x.shape[-4], x.shape[-3], x.shape[-2]
+    global last_conv_path
+    last_conv_path = 'wino43'
+    if out is None:
+        out = torch.empty(((g, n, h, w, cout) if grouped else (n, h, w, cout)), device=x.device, dtype=torch.float32)
+    pk = wino43_packed(wgt, g)
+    H.call('ss_conv3x3_wino43_nhwc', H.dptr(x), H.dptr(pk), H.dptr(bias, True), H.dptr(res, True), H.dptr(out),
+           n, h, w, cin, cout, int(relu), out.shape[-1], g, 0 if (shared or not grouped) else x[0].numel(),
+           pk.shape[1], out[0].numel() if grouped else 0, H.stream())
+    return out
 
 
 POOL_FUSED = os.environ.get('SS_POOL_FUSED', '1') == '1'      # the regressors' 2x2 max-pool inside the Winograd epilogue
@@ -314,6 +374,8 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
     if out is None:
         shape = (n, to, ho, wo, cout) if five else (n, ho, wo, cout)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    if not five and _uses_wino43(kt, kh, kw, stride, pad, c, cout, ho, wo, n):
+        return conv_winograd43(x, wgt, bias, res, relu, out)
     if not five and _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n):
         return conv_winograd(x, wgt, bias, res, relu, out)
     global last_conv_path
@@ -352,6 +414,8 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
     if out is None:
         out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
     assert tuple(out.shape) == (g, n, ho, wo, cout) and out.is_contiguous()
+    if _uses_wino43(kt, kh, kw, stride, pad, c, cout, ho, wo, n, g):
+        return conv_winograd43(x, wgt, bias, res, relu, out)
     if _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n * g):
         return conv_winograd(x, wgt, bias, res, relu, out)
     global last_conv_path
