@@ -1013,15 +1013,21 @@ def test_conv_winograd_grouped_and_dispatch(dev):
     assert lib.ss_conv_uses_winograd(1, 3, 3, 1, 4, 64, 23, 30, 32) == 0         # 2-channel flow input
     xl = torch.from_numpy(rs.normal(0, 1, (64, 45, 60, 128)).astype(np.float32)).to(dev)
     wl = torch.from_numpy((rs.normal(0, 1, (128, 1, 3, 3, 128)) / 34.0).astype(np.float32)).to(dev)
-    a = ops.conv(xl, wl, None, None, relu=True)                        # dispatches to Winograd (large launch)
-    assert torch.equal(a, ops.conv_winograd(xl, wl, None, None, relu=True))
+    a = ops.conv(xl, wl, None, None, relu=True)                        # large launch on a 60-wide map: F(4x4,3x3) (round 4)
+    assert ops.last_conv_path == 'wino43'
+    assert torch.equal(a, ops.conv_winograd43(xl, wl, None, None, relu=True))
+    f23 = ops.conv_winograd(xl, wl, None, None, relu=True)
+    close(a, f23, 1e-4 * max(1.0, float(f23.abs().max())), 'dispatch: F(4x4,3x3) vs F(2x2,3x3)')
+    if ops.WINO43 == 'auto':
+        a6 = ops.conv(xl[:6], wl, None, None, relu=True)               # a shallow launch of the same layer stays on F(2x2,3x3)
+        assert ops.last_conv_path == 'wino' and torch.equal(a6, f23[:6])
     old = ops.WINOGRAD
     ops.WINOGRAD = False
     try:
         d = ops.conv(xl, wl, None, None, relu=True)
     finally:
         ops.WINOGRAD = old
-    close(a, d, 4e-5 * max(1.0, float(d.abs().max())), 'dispatch: winograd vs implicit GEMM')
+    close(a, d, 1e-4 * max(1.0, float(d.abs().max())), 'dispatch: winograd vs implicit GEMM')
 
 
 def test_conv_winograd_schedules_bit_identical(dev, request):

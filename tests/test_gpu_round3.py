@@ -245,8 +245,10 @@ def test_joint_estimator_cached_first_view(dev, hip_nets):
     got = pipeline.joint_stage(hip_nets[0], hip_nets[1], None, lr[2], tmotion1=a12['tmotion2'], cache1=a12['spatial_cache2'])
     s1, s2 = pipeline.spatial_stage(hip_nets[0], lr[1], lr[2])
     t2 = pipeline.temporal_stage(hip_nets[1], lr[2])
-    close(got[0], s1, 1e-4, 'smotion1 of pair (2,3)')
-    close(got[1], s2, 1e-4, 'smotion2 of pair (2,3)')
+    # (the 40-image launches of the cached pass stay on F(2x2,3x3), the 80-image ones of the plain stages take F(4x4,3x3):
+    # spatial motions are DLT outputs, their gate against the reference goldens is 5e-3 px; observed 1.2e-4)
+    close(got[0], s1, 5e-4, 'smotion1 of pair (2,3)')
+    close(got[1], s2, 5e-4, 'smotion2 of pair (2,3)')
     close(got[3], t2, 1e-4, 'tmotion of view 3')
     assert got[2] is a12['tmotion2']
     with pytest.raises(ValueError):

@@ -10,7 +10,7 @@ import torch
 
 import cases
 from stabstitch2_amd import synth
-from test_gpu_parity import dev, hip_nets, close  # noqa: F401  (fixtures / helpers)
+from test_gpu_parity import dev, hip_nets, close, clip16  # noqa: F401  (fixtures / helpers)
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -460,3 +460,111 @@ def test_cost_volume_output_pitch_paths(dev):
             finally:
                 H.lib().ss_cost_volume_set_tile(0)
             assert torch.equal(wide[..., :d], ref[..., :d]) and float(wide[..., d:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Winograd F(4x4,3x3) (csrc/wino43.hip): the trunk's stride-1 3x3 layers on deep launches
+@pytest.mark.parametrize('shape', [(3, 45, 60, 128, 128, True, True), (2, 90, 120, 64, 64, True, False),
+                                   (2, 23, 30, 64, 128, False, True), (1, 8, 61, 32, 64, True, True),
+                                   (2, 7, 9, 16, 64, False, False), (1, 17, 131, 48, 192, True, True)])
+def test_conv_wino43_against_fp64(dev, shape):
+    """nn.Conv2d(3x3, stride 1, pad 1) + folded-BN bias + residual + ReLU (spatial_network.py:132-136) on the F(4x4,3x3) kernel
+    against the same layer in fp64: maps that end inside a tile block (rows and columns), more than one 60-pixel block per row,
+    cin below one MFMA block, three cout blocks.  Tolerance: F(4x4,3x3)'s transform constants (4, -5, 8) cost ~20x the
+    rounding error of F(2x2,3x3); measured 2e-5 .. 9e-5 of max|y| on these shapes, gate 2e-4 (F(2x2,3x3): 4e-5)."""
+    from stabstitch2_amd import ops
+    import torch.nn.functional as F
+    n, h, w, cin, cout, with_res, relu = shape
+    g = torch.Generator().manual_seed(1234 + h * w + cin)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev)
+    wgt = (torch.randn(cout, 1, 3, 3, cin, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    res = torch.randn(n, h, w, cout, generator=g).to(dev) if with_res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wgt[:, 0].permute(0, 3, 1, 2).double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    y = ops.conv_winograd43(x, wgt, bias, res, relu)
+    scale = max(1.0, float(ref.abs().max()))
+    close(y, ref.float(), 2e-4 * scale, 'F(4x4,3x3) vs fp64 conv %s' % (shape,))
+    # a channel-padded destination keeps its padding; no bias
+    wide = torch.full((n, h, w, cout + 8), 7.0, device=dev)
+    ops.conv_winograd43(x, wgt, None, None, False, out=wide)
+    assert float((wide[..., cout:] - 7.0).abs().max()) == 0.0
+    ref0 = F.conv2d(x.permute(0, 3, 1, 2).double(), wgt[:, 0].permute(0, 3, 1, 2).double(), None, padding=1).permute(0, 2, 3, 1)
+    close(wide[..., :cout], ref0.float(), 2e-4 * max(1.0, float(ref0.abs().max())), 'F(4x4,3x3), no bias, wide destination')
+
+
+def test_conv_wino43_groups_and_limits(dev):
+    """Grouped launches (group strides, one input shared by both groups) equal the single launches bit for bit; geometry the kernel
+    does not take is refused, not mis-computed."""
+    from stabstitch2_amd import ops, _hip
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 3, 16, 60, 32, generator=g).to(dev)
+    w = (torch.randn(2, 64, 1, 3, 3, 32, generator=g) / 17.0).to(dev)
+    b = torch.randn(2, 64, generator=g).to(dev)
+    r = torch.randn(2, 3, 16, 60, 64, generator=g).to(dev)
+    y = ops.conv_winograd43(x, w, b, r, True)
+    for k in range(2):
+        one = ops.conv_winograd43(x[k].contiguous(), w[k].contiguous(), b[k].contiguous(), r[k].contiguous(), True)
+        assert torch.equal(y[k], one)
+    shared = ops.conv_winograd43(x[0].contiguous(), w, b, r, True)
+    assert torch.equal(shared[0], y[0])
+    lib = _hip.lib()
+    assert lib.ss_wino43_packed_floats(64, 24) == 0 and lib.ss_wino43_packed_floats(48, 32) == 0
+    assert lib.ss_wino43_packed_floats(64, 32) == 2 * 2 * 36 * 2 * 64 * 4
+    xs = torch.randn(1, 8, 8, 32, generator=g).to(dev)
+    pk = torch.zeros(1 << 16, device=dev)
+    out = torch.zeros(1, 8, 8, 64, device=dev)
+    with pytest.raises(_hip.HipError, match='unsupported'):         # cin % 16
+        _hip.call('ss_conv3x3_wino43_nhwc', _hip.dptr(xs), _hip.dptr(pk), None, None, _hip.dptr(out), 1, 8, 8, 24, 64, 0, 64, 1, 0, 0, 0, _hip.stream())
+    with pytest.raises(_hip.HipError, match='bad argument'):        # out_cs < cout
+        _hip.call('ss_conv3x3_wino43_nhwc', _hip.dptr(xs), _hip.dptr(pk), None, None, _hip.dptr(out), 1, 8, 8, 32, 64, 0, 32, 1, 0, 0, 0, _hip.stream())
+
+
+def test_wino43_dispatch_rule_and_pipeline_agreement(dev, hip_nets):
+    """ops.conv takes F(4x4,3x3) for the deep launches of the 60 / 120-wide trunk maps only, and a whole clip estimated with it
+    agrees with the F(2x2,3x3)-only engine far inside the reference gates (offsets / motions 1e-4 px)."""
+    from stabstitch2_amd import ops, pipeline
+    assert ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 128, 128, 45, 60, 64)
+    assert ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 64, 64, 90, 120, 64)
+    assert not ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 256, 256, 23, 30, 64)      # 30-wide map: half of every tile block idles
+    assert not ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 128, 128, 45, 60, 2)       # streaming-sized launch
+    assert not ops._uses_wino43(1, 3, 3, 2, (0, 1, 1), 64, 128, 45, 60, 64)       # strided
+    assert not ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 4, 64, 90, 120, 64)        # cin % 16
+    _, lr = synth.make_clip_device(40, 360, 480, seed=5, device=dev)
+    old = ops.WINO43
+    try:
+        ops.WINO43 = 'auto'
+        with_43 = pipeline.joint_stage(hip_nets[0], hip_nets[1], lr[0], lr[1])
+        assert ops.last_conv_path is not None
+        ops.WINO43 = '0'
+        without = pipeline.joint_stage(hip_nets[0], hip_nets[1], lr[0], lr[1])
+    finally:
+        ops.WINO43 = old
+    # spatial motions come out of the DLT / decomposition, which amplifies offset differences (their gate against the reference
+    # goldens is 5e-3 px, G8); temporal motions are network outputs (gate 1e-4)
+    for x43, x23, name, tol in zip(with_43, without, ('spatial motions 1', 'spatial motions 2', 'temporal motions 1', 'temporal motions 2'),
+                                   (5e-4, 5e-4, 1e-4, 1e-4)):
+        d = float((x43 - x23).abs().max())
+        assert 0.0 < d < tol, (name, d)       # (0 would mean the F(4x4,3x3) kernel never ran)
+
+
+def test_reference_goldens_with_wino43_everywhere(dev, golden, hip_nets, clip16, monkeypatch):
+    """The reference goldens (G8: offsets / motions of both nets, spatial_network.py:276-331, temporal_network.py:24-60; G9 / G10:
+    the pipeline) with EVERY eligible stride-1 3x3 layer forced onto the F(4x4,3x3) kernel -- the golden clips are 16 frames,
+    too shallow for the dispatch rule to pick it by itself.  Same gates as with F(2x2,3x3)."""
+    import test_gpu_parity as T
+    from stabstitch2_amd import ops
+    calls = [0]
+    real = ops.conv_winograd43
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops, 'conv_winograd43', counted)
+    monkeypatch.setattr(ops, 'WINO43', '1')
+    T.test_nets_vs_reference(dev, golden, hip_nets, clip16)
+    assert calls[0] >= 10, calls
+    T.test_pipeline_vs_reference(dev, golden, hip_nets, clip16)
