@@ -31,6 +31,7 @@ typedef float x_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned x_u32x4 __attribute__((ext_vector_type(4)));
 typedef float x_f32x16 __attribute__((ext_vector_type(16)));
 typedef float x_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned x_u32x2 __attribute__((ext_vector_type(2)));
 
 struct W43P {
     const float* in;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     const int blk = wave & 1;                              // 32-channel half of the workgroup's 64 output channels
     const int pa = wave >> 2, pbb = (wave >> 1) & 1;        // position block: rows 3 pa .., columns 3 pbb ..
 #ifdef SS_TUNING
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     X_STAMP(0);
 
@@ -192,14 +193,56 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     };
 
     // ---- prologue: chunk 0 row-transformed in LDS, chunk 1's rows and the first two filter groups in flight
+    X_STAMP(7);
     raw_issue(0);
     u_issue(0, 0, 0);
     u_issue(1, 0, 1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) s1_piece(smem, k);
+    X_STAMP(8);
     lds_barrier();
     X_STAMP(1);
     raw_issue(p.nchunk > 1 ? 1 : 0);
+
+    // ---- epilogue addressing and the residual: set up inside the LAST chunk (live ranges do not cross the K loop), the residual
+    // of the first phase requested there too -- behind the chunk's last filter loads, so no wait of the stream covers it
+    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    const __amdgpu_buffer_rsrc_t rout = x_rsrc(out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = x_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
+    int e_n, tx, kh_e, lane_e;
+    unsigned pixb, rowb, base;
+    unsigned roff[4], cinv[4];
+    x_f32x2 rv[4][4];
+    auto epi_setup = [&]() {
+        // (thread indices re-derived behind an opaque copy: hipcc otherwise computes these addresses in front of the K loop and
+        // spills them across it)
+        int tid_e = threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        e_n = tid_e & 31;
+        tx = tid_e >> 5;
+        lane_e = tid_e & 63;
+        kh_e = lane_e >> 5;
+        // pixel offsets: row part per a -- 0xFFFF0000 (past every buffer the launcher admits) for rows outside the image -- plus
+        // y * pixel pitch, or-ed with the column's out-of-range mask (columns past the image, the idle tile slot)
+        const int oxb = ox0 + 4 * tx;
+        pixb = (unsigned)p.out_cs * 4u;
+        rowb = pixb * (unsigned)p.W;
+        base = ((((unsigned)img * p.H + oy0) * p.W + oxb) * (unsigned)p.out_cs + cbk * 64 + 2 * e_n) * 4u;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) cinv[y] = (tx < X_TXU && oxb + y < p.W) ? 0u : 0xFFFFFFFFu;
+    };
+    auto row_offsets = [&](int ty) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) roff[a] = oy0 + 4 * ty + a < p.H ? base + (unsigned)(4 * ty + a) * rowb : 0xFFFF0000u;
+    };
+    // residual of output column y of the current phase's rows (roff)
+    auto res_col = [&](int y) {
+        if constexpr (RES) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                rv[y][a] = __builtin_bit_cast(x_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, (roff[a] + (unsigned)y * pixb) | cinv[y], 0, 0));
+        }
+    };
 
     auto kloop = [&](auto bc) {
         constexpr int B = decltype(bc)::value;          // column block of this wave (compile time: the column transform differs)
@@ -254,6 +297,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
                     acc[g][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m & 1][s], u[G % 3][s][e], acc[g][s], 0, 0, 0);
+                if constexpr (!MORE) {
+                    if (m == 13) { epi_setup(); row_offsets(0); }
+                    if (m == 14) res_col(0);
+                    if (m == 16) res_col(1);
+                    if (m == 18) res_col(2);
+                    if (m == 20) res_col(3);
+                }
                 if constexpr (MORE) {
                     // stage 1 of chunk c + 1 between the MFMAs of steps 8..14 (its rows were requested a chunk ago)
                     if (m == 8) s1_piece(bn, 0);
@@ -275,62 +325,51 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     X_STAMP(2);
 
     // ---------------------------------------------------------------- epilogue: Y = A^T M A, bias, residual, ReLU
-    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
-    const __amdgpu_buffer_rsrc_t rout = x_rsrc(out, p.out_bytes);
-    const __amdgpu_buffer_rsrc_t rres = x_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
-    const int e_n = tid & 31;
-#pragma unroll 1
-    for (int ph = 0; ph < 2; ++ph) {
-        __syncthreads();                                    // V1 (phase 0) / the previous phase's stage is free
-        if (blk == ph) {
-            float* d = smem + ((3 * pa) * 6 + 3 * pbb) * 1024 + (lane & 31);
+    // Two phases, one per tile row ty: ALL eight waves stage their accumulators of that row's 16 tiles ([position][tile][64 couts],
+    // 144 KB), then every thread owns the tile (ty, tx) for the output channels 2 e_n and 2 e_n + 1 -- the two halves of packed
+    // registers (nothing multiplies here: v_pk_add_f32 / v_pk_fma_f32 do both channels' work per issue slot) and of 8-byte LDS
+    // reads, residual loads and stores (a wave moves 256-byte runs of a pixel's channels).
+    const float* s0 = smem + tx * 64 + 2 * e_n;
+    float bias0 = 0.f, bias1 = 0.f;
+    if (p.bias) {
+        bias0 = p.bias[(long long)grp * p.Co + cbk * 64 + 2 * e_n];
+        bias1 = p.bias[(long long)grp * p.Co + cbk * 64 + 2 * e_n + 1];
+    }
+    const x_f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f}, bias2 = {bias0, bias1};
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+        lds_barrier();                                      // V1 (phase 0) / the previous phase's stage is free; (not
+                                                            // __syncthreads(): its vmcnt(0) would wait for the residual here)
+        if (ty == 0) X_STAMP(5);
+        {
+            float* d = smem + ((3 * pa) * 6 + 3 * pbb) * 1024 + blk * 32 + (lane_e & 31);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                        d[(g * 6 + s) * 1024 + tile * 32] = acc[g][s][r];
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int t16 = (r8 & 3) + 8 * (r8 >> 2) + 4 * kh_e;   // accumulator 8 ty + r8 = tile 16 ty + t16
+                        d[(g * 6 + s) * 1024 + t16 * 64] = acc[g][s][8 * ty + r8];
                     }
         }
-        __syncthreads();
-        X_STAMP(3 + ph);
-        const float bias = p.bias ? p.bias[(long long)grp * p.Co + cbk * 64 + ph * 32 + e_n] : 0.f;
-        // this thread's two items: tiles (0, tx) and (1, tx) for output channel e_n, as the halves of packed registers (nothing
-        // multiplies here: v_pk_add_f32 / v_pk_fma_f32 do two items' work per issue slot); their stage entries are 512 floats apart
-        const int tx = tid >> 5;
-        const float* s0 = smem + tx * 32 + e_n;
-        // pixel offsets: row part per (item, a) -- 0xFFFF0000 (past every buffer the launcher admits) for rows outside the image --
-        // plus y * pixel pitch, or-ed with the column's out-of-range mask (columns past the image, the idle tile slot)
-        const int oxb = ox0 + 4 * tx;
-        const unsigned pixb = (unsigned)p.out_cs * 4u, rowb = pixb * (unsigned)p.W;
-        const unsigned base = ((((unsigned)img * p.H + oy0) * p.W + oxb) * (unsigned)p.out_cs + cbk * 64 + ph * 32 + e_n) * 4u;
-        unsigned roff[8], cinv[4];
+        if (ty == 0) X_STAMP(6);
+        lds_barrier();
+        X_STAMP(3 + ty);
+        // this phase's store offsets; roff then moves on to the next phase: its residual columns are requested as soon as this
+        // phase has consumed theirs
+        unsigned roff_s[4];
 #pragma unroll
-        for (int a2 = 0; a2 < 8; ++a2) roff[a2] = oy0 + a2 < p.H ? base + (unsigned)a2 * rowb : 0xFFFF0000u;
-#pragma unroll
-        for (int y = 0; y < 4; ++y) cinv[y] = (tx < X_TXU && oxb + y < p.W) ? 0u : 0xFFFFFFFFu;
-        x_f32x2 rv[2][4];
-        auto res_issue = [&](int y, x_f32x2 (&dst)[4]) {
-            if constexpr (RES) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    dst[a][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (roff[a] + (unsigned)y * pixb) | cinv[y], 0, 0));
-                    dst[a][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (roff[4 + a] + (unsigned)y * pixb) | cinv[y], 0, 0));
-                }
-            }
-        };
-        res_issue(0, rv[0]);
+        for (int a = 0; a < 4; ++a) roff_s[a] = roff[a];
+        if (ty == 0) row_offsets(1);
         // rows of M -> T[i][y] = sum_j M[i][j] A[j][y]
-        const x_f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f}, bias2 = {bias, bias};
         x_f32x2 t[6][4];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             x_f32x2 m[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m[j] = (x_f32x2){s0[(i * 6 + j) * 1024], s0[(i * 6 + j) * 1024 + 512]};
+            for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const x_f32x2*>(s0 + (i * 6 + j) * 1024);
             const x_f32x2 p12 = m[1] + m[2], q12 = m[1] - m[2], p34 = m[3] + m[4], q34 = m[3] - m[4];
             t[i][0] = (m[0] + p12) + p34;
             t[i][1] = __builtin_elementwise_fma(c2, q34, q12);
@@ -339,7 +378,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
         }
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            if (y + 1 < 4) res_issue(y + 1, rv[(y + 1) & 1]);
             const x_f32x2 p12 = t[1][y] + t[2][y], q12 = t[1][y] - t[2][y], p34 = t[3][y] + t[4][y], q34 = t[3][y] - t[4][y];
             x_f32x2 o[4];
             o[0] = (t[0][y] + p12) + p34;
@@ -349,18 +387,24 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 x_f32x2 v = o[a] + bias2;
-                if (RES) v = v + rv[y & 1][a];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[0], relu_lo)), rout, (roff[a] + (unsigned)y * pixb) | cinv[y], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[1], relu_lo)), rout, (roff[4 + a] + (unsigned)y * pixb) | cinv[y], 0, 0);
+                if (RES) v = v + rv[y][a];
+                const unsigned off = (roff_s[a] + (unsigned)y * pixb) | cinv[y];
+                v[0] = fmaxf(v[0], relu_lo);
+                v[1] = fmaxf(v[1], relu_lo);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(x_u32x2, v), rout, off, 0, 0);
             }
+            if (ty == 0) res_col(y);
         }
     }
 #ifdef SS_TUNING
     if (p.dbg && tid == 0) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 10;
         for (int i = 0; i < 5; ++i) d[i] = ts[i];
         d[5] = __builtin_amdgcn_s_memtime();
-        d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        d[6] = ts[5];
+        d[7] = ts[6];
+        d[8] = ts[7];
+        d[9] = ts[8];
     }
 #endif
 }

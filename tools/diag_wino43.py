@@ -21,7 +21,7 @@ for name in sys.argv[1].split(','):
         for _ in range(5): ops.conv_winograd43(x, wt, b, r, relu=True, out=out)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        dbg = torch.zeros((1 << 16, 8), dtype=torch.int64, device=dev)
+        dbg = torch.zeros((1 << 16, 10), dtype=torch.int64, device=dev)
         lib.ss_debug_ptr(ctypes.c_void_p(dbg.data_ptr()))
         ops.conv_winograd43(x, wt, b, r, relu=True, out=out)
         torch.cuda.synchronize()
@@ -29,6 +29,6 @@ for name in sys.argv[1].split(','):
         d = dbg.cpu().numpy().astype(np.int64)
         d = d[d[:, 0] > 0]
         med = lambda a: int(np.median(a))
-        print('%s res=%d: %.1f us per launch | %d blocks; median ticks: prologue %d | K loop %d (%d chunks: %d per chunk) | wait + dump 0 %d | combine 0 + dump 1 %d | combine 1 %d | total %d | launch span %d'
-              % (name, use_res, ms * 1e3, len(d), med(d[:, 1] - d[:, 0]), med(d[:, 2] - d[:, 1]), cin // 16, med(d[:, 2] - d[:, 1]) // (cin // 16),
-                 med(d[:, 3] - d[:, 2]), med(d[:, 4] - d[:, 3]), med(d[:, 5] - d[:, 4]), med(d[:, 5] - d[:, 0]), d[:, 5].max() - d[:, 0].min()), flush=True)
+        print('%s res=%d: %.1f us per launch | %d blocks; median ticks: prologue %d (setup %d, loads + row transform %d, barrier %d) | first / later rounds prologue %d / %d | K loop %d (%d chunks: %d per chunk) | wait %d, dump 0 %d, barrier %d | combine 0 + dump 1 %d | combine 1 %d | total %d | launch span %d'
+              % (name, use_res, ms * 1e3, len(d), med(d[:, 1] - d[:, 0]), med(d[:, 8] - d[:, 0]), med(d[:, 9] - d[:, 8]), med(d[:, 1] - d[:, 9]), med((d[:, 1] - d[:, 0])[d[:, 0] < np.sort(d[:, 0])[255]]), med((d[:, 1] - d[:, 0])[d[:, 0] >= np.sort(d[:, 0])[256]]), med(d[:, 2] - d[:, 1]), cin // 16, med(d[:, 2] - d[:, 1]) // (cin // 16),
+                 med(d[:, 6] - d[:, 2]), med(d[:, 7] - d[:, 6]), med(d[:, 3] - d[:, 7]), med(d[:, 4] - d[:, 3]), med(d[:, 5] - d[:, 4]), med(d[:, 5] - d[:, 0]), d[:, 5].max() - d[:, 0].min()), flush=True)
