@@ -220,10 +220,11 @@ class ConvProbe:
 
     def by_kernel(self):
         """-> {kernel family: (launches, ms, executed flop, direct-equivalent flop)}: 'conv_wino_kernel' = the launches the
-        engine's dispatch rule sends to the Winograd kernel, 'conv_igemm_kernel' = the rest."""
+        engine's dispatch rule sends to the Winograd F(2x2,3x3) kernel, 'conv_wino43_kernel' = those it sends to F(4x4,3x3),
+        'conv_igemm_kernel' = the rest."""
         out = {}
         for e0, e1, m, cout, taps, cin, nbytes, xr, *name in self.records:
-            k = name[0] if name else ('conv_wino_kernel' if xr < 1.0 else 'conv_igemm_kernel')
+            k = name[0] if name else ('conv_wino43_kernel' if xr < 0.3 else ('conv_wino_kernel' if xr < 1.0 else 'conv_igemm_kernel'))
             a = out.setdefault(k, [0, 0.0, 0.0, 0.0])
             f = 2.0 * m * cout * taps * self._real_cin(cin, taps)
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f * xr; a[3] += f
@@ -800,11 +801,13 @@ def main():
                    'frames_per_step': args.frames, 'canvas': [int(hc), int(wc)], 'parallelism': 'streams%d' % world,
                    'published_reference': '28.3 fps on 1x RTX 4090 at 360x480 (README.md:30); different resolution '
                                           'and hardware, not comparable'},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv engine: conv_wino_kernel / conv_igemm_kernel / stem_pool_kernel (fp32 MFMA, %d launches/clip)'
+        'roofline': {'bound': 'mfma', 'kernel': 'conv engine: conv_wino43_kernel / conv_wino_kernel / conv_igemm_kernel / stem_pool_kernel (fp32 MFMA, %d launches/clip)'
                      % conv_n, 'achieved': round(executed, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
-                     'achieved_is': 'EXECUTED MFMA flop (Winograd F(2x2,3x3) layers count 16/36 of their direct-conv '
-                                    'flop) / summed launch durations (HIP events)',
+                     'achieved_is': 'EXECUTED MFMA flop (Winograd F(2x2,3x3) layers count 16/36 of their direct-conv flop, '
+                                    'F(4x4,3x3) layers 36/144: round 4 moved the deep layer1 / layer2 launches to F(4x4,3x3) -- '
+                                    '21 % fewer executed flop per clip in 6 % less time, so this fraction FELL from 0.64 while '
+                                    'direct_conv_equivalent_tflops and frames/s rose) / summed launch durations (HIP events)',
                      'direct_conv_equivalent_tflops': round(equivalent, 3),
                      'traffic': traffic, 'traffic_source': 'static: %s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this '
                                                            'command), not measured in this run' % PMC_PROFILE,

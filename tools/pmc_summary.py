@@ -7,7 +7,7 @@ import glob
 import json
 import sys
 
-KEYS = (('conv_wino', 'conv_wino_kernel'), ('conv_igemm', 'conv_igemm_kernel'), ('render_average', 'render_average_kernel'), ('cost_volume', 'cost_volume_kernel'),
+KEYS = (('conv_wino43', 'conv_wino43_kernel'), ('conv_wino_kernel', 'conv_wino_kernel'), ('conv_igemm', 'conv_igemm_kernel'), ('render_average', 'render_average_kernel'), ('cost_volume', 'cost_volume_kernel'),
         ('maxpool', 'maxpool_kernel'), ('linear_kernel', 'linear_kernel'), ('linear_grouped', 'linear_grouped_kernel'), ('homo_warp', 'homo_warp_kernel'), ('stem_pool_kernel', 'stem_pool_kernel'))
 
 
@@ -42,7 +42,7 @@ out = {'steps_profiled': steps, 'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SI
                 'loads, homography sampler: float4 taps) fetch bytes = 2 x FETCH_SIZE; dword gathers (render, cost volume) and WRITE_SIZE are used as reported.',
        'kernels': {}}
 for key in f:
-    corr = 2.0 if key in ('conv_wino_kernel', 'conv_igemm_kernel', 'maxpool_kernel', 'linear_kernel', 'linear_grouped_kernel', 'homo_warp_kernel', 'stem_pool_kernel') else 1.0
+    corr = 2.0 if key in ('conv_wino43_kernel', 'conv_wino_kernel', 'conv_igemm_kernel', 'maxpool_kernel', 'linear_kernel', 'linear_grouped_kernel', 'homo_warp_kernel', 'stem_pool_kernel') else 1.0
     fa, wa = sum(f[key]) / len(f[key]), sum(w[key]) / len(w[key])
     out['kernels'][key] = {'launches': len(f[key]), 'FETCH_SIZE_avg': round(fa, 1), 'WRITE_SIZE_avg': round(wa, 1),
                            'fetch_correction': corr, 'hbm_bytes_per_launch': round((corr * fa + wa) * 1000.0)}
@@ -51,7 +51,7 @@ for key in f:
         out['kernels'][key]['avg_us_under_pmc'] = round(us, 2)
         out['kernels'][key]['hbm_TB_per_s'] = round((corr * fa + wa) * 1000.0 / us / 1e6, 3)
 # the conv engine as one family (what bench.py's roofline block quotes): all Winograd + implicit-GEMM launches together
-fam = [k for k in ('conv_wino_kernel', 'conv_igemm_kernel', 'stem_pool_kernel') if k in f]
+fam = [k for k in ('conv_wino43_kernel', 'conv_wino_kernel', 'conv_igemm_kernel', 'stem_pool_kernel') if k in f]
 if fam:
     nl = sum(len(f[k]) for k in fam)
     tot = sum(2.0 * sum(f[k]) + sum(w[k]) for k in fam) * 1000.0

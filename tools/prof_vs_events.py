@@ -21,7 +21,7 @@ prof, unprof = last_json(sys.argv[2]), last_json(sys.argv[3])
 print('#')
 print('# trace vs HIP events (bench.py per_kernel.avg_launch_us; same command):')
 print('#   %-22s %12s %14s %16s %10s' % ('kernel family', 'trace avg us', 'events profiled', 'events unprofiled', 'trace/ev'))
-for fam in ('conv_wino_kernel', 'conv_igemm_kernel', 'stem_pool_kernel'):
+for fam in ('conv_wino43_kernel', 'conv_wino_kernel', 'conv_igemm_kernel', 'stem_pool_kernel'):
     rows = [v for k, v in stats.items() if fam in k]
     calls = sum(r[0] for r in rows)
     tot = sum(r[1] for r in rows)

@@ -27,9 +27,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f_$TAG
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$TAG -- $PCMD > $OUT/${TAG}_pmc_w.log 2>&1
 python $R/tools/pmc_summary.py /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG $PSTEPS "python bench.py $ARGS" > $OUT/${TAG}_pmc_hbm.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_m_$TAG -- $PCMD > $OUT/${TAG}_pmc_m.log 2>&1
-python $R/tools/pmc_kernels.py /tmp/pmc_m_$TAG conv_wino conv_igemm stem_pool_kernel render_average cost_volume maxpool homo_warp > $OUT/${TAG}_pmc_mfma.json
+python $R/tools/pmc_kernels.py /tmp/pmc_m_$TAG conv_wino43 conv_wino_kernel conv_igemm stem_pool_kernel render_average cost_volume maxpool homo_warp > $OUT/${TAG}_pmc_mfma.json
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_l_$TAG -- $PCMD > $OUT/${TAG}_pmc_l.log 2>&1
-python $R/tools/pmc_kernels.py /tmp/pmc_l_$TAG conv_wino conv_igemm stem_pool_kernel render_average cost_volume ccl_softmax > $OUT/${TAG}_pmc_lds.json
+python $R/tools/pmc_kernels.py /tmp/pmc_l_$TAG conv_wino43 conv_wino_kernel conv_igemm stem_pool_kernel render_average cost_volume ccl_softmax > $OUT/${TAG}_pmc_lds.json
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d /tmp/pmc_v_$TAG -- $PCMD > $OUT/${TAG}_pmc_v.log 2>&1
 python $R/tools/pmc_render_summary.py /tmp/pmc_v_$TAG > $OUT/${TAG}_pmc_render.json
 ls -la $OUT/${TAG}_*
