@@ -509,6 +509,7 @@ unsigned long long* ss_tuning_dbg = nullptr;
 extern int g_wino_nb1_max_cin, g_wino_ablate, g_wino_variant;
 extern int g_wino_knob[4];
 extern int g_wino_lds_pad;
+extern int g_w43_ablate;
 #define g_dbg ss_tuning_dbg
 extern "C" SS_API void ss_debug_ptr(void* ptr) { g_dbg = (unsigned long long*)ptr; }
 extern "C" SS_API void ss_debug_set(int key, int value) {
@@ -521,6 +522,7 @@ extern "C" SS_API void ss_debug_set(int key, int value) {
     if (key == 7) g_wino_variant = value;          // Winograd kernel: 0 auto, 1 one tile block per workgroup, 2 pair kernel
     if (key == 5) g_wino_nb1_max_cin = value;      // Winograd: 32-channel blocks (3 workgroups / CU) up to this cin
     if (key == 20) g_wino_lds_pad = value;
+    if (key == 21) g_w43_ablate = value;           // F(4x4,3x3) K-loop ablations (timing only)
     if (key >= 16 && key < 20) g_wino_knob[key - 16] = value;      // Winograd round-3 experiments (see WinoP::knob)
 }
 #else

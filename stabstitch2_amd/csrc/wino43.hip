@@ -79,7 +79,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const float* base, unsi
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <bool RES>
+// ABL (tuning build, timing only -- wrong results): compile-time ablations of the K loop: 1 no filter loads, 2 no stage 1 (raw
+// loads, row transform, LDS writes), 4 no stage-2 arithmetic, 8 no LDS reads, 16 no barrier
+template <bool RES, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -150,7 +152,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
             for (int r = 0; r < 16; ++r) acc[g][s][r] = 0.f;
 
     x_f32x4 rr[6];
+    if constexpr (ABL & 2) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) rr[r] = (x_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     auto raw_issue = [&](int c) {
+        if constexpr (ABL & 2) return;
         const unsigned coff = (unsigned)c * 64u;
         int rm = rmask;
         asm volatile("" : "+v"(rm));         // (left alone, hipcc hoists the six masks out of the K loop and spills them)
@@ -160,6 +167,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     };
     // row transform B^T d of channel k of the quad, written to V1 rows 0..5
     auto s1_piece = [&](float* buf, int k) {
+        if constexpr (ABL & 2) return;
         const float d0 = rr[0][k], d1 = rr[1][k], d2 = rr[2][k], d3 = rr[3][k], d4 = rr[4][k], d5 = rr[5][k];
         float t1 = __builtin_fmaf(-4.f, d2, d4);
         asm("" : "+v"(t1));
@@ -176,6 +184,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
         w[5 * X_RWP] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
     };
     auto lds_barrier = [&]() {       // __syncthreads() minus its global-memory fence (it would drain every prefetch in flight)
+        if constexpr (ABL & 16) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -183,7 +192,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
 
     // filters of one GROUP = (chunk, half h, position row g): three positions x 16 bytes (MFMA steps 4 h .. 4 h + 3)
     x_f32x4 u[3][3];
+    if constexpr (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) u[i][j] = (x_f32x4){(float)lane, 1.f, 2.f, (float)(i + j)};
+    }
     auto u_issue = [&](int set, int c, int G) {
+        if constexpr (ABL & 1) return;
         const int h = G / 3, g = G % 3;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -248,14 +264,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
         constexpr int B = decltype(bc)::value;          // column block of this wave (compile time: the column transform differs)
         x_f32x4 rd[2][2];
         float av[2][3];
+        if constexpr (ABL & (4 | 8)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                rd[i][0] = rd[i][1] = (x_f32x4){(float)lane, 1.f, 2.f, 3.f};
+                av[i][0] = av[i][1] = av[i][2] = (float)(lane + i);
+            }
+        }
         // step m of a chunk = (half h = m / 12, position row g = (m / 4) % 3, channel e = m % 4)
         auto rd_issue = [&](const float* buf, int m, int slot) {
+            if constexpr (ABL & 8) return;
             const int h = m / 12, g = (m / 4) % 3, e = m % 4;
             const float* src = buf + t_src + (4 * h + e) * X_PL + g * X_RWP;
             rd[slot][0] = *reinterpret_cast<const x_f32x4*>(src);
             rd[slot][1] = *reinterpret_cast<const x_f32x4*>(src + 4);
         };
         auto xf = [&](int slot) {
+            if constexpr (ABL & 4) return;
             const float x0 = rd[slot][0][0], x1 = rd[slot][0][1], x2 = rd[slot][0][2], x3 = rd[slot][0][3];
             const float x4 = rd[slot][1][0], x5 = rd[slot][1][1];
             if constexpr (B == 0) {
@@ -457,6 +482,10 @@ extern "C" int ss_wino43_pack(const float* wgt, float* packed, int cout, int cin
     return ss_launch_status();
 }
 
+#ifdef SS_TUNING
+int g_w43_ablate = 0;                    // ss_debug_set key 21
+#endif
+
 extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
                                       int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
                                       long long in_gs, long long u_gs, long long out_gs, void* stream) {
@@ -498,6 +527,17 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     }
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
+#ifdef SS_TUNING
+    if (g_w43_ablate && !res) {         // tools/diag_wino43.py <layers> <ablation masks>
+        switch (g_w43_ablate) {
+#define X_ABL_CASE(m) case m: hipFuncSetAttribute((const void*)conv_wino43_kernel<false, m>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((conv_wino43_kernel<false, m>), g, dim3(512), lds, st, p); return ss_launch_status();
+            X_ABL_CASE(1) X_ABL_CASE(2) X_ABL_CASE(4) X_ABL_CASE(8) X_ABL_CASE(12) X_ABL_CASE(14) X_ABL_CASE(15) X_ABL_CASE(16) X_ABL_CASE(31)
+#undef X_ABL_CASE
+            default: break;
+        }
+    }
+#endif
     if (res) hipLaunchKernelGGL((conv_wino43_kernel<true>), g, dim3(512), lds, st, p);
     else hipLaunchKernelGGL((conv_wino43_kernel<false>), g, dim3(512), lds, st, p);
     return ss_launch_status();

@@ -1,4 +1,4 @@
-"""Per-workgroup phase timeline of one F(4x4,3x3) launch (s_memtime stamps, tuning build).   python tools/diag_wino43.py layer2,layer1"""
+"""Per-workgroup phase timeline of one F(4x4,3x3) launch (s_memtime stamps, tuning build).   python tools/diag_wino43.py layer2,layer1 [ablation masks, e.g. 0,1,2,4,8,15,16]"""
 import sys, os, torch, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,12 +7,14 @@ import _tuning
 lib = _tuning.lib()
 dev = torch.device('cuda:0')
 SHAPES = {'layer1': (64, 90, 120, 64, 64), 'layer2': (64, 45, 60, 128, 128), 'layer3': (64, 23, 30, 256, 256)}
-for name in sys.argv[1].split(','):
+ABL = [int(a) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
+for name, abl in ((n_, a_) for n_ in sys.argv[1].split(',') for a_ in ABL):
+    lib.ss_debug_set(21, abl)
     n, h, w, cin, cout = SHAPES[name]
     x = torch.randn(n, h, w, cin, device=dev); wt = torch.randn(cout, 1, 3, 3, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     out = ops.conv_winograd43(x, wt, b, None, relu=True)
     res = torch.randn_like(out)
-    for use_res in (False, True):
+    for use_res in ((False,) if abl else (False, True)):
         r = res if use_res else None
         for _ in range(3): ops.conv_winograd43(x, wt, b, r, relu=True, out=out)
         torch.cuda.synchronize()
@@ -29,6 +31,6 @@ for name in sys.argv[1].split(','):
         d = dbg.cpu().numpy().astype(np.int64)
         d = d[d[:, 0] > 0]
         med = lambda a: int(np.median(a))
-        print('%s res=%d: %.1f us per launch | %d blocks; median ticks: prologue %d (setup %d, loads + row transform %d, barrier %d) | first / later rounds prologue %d / %d | K loop %d (%d chunks: %d per chunk) | wait %d, dump 0 %d, barrier %d | combine 0 + dump 1 %d | combine 1 %d | total %d | launch span %d'
-              % (name, use_res, ms * 1e3, len(d), med(d[:, 1] - d[:, 0]), med(d[:, 8] - d[:, 0]), med(d[:, 9] - d[:, 8]), med(d[:, 1] - d[:, 9]), med((d[:, 1] - d[:, 0])[d[:, 0] < np.sort(d[:, 0])[255]]), med((d[:, 1] - d[:, 0])[d[:, 0] >= np.sort(d[:, 0])[256]]), med(d[:, 2] - d[:, 1]), cin // 16, med(d[:, 2] - d[:, 1]) // (cin // 16),
+        print('%s abl=%d res=%d: %.1f us per launch | %d blocks; median ticks: prologue %d (setup %d, loads + row transform %d, barrier %d) | first / later rounds prologue %d / %d | K loop %d (%d chunks: %d per chunk) | wait %d, dump 0 %d, barrier %d | combine 0 + dump 1 %d | combine 1 %d | total %d | launch span %d'
+              % (name, abl, use_res, ms * 1e3, len(d), med(d[:, 1] - d[:, 0]), med(d[:, 8] - d[:, 0]), med(d[:, 9] - d[:, 8]), med(d[:, 1] - d[:, 9]), med((d[:, 1] - d[:, 0])[d[:, 0] < np.sort(d[:, 0])[255]]), med((d[:, 1] - d[:, 0])[d[:, 0] >= np.sort(d[:, 0])[256]]), med(d[:, 2] - d[:, 1]), cin // 16, med(d[:, 2] - d[:, 1]) // (cin // 16),
                  med(d[:, 6] - d[:, 2]), med(d[:, 7] - d[:, 6]), med(d[:, 3] - d[:, 7]), med(d[:, 4] - d[:, 3]), med(d[:, 5] - d[:, 4]), med(d[:, 5] - d[:, 0]), d[:, 5].max() - d[:, 0].min()), flush=True)
