@@ -212,6 +212,8 @@ def test_default_switches_are_the_measured_configuration():
         pytest.skip('an A/B switch is set in the environment')
     from stabstitch2_amd import ops, pipeline
     assert ops.WINO_MATH == 'f32' and ops.WINOGRAD is True
+    if 'SS_WINO43' not in os.environ and 'SS_WINO43_MIN_CIN' not in os.environ:
+        assert ops.WINO43 == 'auto' and ops.WINO43_MIN_CIN == 64
     assert pipeline.SKIP_OUTSIDE is True and pipeline.U8_FUSED is True
     src = open(os.path.join(ROOT, 'bench.py')).read()
     assert "'dtype': 'f32'" in src
@@ -263,3 +265,33 @@ def test_round4_entry_points_validate_arguments(built_lib):
     assert L.ss_cost_volume_set_tile(5) == -1 and L.ss_cost_volume_set_tile(0) == 0
     assert L.ss_linear_clip_set_rows(0) == 0
     assert L.ss_version() >= 400
+    # Winograd F(4x4,3x3): pack sizes, geometry it does not take
+    assert L.ss_wino43_packed_floats(128, 128) == 4 * 8 * 36 * 2 * 64 * 4
+    assert L.ss_wino43_packed_floats(128, 120) == 0 and L.ss_wino43_packed_floats(96, 80) == 4608 * 3 * 5 * 4
+    assert L.ss_wino43_pack(None, None, 64, 64, 1, None) == -1
+    assert L.ss_conv3x3_wino43_nhwc(None, None, None, None, None, 1, 8, 8, 64, 64, 0, 64, 1, 0, 0, 0, None) == -1
+
+
+def test_wino43_dispatch_rule(monkeypatch):
+    """ops._uses_wino43 (host logic, no device work): the deep launches of the 60 / 120-wide trunk maps, nothing else."""
+    from stabstitch2_amd import ops
+    monkeypatch.setattr(ops, 'WINO43', 'auto')
+    monkeypatch.setattr(ops, 'WINO43_MIN_CIN', 64)
+    monkeypatch.setattr(ops, 'WINOGRAD', True)
+    monkeypatch.setattr(ops, 'WINO_MATH', 'f32')
+    yes = lambda *a, **k: ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), *a, **k)
+    assert yes(128, 128, 45, 60, 64) and yes(64, 64, 90, 120, 64) and yes(64, 64, 90, 120, 32)
+    assert not yes(128, 128, 45, 60, 32)            # 384 workgroups: less than two rounds of the chip
+    assert not yes(256, 256, 23, 30, 64)            # half of every tile block idle
+    assert not yes(128, 128, 45, 60, 2)             # streaming
+    assert not yes(120, 128, 45, 60, 64) and not yes(128, 96, 45, 60, 64)
+    assert not ops._uses_wino43(1, 3, 3, 2, (0, 1, 1), 64, 128, 45, 60, 64)
+    assert not ops._uses_wino43(5, 3, 3, 1, (2, 1, 1), 128, 128, 7, 9, 64)
+    assert yes(128, 128, 45, 60, 16, groups=4)      # grouped launches count every group's workgroups
+    monkeypatch.setattr(ops, 'WINO_MATH', 'bf16x9')
+    assert not yes(128, 128, 45, 60, 64)            # the exact-product variant exists for F(2x2,3x3) only
+    monkeypatch.setattr(ops, 'WINO_MATH', 'f32')
+    monkeypatch.setattr(ops, 'WINO43', '0')
+    assert not yes(128, 128, 45, 60, 64)
+    monkeypatch.setattr(ops, 'WINO43', '1')
+    assert yes(256, 256, 23, 30, 1) and not yes(120, 128, 45, 60, 64)
