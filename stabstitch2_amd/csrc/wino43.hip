@@ -518,12 +518,15 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
     if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
     constexpr unsigned lds = (unsigned)X_SMEMF * 4u;
-    static bool attr_set = false;
-    if (!attr_set) {        // more than the 64 KB a kernel gets by default
+    // more than the 64 KB a kernel gets by default: a per-DEVICE function attribute (a process may drive several GPUs)
+    static unsigned long long attr_devices = 0ull;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SS_ERR_LAUNCH;
+    if (!((attr_devices >> dev) & 1ull)) {
         if (hipFuncSetAttribute((const void*)conv_wino43_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv_wino43_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return SS_ERR_LAUNCH;
-        attr_set = true;
+        attr_devices |= 1ull << dev;
     }
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
