@@ -831,7 +831,10 @@ def main():
                      'path_hbm_traffic': path_traffic(pmc, io_bytes * args.frames),
                      'path_hbm_frac': round(fps / world * io_bytes / 1e9 / PEAK_HBM_GBS, 5),
                      # whole path against the MFMA roof: 41.31 GFLOP of dense contraction per 2-view frame
-                     'path_mfma_frac': round(fps / world * 41.31e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if args.views == 2 else None},
+                     'path_mfma_frac': round(fps / world * 41.31e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if args.views == 2 else None,
+                     'path_mfma_frac_is': 'DIRECT-convolution flop of the path (41.31 GFLOP per frame) x frames/s / peak: may exceed 1 -- the '
+                                          'Winograd layers execute 16/36 (F(2x2,3x3)) and 36/144 (F(4x4,3x3)) of their direct flop; `frac` above '
+                                          'is on executed flop'},
     }
     if dist is not None:
         result['ranks'] = dist.get_world_size()
