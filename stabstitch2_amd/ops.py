@@ -159,6 +159,7 @@ WINOGRAD = os.environ.get('SS_WINOGRAD', '1') == '1'
 # 'auto' = the rule below, '0' = never, '1' = wherever the kernel's geometry constraints hold (tests / A-B runs)
 WINO43 = os.environ.get('SS_WINO43', 'auto')
 WINO43_MIN_CIN = int(os.environ.get('SS_WINO43_MIN_CIN', '64'))
+WINO43_MIN_WGS = int(os.environ.get('SS_WINO43_MIN_WGS', '512'))
 
 
 def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
@@ -172,7 +173,7 @@ def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
     eff = ho * wo / float(nby * 8 * nbx * 60)
     # one workgroup per CU: at least two full rounds of the chip, tile slots >= 85 % used, K long enough to carry the
     # un-overlapped prologue / epilogue (cin >= 128: tools/bench_wino43.py)
-    return eff >= 0.85 and images * nby * nbx * (cout // 64) * groups >= 512 and cin >= WINO43_MIN_CIN
+    return eff >= 0.85 and images * nby * nbx * (cout // 64) * groups >= WINO43_MIN_WGS and cin >= WINO43_MIN_CIN
 
 
 def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
