@@ -167,6 +167,8 @@ def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
         return False
     if (kt, kh, kw) != (1, 3, 3) or stride != 1 or tuple(pad) != (0, 1, 1) or cin % 16 or cout % 64:
         return False
+    if images * ho * wo * max(cin, cout) * 4 >= 0xFFFF0000:       # the kernel's 32-bit buffer offsets (ss_conv3x3_wino43_nhwc refuses)
+        return False
     if WINO43 == '1':
         return True
     nby, nbx = -(-ho // 8), -(-wo // 60)
