@@ -423,13 +423,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     }
 #ifdef SS_TUNING
     if (p.dbg && tid == 0) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 10;
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 12;
         for (int i = 0; i < 5; ++i) d[i] = ts[i];
         d[5] = __builtin_amdgcn_s_memtime();
         d[6] = ts[5];
         d[7] = ts[6];
         d[8] = ts[7];
         d[9] = ts[8];
+        d[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID, XCC_ID
+        d[11] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
