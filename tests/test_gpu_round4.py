@@ -568,3 +568,32 @@ def test_reference_goldens_with_wino43_everywhere(dev, golden, hip_nets, clip16,
     T.test_nets_vs_reference(dev, golden, hip_nets, clip16)
     assert calls[0] >= 10, calls
     T.test_pipeline_vs_reference(dev, golden, hip_nets, clip16)
+
+
+def test_conv_wino43_random_geometry(dev):
+    """Sixteen seeded random geometries of the F(4x4,3x3) kernel against fp64: maps from 1 x 1 up to several tile blocks in both
+    directions (rows not a multiple of 8, columns not a multiple of 60 / 4), 1-3 images, 16-80 input channels, residual / ReLU at
+    random.  Same gate as test_conv_wino43_against_fp64."""
+    from stabstitch2_amd import ops
+    import torch.nn.functional as F
+    rs = np.random.RandomState(20260929)
+    for case in range(16):
+        n = int(rs.randint(1, 4))
+        h = int(rs.choice([1, 2, 3, 5, 8, 9, 17, 31, 46]))
+        w = int(rs.choice([1, 2, 4, 7, 59, 60, 61, 64, 121, 139]))
+        cin = int(rs.choice([16, 32, 48, 64, 80]))
+        cout = int(rs.choice([64, 128]))
+        with_res, relu = bool(rs.randint(2)), bool(rs.randint(2))
+        g = torch.Generator().manual_seed(1000 + case)
+        x = torch.randn(n, h, w, cin, generator=g).to(dev)
+        wgt = (torch.randn(cout, 1, 3, 3, cin, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev)
+        bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+        res = torch.randn(n, h, w, cout, generator=g).to(dev) if with_res else None
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wgt[:, 0].permute(0, 3, 1, 2).double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+        if with_res:
+            ref = ref + res.double()
+        if relu:
+            ref = torch.relu(ref)
+        y = ops.conv_winograd43(x, wgt, bias, res, relu)
+        close(y, ref.float(), 2e-4 * max(1.0, float(ref.abs().max())), 'F(4x4,3x3) random case %d: n %d %dx%d %d->%d res %d relu %d'
+              % (case, n, h, w, cin, cout, with_res, relu))
