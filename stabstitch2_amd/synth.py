@@ -121,24 +121,103 @@ def _fill(key, ref):
     return torch.from_numpy(rs.normal(0, np.sqrt(gain / fan_in), shape).astype(np.float32))
 
 
-def synthetic_state_dict(module, view_shift_px=-216.0):
+# ---- profile 'trained_like': the adversary for the conv engine's rounding error.
+# The default filler is benign (fan-in-scaled normal weights, BN scales within 0.8..1.2 / sqrt(0.5..2)); trained, BN-folded ResNet
+# weights have per-channel scales spread over 10-100x and heavy-tailed taps.  No trained checkpoint exists here, so this profile
+# builds those statistics deterministically: BN gamma log-uniform in [0.05, 4], running_var log-uniform in [1e-3, 30] (folded scale
+# gamma / sqrt(var) over ~4 decades), running_mean = 0.5 sqrt(var) N(0,1), beta N(0, 0.25); conv / FC weights Student-t(nu = 3) times
+# a per-output-channel log-normal gain (sigma 0.8); FC / Conv3d biases N(0, 0.1).  Each weight tensor is then scaled by ONE scalar so
+# that the layer keeps the mean square of its input (He rule on the mean of the per-channel folded gains), i.e. a few loud channels
+# carry the signal and most are 10-100x quieter -- the network stays finite through 17 layers and the regressed motions stay at a
+# few pixels (same head gains as the default profile).
+PROFILES = ('default', 'trained_like')
+T_NU = 3.0
+CH_SIGMA = 0.8
+
+
+def _bn_prefix(conv_key):
+    """'...conv1.weight' -> '...bn1', '...downsample.0.weight' -> '...downsample.1', the stem -> '...stage1.1'; None without BN."""
+    stem = conv_key[:-len('.weight')]
+    if stem.endswith('.conv1') or stem.endswith('.conv2'):
+        return stem[:-len('conv1')] + 'bn' + stem[-1]
+    if stem.endswith('downsample.0'):
+        return stem[:-1] + '1'
+    if stem.endswith('feature_extractor_stage1.0'):
+        return stem[:-1] + '1'
+    return None
+
+
+def _bn_trained(prefix, n):
+    """(gamma, beta, running_mean, running_var) of one BatchNorm of the trained_like profile."""
+    rs = _rs(prefix + '#trained_like')
+    gamma = np.exp(rs.uniform(np.log(0.05), np.log(4.0), n))
+    var = np.exp(rs.uniform(np.log(1e-3), np.log(30.0), n))
+    mean = 0.5 * np.sqrt(var) * rs.normal(0, 1, n)
+    beta = rs.normal(0, 0.25, n)
+    return gamma, beta, mean, var
+
+
+def _fill_trained(key, ref):
+    shape = tuple(ref.shape)
+    leaf = key.rsplit('.', 1)[-1]
+    if leaf == 'num_batches_tracked':
+        return torch.tensor(100, dtype=torch.long)
+    prefix = key.rsplit('.', 1)[0]
+    is_bn = leaf in ('running_var', 'running_mean') or \
+        (len(shape) == 1 and ('bn' in key or 'downsample.1' in key or key.endswith('stage1.1.' + leaf)))
+    if is_bn:
+        gamma, beta, mean, var = _bn_trained(prefix, shape[0])
+        return torch.from_numpy({'weight': gamma, 'bias': beta, 'running_mean': mean, 'running_var': var}[leaf].astype(np.float32))
+    rs = _rs(key + '#trained_like')
+    if leaf == 'bias':
+        return torch.from_numpy(rs.normal(0, 0.1, shape).astype(np.float32))
+    fan_in = int(np.prod(shape[1:]))
+    gain = 2.0
+    if key.startswith('regressNet1_part2.4'):
+        gain = 0.03
+    elif '_part2_ref.4' in key or '_part2_tgt.4' in key:
+        gain = 0.016
+    elif key.startswith('regressNet2_part2.4'):
+        gain = 0.005
+    elif key.startswith('MotionPre.embedding1'):
+        gain = 0.004 ** 2 * fan_in
+    elif key.startswith('MotionPre.embedding3'):
+        gain = 0.3 ** 2 * fan_in
+    elif key.startswith('MotionPre.decoding'):
+        gain = 0.5
+    taps = rs.standard_t(T_NU, shape)
+    ch = np.exp(CH_SIGMA * rs.normal(0, 1, shape[0]))
+    fold = np.ones(shape[0])
+    bn = _bn_prefix(key)
+    if bn is not None:
+        gamma, _, _, var = _bn_trained(bn, shape[0])
+        fold = gamma / np.sqrt(var + 1e-5)
+    t_var = T_NU / (T_NU - 2.0)
+    base = np.sqrt(gain / (fan_in * t_var * np.mean((ch * fold) ** 2)))
+    w = taps * (base * ch).reshape((-1,) + (1,) * (len(shape) - 1))
+    return torch.from_numpy(w.astype(np.float32))
+
+
+def synthetic_state_dict(module, view_shift_px=-216.0, profile='default'):
     """Fill every entry of `module.state_dict()` deterministically (same values for any module
-    with the same key layout: reference, oracle or HIP-backed)."""
+    with the same key layout: reference, oracle or HIP-backed).  profile: 'default' (benign) | 'trained_like' (harsh, above)."""
+    assert profile in PROFILES, profile
+    fill = _fill if profile == 'default' else _fill_trained
     sd = {}
     for key, ref in module.state_dict().items():
-        sd[key] = _fill(key, ref).to(ref.dtype)
+        sd[key] = fill(key, ref).to(ref.dtype)
     k = 'regressNet1_part2.4.bias'
     if k in sd and view_shift_px is not None:
         sd[k] = torch.tensor([view_shift_px, 0.0] * 4, dtype=torch.float32)
     return sd
 
 
-def write_synthetic_checkpoints(model_dir, spatial, temporal, smooth):
+def write_synthetic_checkpoints(model_dir, spatial, temporal, smooth, profile='default'):
     """spatial_warp.pth / temporal_warp.pth / smooth_warp.pth in the reference layout."""
     import os
     os.makedirs(model_dir, exist_ok=True)
     for name, mod in (('spatial_warp', spatial), ('temporal_warp', temporal), ('smooth_warp', smooth)):
-        torch.save({'model': synthetic_state_dict(mod)}, os.path.join(model_dir, name + '.pth'))
+        torch.save({'model': synthetic_state_dict(mod, profile=profile)}, os.path.join(model_dir, name + '.pth'))
 
 
 def make_clip_device(n_frames, height, width, seed=0, views=2, device='cuda'):

@@ -26,6 +26,7 @@ import ref_shim  # noqa: E402
 ref_shim.install()
 
 import cases  # noqa: E402
+import manifest  # noqa: E402
 from stabstitch2_amd import synth  # noqa: E402
 
 import spatial_network as RS  # noqa: E402   (reference)
@@ -42,6 +43,8 @@ torch.set_grad_enabled(False)
 
 
 def save(name, **arrs):
+    assert sorted(arrs) == sorted(manifest.KEYS[name]), \
+        '%s: keys differ from tests/golden/manifest.py: %s' % (name, sorted(set(arrs) ^ set(manifest.KEYS[name])))
     out = {}
     for k, v in arrs.items():
         if torch.is_tensor(v):
@@ -52,10 +55,10 @@ def save(name, **arrs):
     print('%-28s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
 
 
-def ref_nets():
+def ref_nets(profile='default'):
     sp, tp, sm = RS.SpatialNet().eval(), RT.TemporalNet().eval(), RM.SmoothNet().eval()
     for m in (sp, tp, sm):
-        m.load_state_dict(synth.synthetic_state_dict(m), strict=True)
+        m.load_state_dict(synth.synthetic_state_dict(m, profile=profile), strict=True)
     return sp, tp, sm
 
 
@@ -383,6 +386,37 @@ def g13(nets):
          left_f32=frames[0][:, 96:160].copy(), right_f32=frames[0][:, 544:608].copy())
 
 
+def g14():
+    """G8 + G9 again under the harsh checkpoint (`synth.synthetic_state_dict(profile='trained_like')`: BN-folded channel scales over
+    four decades, Student-t taps, per-channel log-normal gains) on a 24-frame clip -- long enough that the product's launch-size rule
+    picks F(4x4,3x3) for layer1 AND layer2 by itself (48 images x 12 tile blocks x 2 cout blocks = 576 >= 512 workgroups).
+    Pins: the networks' raw outputs, the motions, the smoothed meshes, the NORMAL / AVERAGE frames and the alignment PSNR / SSIM."""
+    nets = ref_nets('trained_like')
+    sp = nets[0]
+    n = 24
+    hr, lr = synth.make_clip(n, 360, 480, seed=5)
+    o1, o2r, o2t = sp(lr[0][0], lr[1][0])
+    st = run_motion_stages(nets, lr[0], lr[1])
+    acc = st['acc']
+    res = dict(offset_1=o1, offset_2_ref=o2r, offset_2_tgt=o2t,
+               motion1=torch.cat(st['s1'], 0), motion2=torch.cat(st['s2'], 0),
+               tmotion1=torch.cat(st['t1'], 0), tmotion2=torch.cat(st['t2'], 0),
+               tsmotion1=torch.cat(st['ts1'], 0), tsmotion2=torch.cat(st['ts2'], 0),
+               smooth_mesh1=acc['smooth_mesh1'], smooth_mesh2=acc['smooth_mesh2'], ori_mesh2=acc['ori_mesh2'],
+               ori_path2=acc['ori_path2'], smooth_path2=acc['smooth_path2'],
+               **{'w0_' + k: v for k, v in st['first'].items()})
+    frames, ow, oh = RP.get_stable_sqe(hr[0], hr[1], acc['smooth_mesh1'], acc['smooth_mesh2'], 'NORMAL', 'AVERAGE')
+    res['canvas_normal_average'] = np.array([int(oh), int(ow)])
+    res['frames_normal_average'] = np.stack([cases.box_down(f, 16) for f in frames])
+    res['iqr_normal_average'] = np.stack([cases.box_iqr(f, 16) for f in frames])
+    l1, l2 = RMET.get_stable_sqe(lr[0], lr[1], acc['smooth_mesh1'], acc['smooth_mesh2'])
+    ps = skimage_metrics([(a[..., 0:3] * (a[..., 3:6] * b[..., 3:6]), b[..., 0:3] * (a[..., 3:6] * b[..., 3:6]))
+                          for a, b in zip(l1, l2)])
+    res['psnr'] = np.array([p for p, _ in ps])
+    res['ssim'] = np.array([s for _, s in ps])
+    save('g14_trained_like', **res)
+
+
 def g11():
     a, b = cases.g11_images()
     (p, s), = skimage_metrics([(a, b)])
@@ -417,3 +451,5 @@ if __name__ == '__main__':
         g11()
     if want('g12'):
         g12(nets)
+    if want('g14'):
+        g14()

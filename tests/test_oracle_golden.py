@@ -370,3 +370,57 @@ def test_frame_io_vs_handworked_cv2_vectors():
     assert [[int(r0[i]), int(r1[i]), int(b0[i]), int(b1[i])] for i in range(4)] == d['taps_y_1080_360_first4']
     # one value worked by hand: 5 -> 3 columns: dx = 0: fx = 0.5 * (5/3) - 0.5 = 1/3 -> taps (round(2048 * 2/3), round(2048 / 3))
     assert [list(t) for t in [FIO.linear_tables(5, 3)[k][:1].tolist() for k in range(3)]] == [[0], [1365], [683]]
+
+
+def test_fixture_keys_match_manifest(golden):
+    """Every committed fixture carries exactly the keys tests/golden/manifest.py lists -- the table make_goldens.save() is held
+    to at generation time -- and every manifest entry has its fixture: a fixture cannot drift from its recipe unnoticed."""
+    import glob
+    import manifest
+    here = os.path.dirname(cases.__file__)
+    on_disk = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(here, '*.npz')))
+    assert on_disk == sorted(manifest.KEYS), (on_disk, sorted(manifest.KEYS))
+    for name, keys in manifest.KEYS.items():
+        assert sorted(golden(name).files) == sorted(keys), (name, sorted(set(golden(name).files) ^ set(keys)))
+
+
+def test_g14_trained_like_profile(golden):
+    """The oracle against the reference under the harsh checkpoint (G14: BN-folded channel scales over four decades, Student-t
+    taps, per-channel gains).  Networks on the first 8 frames of the 24 (motions, first smoothing window), frames rendered with the
+    golden meshes; same gates as G8 / G9."""
+    g = golden('g14_trained_like')
+    sp, tp, sm = N.SpatialNet().eval(), N.TemporalNet().eval(), N.SmoothNet().eval()
+    for m in (sp, tp, sm):
+        m.load_state_dict(synth.synthetic_state_dict(m, profile='trained_like'), strict=True)
+    n = 8
+    hr, lr = synth.make_clip(24, 360, 480, seed=5)
+    hr = [v[:n] for v in hr]
+    lr = [v[:n] for v in lr]
+    o1, o2r, o2t = sp(lr[0][0], lr[1][0])
+    close(o1, g['offset_1'], 1e-3, 'offset_1')
+    close(o2r, g['offset_2_ref'], 1e-3, 'offset_2_ref')
+    close(o2t, g['offset_2_tgt'], 1e-3, 'offset_2_tgt')
+    s1, s2 = P.spatial_stage(sp, lr[0], lr[1])
+    t1 = P.temporal_stage(tp, lr[0])
+    t2 = P.temporal_stage(tp, lr[1])
+    smesh1, ts1 = P.tsmotion_prepare(s1, t1)
+    smesh2, ts2 = P.tsmotion_prepare(s2, t2)
+    close(torch.cat(s1, 0), g['motion1'][:n], 5e-2, 'motion1')
+    close(torch.cat(s2, 0), g['motion2'][:n], 5e-2, 'motion2')
+    close(torch.cat(t1, 0), g['tmotion1'][:n], 1e-3, 'tmotion1')
+    close(torch.cat(t2, 0), g['tmotion2'][:n], 1e-3, 'tmotion2')
+    close(torch.cat(ts1, 0), g['tsmotion1'][:n], 5e-2, 'tsmotion1')
+    acc = P.smooth_stage(sm, ts1, ts2, smesh1, smesh2)             # windows 0 and 1
+    close(acc['smooth_mesh1'], g['smooth_mesh1'][:, :n], 5e-2, 'smooth_mesh1')
+    close(acc['smooth_mesh2'], g['smooth_mesh2'][:, :n], 5e-2, 'smooth_mesh2')
+    m1 = torch.from_numpy(g['smooth_mesh1'])
+    m2 = torch.from_numpy(g['smooth_mesh2'])
+    frames, ow, oh = P.get_stable_sqe(hr[0][:3], hr[1][:3], m1, m2, 'NORMAL', 'AVERAGE')
+    assert [int(oh), int(ow)] == list(g['canvas_normal_average'])
+    got = np.stack([cases.box_down(f, 16) for f in frames])
+    close_boxes(got, g['frames_normal_average'][:3], g['iqr_normal_average'][:3], 5e-2, 'frames')
+    w1 = M.warp_lr_with_mask(lr[0][:3], m1)
+    w2 = M.warp_lr_with_mask(lr[1][:3], m2)
+    for i in range(3):
+        p, s = M.alignment_psnr_ssim(w1[i], w2[i])
+        assert abs(p - g['psnr'][i]) < 0.01 and abs(s - g['ssim'][i]) < 1e-3, (i, p, s, g['psnr'][i], g['ssim'][i])
