@@ -139,6 +139,15 @@ SS_API int ss_conv3x3_wino_pool2_nhwc(const float* in, const float* packed, cons
  * SS_ERR_UNSUPPORTED.  ss_wino43_pack: wgt [groups][cout][1][3][3][cin] -> packed [groups][ss_wino43_packed_floats].  All other
  * arguments as ss_conv3x3_wino_nhwc. */
 SS_API long long ss_wino43_packed_floats(int cout, int cin);
+/* The engine's dispatch rule for the F(4x4,3x3) kernel, for callers that want the library's choice (the Python host applies it:
+ * ops._uses_wino43; the counterpart of ss_conv_uses_winograd): 1 when the geometry is one the kernel takes (1x3x3, stride 1,
+ * cin % 16 == 0, cout % 64 == 0, 32-bit buffer offsets) AND the launch pays -- one 8 x 60-pixel x 64-channel tile per workgroup,
+ * one workgroup per CU: >= min_wgs workgroups (<= 0: 512, two rounds of the chip), >= min_fill_pct % of the tile slots on real
+ * pixels (<= 0: 85), cin >= min_cin (<= 0: 64); all three at 1 = wherever the kernel runs at all.  images = images per group,
+ * groups = launch groups.  Results of the three 3x3 kernels agree to fp32
+ * rounding, so the kernel choice (hence the launch size) shows in the last digits: pin it with min_wgs for reproducible runs. */
+SS_API int ss_conv_uses_wino43(int kt, int kh, int kw, int stride, int cin, int cout, int ho, int wo, int images, int groups,
+                               int min_wgs, int min_cin, int min_fill_pct);
 SS_API int ss_wino43_pack(const float* wgt, float* packed, int cout, int cin, int groups, void* stream);
 SS_API int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
                                   int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,

@@ -39,6 +39,7 @@ SIGNATURES = {
     'ss_conv3x3_wino_nhwc': (c_i, [c_fp] * 5 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
     'ss_conv3x3_wino3_nhwc': (c_i, [c_fp] * 5 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
     'ss_wino43_packed_floats': (c_ll, [c_i, c_i]),
+    'ss_conv_uses_wino43': (c_i, [c_i] * 13),
     'ss_wino43_pack': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
     'ss_conv3x3_wino43_nhwc': (c_i, [c_fp] * 5 + [c_i] * 8 + [c_ll] * 3 + [c_st]),
     'ss_conv3x3_wino_pool2_nhwc': (c_i, [c_fp] * 4 + [c_i] * 8 + [c_ll] * 3 + [c_st]),

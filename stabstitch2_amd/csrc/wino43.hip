@@ -25,6 +25,8 @@
 // Results differ from wino.hip / the direct form by fp32 rounding of the larger transform constants; simulated end to end
 // against the reference goldens in tools/sim_wino43.py (profiles/r03_f43_simulation.txt) and gated in tests/.
 #include "common.h"
+#include <atomic>
+#include <thread>
 #include <type_traits>
 
 typedef float x_f32x4 __attribute__((ext_vector_type(4)));
@@ -81,7 +83,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const float* base, unsi
 
 // ABL (tuning build, timing only -- wrong results): compile-time ablations of the K loop: 1 no filter loads, 2 no stage 1 (raw
 // loads, row transform, LDS writes), 4 no stage-2 arithmetic, 8 no LDS reads, 16 no barrier
-template <bool RES, int ABL = 0>
+// ONE: cin == 16, the single chunk is the last one (its own instantiation: with the K loop's zero-trip case in the same code hipcc
+// kept the prologue's prefetches alive on a second path around the loop and spilled 47 registers to scratch for it)
+template <bool RES, int ABL = 0, bool ONE = false>
 __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -144,12 +148,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     const unsigned u_wave = (cbk * 2u + (unsigned)blk) * (unsigned)p.nchunk * X_UCHUNK + (unsigned)((3 * pa) * 6 + 3 * pbb) * X_UPOS;
 
     x_f32x16 acc[3][3];
+    auto acc_zero = [&]() {
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][s][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[g][s][r] = 0.f;
+    };
 
     x_f32x4 rr[6];
     if constexpr (ABL & 2) {
@@ -208,17 +214,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
         }
     };
 
-    // ---- prologue: chunk 0 row-transformed in LDS, chunk 1's rows and the first two filter groups in flight
-    X_STAMP(7);
-    raw_issue(0);
-    u_issue(0, 0, 0);
-    u_issue(1, 0, 1);
+    // ---- prologue: chunk 0 row-transformed in LDS, chunk 1's rows and the first two filter groups in flight.  Runs INSIDE each of
+    // the two column-block copies of the K loop: hipcc structurizes the (wave-uniform) branch between them as "copy 0, then maybe
+    // copy 1", so whatever the prologue leaves in registers for copy 1 is live across all of copy 0 -- it spilled 47 registers (12
+    // prefetched vectors) to scratch around copy 0 for that: 114 KB of scratch stores per workgroup, as much as the output tile
+    auto prologue = [&]() {
+        acc_zero();
+        X_STAMP(7);
+        raw_issue(0);
+        u_issue(0, 0, 0);
+        u_issue(1, 0, 1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s1_piece(smem, k);
-    X_STAMP(8);
-    lds_barrier();
-    X_STAMP(1);
-    raw_issue(p.nchunk > 1 ? 1 : 0);
+        for (int k = 0; k < 4; ++k) s1_piece(smem, k);
+        X_STAMP(8);
+        lds_barrier();
+        X_STAMP(1);
+        if constexpr (!ONE) raw_issue(1);
+    };
 
     // ---- epilogue addressing and the residual: set up inside the LAST chunk (live ranges do not cross the K loop), the residual
     // of the first phase requested there too -- behind the chunk's last filter loads, so no wait of the stream covers it
@@ -262,6 +274,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
 
     auto kloop = [&](auto bc) {
         constexpr int B = decltype(bc)::value;          // column block of this wave (compile time: the column transform differs)
+        prologue();
         x_f32x4 rd[2][2];
         float av[2][3];
         if constexpr (ABL & (4 | 8)) {
@@ -342,7 +355,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
                 }
             }
         };
-        for (int c = 0; c + 1 < p.nchunk; ++c) chunk(c, std::true_type{});
+        if constexpr (!ONE) {
+            int c = 0;
+            do { chunk(c, std::true_type{}); } while (++c + 1 < p.nchunk);
+        }
         chunk(p.nchunk - 1, std::false_type{});
     };
     if (pbb == 0) kloop(std::integral_constant<int, 0>{});
@@ -484,6 +500,24 @@ extern "C" int ss_wino43_pack(const float* wgt, float* packed, int cout, int cin
     return ss_launch_status();
 }
 
+// The engine's dispatch rule for this kernel (host/ops.py applies it; bench.py counts executed flops with it): geometry the kernel
+// takes at all, then -- one workgroup per CU -- at least `min_wgs` workgroups (default 512: two rounds of the chip), >= 85 % of the
+// 8 x 60 tile slots used, K long enough to carry the un-overlapped prologue / epilogue (cin >= 64; tools/bench_wino43.py).
+// images = images per group, groups = launch groups.  min_wgs / min_cin / min_fill_pct <= 0: the defaults (512 / 64 / 85); all
+// three at 1 = "wherever the kernel runs at all".
+extern "C" int ss_conv_uses_wino43(int kt, int kh, int kw, int stride, int cin, int cout, int ho, int wo, int images, int groups,
+                                   int min_wgs, int min_cin, int min_fill_pct) {
+    if (kt != 1 || kh != 3 || kw != 3 || stride != 1 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 63)) return 0;
+    if (ho <= 0 || wo <= 0 || images <= 0 || groups <= 0) return 0;
+    if ((long long)images * ho * wo * (cin > cout ? cin : cout) * 4 >= 0xFFFF0000ll) return 0;   // the kernel's 32-bit buffer offsets
+    if (min_wgs <= 0) min_wgs = 512;
+    if (min_cin <= 0) min_cin = 64;
+    if (min_fill_pct <= 0) min_fill_pct = 85;
+    const long long nby = ss_cdiv(ho, X_BH), nbx = ss_cdiv(wo, X_BW);
+    const double eff = (double)ho * wo / (double)(nby * X_BH * nbx * X_BW);
+    return eff * 100.0 >= (double)min_fill_pct && (long long)images * nby * nbx * (cout / 64) * groups >= min_wgs && cin >= min_cin;
+}
+
 #ifdef SS_TUNING
 int g_w43_ablate = 0;                    // ss_debug_set key 21
 #endif
@@ -520,22 +554,32 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
     if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
     constexpr unsigned lds = (unsigned)X_SMEMF * 4u;
-    // more than the 64 KB a kernel gets by default: a per-DEVICE function attribute (a process may drive several GPUs)
-    static unsigned long long attr_devices = 0ull;
+    // more than the 64 KB a kernel gets by default: a per-DEVICE function attribute (a process may drive several GPUs), set once per
+    // device whichever host thread launches first: 0 = not yet, 1 = a thread is setting it, 2 = set, 3 = the device refused
+    static std::atomic<int> attr_state[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SS_ERR_LAUNCH;
-    if (!((attr_devices >> dev) & 1ull)) {
-        if (hipFuncSetAttribute((const void*)conv_wino43_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_wino43_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return SS_ERR_LAUNCH;
-        attr_devices |= 1ull << dev;
+    int st8 = attr_state[dev].load(std::memory_order_acquire);
+    if (st8 != 2) {
+        int expect = 0;
+        if (st8 == 0 && attr_state[dev].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) {
+            const bool ok =
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            attr_state[dev].store(ok ? 2 : 3, std::memory_order_release);
+        }
+        while ((st8 = attr_state[dev].load(std::memory_order_acquire)) == 1) std::this_thread::yield();
+        if (st8 != 2) return SS_ERR_UNSUPPORTED;       // the device cannot give a workgroup 144 KB of LDS (not gfx950)
     }
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
 #ifdef SS_TUNING
     if (g_w43_ablate && !res) {         // tools/diag_wino43.py <layers> <ablation masks>
         switch (g_w43_ablate) {
-#define X_ABL_CASE(m) case m: hipFuncSetAttribute((const void*)conv_wino43_kernel<false, m>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define X_ABL_CASE(m) case m: (void)hipFuncSetAttribute((const void*)conv_wino43_kernel<false, m>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((conv_wino43_kernel<false, m>), g, dim3(512), lds, st, p); return ss_launch_status();
             X_ABL_CASE(1) X_ABL_CASE(2) X_ABL_CASE(4) X_ABL_CASE(8) X_ABL_CASE(12) X_ABL_CASE(14) X_ABL_CASE(15) X_ABL_CASE(16) X_ABL_CASE(31)
 #undef X_ABL_CASE
@@ -543,7 +587,12 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
         }
     }
 #endif
-    if (res) hipLaunchKernelGGL((conv_wino43_kernel<true>), g, dim3(512), lds, st, p);
-    else hipLaunchKernelGGL((conv_wino43_kernel<false>), g, dim3(512), lds, st, p);
+    if (p.nchunk == 1) {
+        if (res) hipLaunchKernelGGL((conv_wino43_kernel<true, 0, true>), g, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_wino43_kernel<false, 0, true>), g, dim3(512), lds, st, p);
+    } else {
+        if (res) hipLaunchKernelGGL((conv_wino43_kernel<true, 0, false>), g, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_wino43_kernel<false, 0, false>), g, dim3(512), lds, st, p);
+    }
     return ss_launch_status();
 }

@@ -158,24 +158,20 @@ WINOGRAD = os.environ.get('SS_WINOGRAD', '1') == '1'
 # Winograd F(4x4,3x3) (csrc/wino43.hip) where its 8 x 60-pixel tile blocks fit the map and the launch is deep enough:
 # 'auto' = the rule below, '0' = never, '1' = wherever the kernel's geometry constraints hold (tests / A-B runs)
 WINO43 = os.environ.get('SS_WINO43', 'auto')
-WINO43_MIN_CIN = int(os.environ.get('SS_WINO43_MIN_CIN', '64'))
-WINO43_MIN_WGS = int(os.environ.get('SS_WINO43_MIN_WGS', '512'))
+WINO43_MIN_CIN = int(os.environ.get('SS_WINO43_MIN_CIN', '0'))      # 0 = the library's default (64)
+WINO43_MIN_WGS = int(os.environ.get('SS_WINO43_MIN_WGS', '0'))      # 0 = the library's default (512); 1 pins the kernel choice
+                                                                    # per layer whatever the batch (reproducible runs)
 
 
 def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
-    if WINO43 == '0' or not WINOGRAD or WINO_MATH != 'f32':
+    """The library's rule (ss_conv_uses_wino43) behind the host switches: SS_WINO43 = 0 never, 1 wherever the kernel's geometry
+    constraints hold (all thresholds 1), auto = the library's thresholds (or SS_WINO43_MIN_WGS / SS_WINO43_MIN_CIN)."""
+    if WINO43 == '0' or not WINOGRAD or WINO_MATH != 'f32' or tuple(pad) != (0, 1, 1):
         return False
-    if (kt, kh, kw) != (1, 3, 3) or stride != 1 or tuple(pad) != (0, 1, 1) or cin % 16 or cout % 64:
-        return False
-    if images * ho * wo * max(cin, cout) * 4 >= 0xFFFF0000:       # the kernel's 32-bit buffer offsets (ss_conv3x3_wino43_nhwc refuses)
-        return False
-    if WINO43 == '1':
-        return True
-    nby, nbx = -(-ho // 8), -(-wo // 60)
-    eff = ho * wo / float(nby * 8 * nbx * 60)
-    # one workgroup per CU: at least two full rounds of the chip, tile slots >= 85 % used, K long enough to carry the
-    # un-overlapped prologue / epilogue (cin >= 128: tools/bench_wino43.py)
-    return eff >= 0.85 and images * nby * nbx * (cout // 64) * groups >= WINO43_MIN_WGS and cin >= WINO43_MIN_CIN
+    forced = WINO43 == '1'
+    return bool(H.lib().ss_conv_uses_wino43(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho), int(wo),
+                                            int(images), int(groups), 1 if forced else WINO43_MIN_WGS,
+                                            1 if forced else WINO43_MIN_CIN, 1 if forced else 0))
 
 
 def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
@@ -190,16 +186,16 @@ last_conv_path = None
 
 
 def conv_executed_flop_ratio(kt, kh, kw, stride, cin, cout, out_shape):
-    """Executed MFMA flop / direct-convolution flop of the launch the engine picks for this geometry: 16/36 where the
-    Winograd F(2x2,3x3) kernel runs (the library's own dispatch rule, ss_conv_uses_winograd), else 1."""
+    """Executed MFMA flop / direct-convolution flop of the launch the engine picks for this geometry (the library's own dispatch
+    rules, as ops.conv / ops.conv_grouped apply them): 36/144 on F(4x4,3x3), 16/36 on F(2x2,3x3), else 1."""
     if len(out_shape) == 5 and kt == 1:          # grouped 2-D launch [g,n,ho,wo,c]
-        images = out_shape[0] * out_shape[1]
+        groups, per_group = out_shape[0], out_shape[1]
     else:
-        images = out_shape[0]
+        groups, per_group = 1, out_shape[0]
     ho, wo = out_shape[-3], out_shape[-2]
-    if _uses_wino43(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, images):
+    if _uses_wino43(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, per_group, groups):
         return 36.0 / 144.0
-    return 16.0 / 36.0 if _uses_winograd(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, images) else 1.0
+    return 16.0 / 36.0 if _uses_winograd(kt, kh, kw, stride, (0, 1, 1), cin, cout, ho, wo, per_group * groups) else 1.0
 
 
 # Arithmetic of the Winograd layers' GEMMs.  'f32' (default): v_mfma_f32_32x32x2_f32.  'bf16x9' (opt-in, SS_WINO_MATH):

@@ -164,3 +164,40 @@ def test_two_view_720p_default_kernel_mix_vs_oracle(dev, hip_nets, monkeypatch, 
                                              metrics.warp_lr_planes(lr[1][:kk].to(dev), m2[:, :kk]))
         for i in range(kk):
             assert abs(float(gp[i]) - cps[i][0]) < 0.01 and abs(float(gs[i]) - cps[i][1]) < 1e-3, (i, float(gp[i]), cps[i])
+
+
+def test_wino43_first_launch_from_two_host_threads():
+    """The F(4x4,3x3) kernel needs a per-device function attribute (144 KB of dynamic LDS) set before its first launch; the library
+    sets it once per device under an atomic state machine.  A fresh process whose FIRST two launches come from two host threads at
+    once (each on its own stream) must get both results right -- and equal to a later single-threaded launch, bit for bit."""
+    code = r'''
+import sys, threading, torch
+sys.path.insert(0, %r)
+from stabstitch2_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(7)
+x = torch.randn(4, 16, 60, 64, generator=g).to(dev)
+w = (torch.randn(64, 1, 3, 3, 64, generator=g) * (1.0 / 576) ** 0.5).to(dev)
+pk = ops.wino43_packed(w, 1)                     # (the filter pack is its own kernel: built before the race)
+torch.cuda.synchronize()
+outs, errs = [None, None], []
+go = threading.Barrier(2)
+def work(i):
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            go.wait()
+            outs[i] = ops.conv_winograd43(x, w, None, None, True)
+            torch.cuda.current_stream().synchronize()
+    except Exception as e:
+        errs.append(repr(e))
+ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errs, errs
+ref = ops.conv_winograd43(x, w, None, None, True)
+torch.cuda.synchronize()
+assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref)
+assert float(ref.abs().max()) > 0.1
+print('ok')
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-2000:], r.stderr[-2000:])

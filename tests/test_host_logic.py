@@ -213,7 +213,16 @@ def test_default_switches_are_the_measured_configuration():
     from stabstitch2_amd import ops, pipeline
     assert ops.WINO_MATH == 'f32' and ops.WINOGRAD is True
     if 'SS_WINO43' not in os.environ and 'SS_WINO43_MIN_CIN' not in os.environ:
-        assert ops.WINO43 == 'auto' and ops.WINO43_MIN_CIN == 64
+        assert ops.WINO43 == 'auto' and ops.WINO43_MIN_CIN == 0 and ops.WINO43_MIN_WGS == 0      # 0 = the library's thresholds
+        from stabstitch2_amd import _hip
+        rule = _hip.lib().ss_conv_uses_wino43                    # (pure host function: callable without a GPU)
+        assert rule(1, 3, 3, 1, 64, 64, 90, 120, 64, 1, 0, 0, 0) == 1 and rule(1, 3, 3, 1, 128, 128, 45, 60, 64, 1, 0, 0, 0) == 1
+        assert rule(1, 3, 3, 1, 128, 128, 45, 60, 16, 1, 0, 0, 0) == 0          # 384 workgroups < 512
+        assert rule(1, 3, 3, 1, 128, 128, 45, 60, 16, 1, 1, 1, 1) == 1          # thresholds pinned to 1: geometry only
+        assert rule(1, 3, 3, 1, 32, 64, 90, 120, 64, 1, 0, 0, 0) == 0           # cin < 64
+        assert rule(1, 3, 3, 1, 256, 256, 23, 30, 64, 1, 0, 0, 0) == 0          # 30-wide map: half of every tile block idles
+        assert rule(1, 3, 3, 2, 64, 128, 45, 60, 64, 1, 0, 0, 0) == 0 and rule(1, 3, 3, 1, 24, 64, 90, 120, 64, 1, 1, 1, 1) == 0
+        assert rule(1, 3, 3, 1, 64, 64, 90, 120, 16, 4, 0, 0, 0) == 1           # groups count towards the launch depth
     assert pipeline.SKIP_OUTSIDE is True and pipeline.U8_FUSED is True
     src = open(os.path.join(ROOT, 'bench.py')).read()
     assert "'dtype': 'f32'" in src
