@@ -34,10 +34,11 @@ PEAK_HBM_GBS = 8000.0
 PMC_PROFILE = os.path.join('profiles', 'r04_pmc_hbm.json')
 
 
-def build_nets(dev):
+def build_nets(dev, profile='default'):
     """The three networks on `dev`: real checkpoints when the reference's `Full_model_inference/full_model_{tra,ssd}/`
     (or $SS_MODEL_DIR) holds the three *.pth files (test_online_tra.py:173-194), else the deterministic synthetic
-    checkpoints of stabstitch2_amd/synth.py.  -> (nets, state_dicts)."""
+    checkpoints of stabstitch2_amd/synth.py (`--weights trained_like`: its harsh profile -- BN-folded channel scales over four
+    decades, Student-t taps; pinned against the reference by tests/golden/g14_trained_like.npz).  -> (nets, state_dicts)."""
     from stabstitch2_amd import synth, pipeline
     from stabstitch2_amd.spatial_network import SpatialNet
     from stabstitch2_amd.temporal_network import TemporalNet
@@ -47,11 +48,11 @@ def build_nets(dev):
         nets = pipeline.load_nets(model_dir, dev)
         build_nets.weights = 'pretrained (%s)' % model_dir
         return list(nets), [{k: v.detach().cpu() for k, v in m.state_dict().items()} for m in nets]
-    build_nets.weights = 'synthetic checkpoints'
+    build_nets.weights = 'synthetic checkpoints' + ('' if profile == 'default' else " (profile '%s')" % profile)
     nets, sds = [], []
     for cls in (SpatialNet, TemporalNet, SmoothNet):
         m = cls()
-        sd = synth.synthetic_state_dict(m)
+        sd = synth.synthetic_state_dict(m, profile=profile)
         m.load_state_dict(sd, strict=True)
         nets.append(m.to(dev))
         sds.append(sd)
@@ -341,6 +342,8 @@ def parse_args(argv=None):
     ap.add_argument('--online', action='store_true', help='streaming mode: one frame pair per push (batch 1), fixed canvas')
     ap.add_argument('--warp_mode', default='NORMAL')
     ap.add_argument('--fusion_mode', default='AVERAGE')
+    ap.add_argument('--weights', default='default', choices=('default', 'trained_like'),
+                    help="synthetic checkpoint profile (stabstitch2_amd/synth.py); trained_like = the conv engine's adversary")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the other BASELINE.json configurations')
     ap.add_argument('--cpu-frames', type=int, default=24)
@@ -681,7 +684,7 @@ def main():
     from stabstitch2_amd import synth, pipeline, _hip
     _hip.lib()
     torch.set_grad_enabled(False)
-    nets, sds = build_nets(dev)
+    nets, sds = build_nets(dev, args.weights)
     # configs[3]: rank r stitches its own clip (seed = rank): N distinct video pairs on N GPUs
     hr, lr = synth.make_clip_device(args.frames, args.height, args.width, seed=rank, views=args.views, device=dev)
     probe = ConvProbe()
@@ -857,6 +860,36 @@ def main():
                 ref_fps = result['other_configs']['720p 2-view fusion LINEAR']['fps'] if 'LINEAR' in k else fps
                 v['frac_of_resident_path'] = round(v['fps'] / ref_fps, 3)
                 v['frac_of_resident_path_steady'] = round(v['fps_steady'] / ref_fps, 3)
+    # Flat scalars of the per-kernel table (the driver's record keeps scalars of `roofline` / `config` / `cpu_baseline` only)
+    for kname, tag in (('conv_wino43_kernel', 'wino43'), ('conv_wino_kernel', 'wino22'), ('conv_igemm_kernel', 'igemm'),
+                       ('stem_pool_kernel', 'stem')):
+        pk = result['roofline']['per_kernel'].get(kname)
+        if pk:
+            result['roofline'][tag + '_launches'] = pk['launches_per_step']
+            result['roofline'][tag + '_avg_us'] = pk['avg_launch_us']
+            result['roofline'][tag + '_frac'] = pk['frac']
+    if 'other_configs' in result:
+        # the reference-definition figures (uint8 host -> uint8 host, D2H inside the clock: test_online_tra.py:152,
+        # 402-403) and the other configurations as FLAT scalars of `config`, so that they survive any truncation of the line
+        oc = result['other_configs']
+
+        def pick(sub, key='fps'):
+            for k, v in oc.items():
+                if sub in k:
+                    return v.get(key)
+            return None
+        hh = '720p 2-view uint8 host->host incl. D2H of every fused frame'
+        summ = {'host_u8_fps': oc.get(hh, {}).get('fps'), 'host_u8_frac_of_resident': oc.get(hh, {}).get('frac_of_resident_path'),
+                'host_u8_fps_steady': oc.get(hh, {}).get('fps_steady'),
+                'host_u8_linear_fps': oc.get(hh + ', fusion LINEAR', {}).get('fps'),
+                'h2d_GBps': oc.get(hh, {}).get('h2d_GBps'), 'd2h_GBps': oc.get(hh, {}).get('d2h_GBps'),
+                'linear_fps': oc.get('720p 2-view fusion LINEAR', {}).get('fps'),
+                'three_view_fps': pick('configs[4]'), 'three_view_linear_fps': oc.get('720p 3-view fusion LINEAR', {}).get('fps'),
+                'configs1_360x480_fps': pick('configs[1]'), 'warp_fast_fps': oc.get('720p 2-view warp FAST', {}).get('fps'),
+                'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
+                'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push')}
+        for k, v in summ.items():
+            result['config']['summary_' + k] = v
     if base and not args.no_cpu_baseline:
         ncpu = os.cpu_count() or 1
         if args.cpu_threads > 0:
@@ -895,6 +928,8 @@ def main():
         par['alignment_psnr_delta_db'] = round(max(abs(float(gp[i]) - cps[i][0]) for i in range(k)), 5)
         par['alignment_ssim_delta'] = round(max(abs(float(gs[i]) - cps[i][1]) for i in range(k)), 6)
         result['parity_vs_cpu'] = par
+        for k, v in par.items():                   # flat copies where the driver's record keeps them
+            result['cpu_baseline']['parity_' + k] = v
     emit(result)
     if dist is not None:
         dist.destroy_process_group()

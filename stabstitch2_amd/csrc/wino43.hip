@@ -59,14 +59,25 @@ struct W43P {
 #define X_STAMP(i) do { } while (0)
 #endif
 
+#ifndef X_SCHED
+#define X_SCHED 1
+#endif
+
 namespace {
 constexpr int X_TXU = 15;                    // tiles per tile row that carry pixels (slot 15 idles)
 constexpr int X_BH = 8, X_BW = 4 * X_TXU;    // output pixels of a block
 constexpr int X_RW = X_BW + 2;               // raw columns (62)
-constexpr int X_RWP = 64;                    // row pitch of V1 (dwords): tile row stride 6 * 64 = 0 (mod 64 banks)
-constexpr int X_TYS = 6 * X_RWP;             // tile-row stride
-constexpr int X_PL = 2 * X_TYS + 4;          // channel plane; = 4 (mod 8): the four channel quads of a pixel 2 lanes per bank
-constexpr int X_V1F = 16 * X_PL;             // dwords of one V1 buffer
+// V1 (row-transformed input of one chunk) in LDS: [channel PAIR 8][tile row 2][transform row 6][X_ROWP], the two channels of a pair
+// interleaved so that both transforms run on v_pk_*_f32 over aligned register pairs.  A row holds its 62 columns as 16-byte entries
+// (x, x + 1) x (c0, c1): entries of x = 0, 1 (mod 4) -- "A", dwords 0..67 -- and of x = 2, 3 (mod 4) -- "B", from dword 72 (tile row 0)
+// / 76 (tile row 1).  Tile tx's window x = 4 tx .. 4 tx + 5 is A[tx], B[tx], A[tx + 1]: three 16-byte reads, a 16-lane group reads 64
+// consecutive dwords each time (conflict-free).  Stage-1 writes (8 bytes per lane: 8 columns x 4 channel quads per half wave) hit all
+// 64 banks once: quads are 2 planes = 16 banks apart (X_PL = 8 mod 32), B sits 8 banks behind A for the columns a half wave covers
+// (they start at x = 0 mod 8 in tile row 0, at x = 2 mod 8 in tile row 1: hence the two B offsets).
+constexpr int X_ROWP = 140;                  // dwords of a V1 row
+constexpr int X_BOFF0 = 72, X_BOFF1 = 76;    // B entries of tile row 0 / 1
+constexpr int X_PL = 12 * X_ROWP + 24;       // channel-pair plane (1704 = 8 mod 32)
+constexpr int X_V1F = 8 * X_PL;              // dwords of one V1 buffer
 constexpr int X_DUMPF = 36 * 32 * 32;        // epilogue stage: [position][tile][cout of one 32-channel block]
 constexpr int X_SMEMF = X_DUMPF > 2 * X_V1F ? X_DUMPF : 2 * X_V1F;
 constexpr unsigned X_UPOS = 2048u;           // bytes of one packed position (2 halves x 64 lanes x 16 B)
@@ -80,6 +91,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const float* base, unsi
     void* ub = (void*)(((unsigned long long)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+
+// Packed fp32 on register PAIRS (the two channels of a pair), forced by inline asm: hipcc's gfx950 model unpacks v_pk_* between MFMAs
+// ("packed fp32 does not co-issue with the matrix pipe"), but beside a dense v_mfma_f32_32x32x2_f32 stream a v_pk_fma_f32 costs the
+// same issue slot as a v_fma_f32 (tools/micro/mfma_valu kind 3 vs 2: 117 vs 121 TF/s at 4 per MFMA, 95 vs 83 at 8) -- half the
+// transform instructions for the same arithmetic, bit for bit.  k = a wave-uniform constant pair in SGPRs (one constant-bus operand).
+__device__ __forceinline__ x_f32x2 x_pk_k(x_f32x2 k, x_f32x2 x, x_f32x2 c) {        // k * x + c
+    x_f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(k), "v"(x), "v"(c));
+    return d;
+}
+__device__ __forceinline__ x_f32x2 x_pk_nk(x_f32x2 k, x_f32x2 x, x_f32x2 c) {       // (-k) * x + c
+    x_f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "s"(k), "v"(x), "v"(c));
+    return d;
+}
+__device__ __forceinline__ x_f32x2 x_pk_add(x_f32x2 a, x_f32x2 b) {
+    x_f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ x_f32x2 x_pk_sub(x_f32x2 a, x_f32x2 b) {                  // a - b
+    x_f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#define X_LO(v) __builtin_shufflevector(v, v, 0, 1)
+#define X_HI(v) __builtin_shufflevector(v, v, 2, 3)
 
 // ABL (tuning build, timing only -- wrong results): compile-time ablations of the K loop: 1 no filter loads, 2 no stage 1 (raw
 // loads, row transform, LDS writes), 4 no stage-2 arithmetic, 8 no LDS reads, 16 no barrier
@@ -135,13 +173,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
         rmask |= (s1_real && (unsigned)(s1_iy0 + r) < (unsigned)p.H && (unsigned)s1_ix < (unsigned)p.W) ? 0 : (1 << r);
-    const int s1_lds = (4 * s1_q) * X_PL + s1_ty * X_TYS + s1_xx;
+    const int s1_lds = (2 * s1_q) * X_PL + (6 * s1_ty) * X_ROWP + ((s1_xx & 2) ? (s1_ty ? X_BOFF1 : X_BOFF0) : 0) + (s1_xx >> 2) * 4 + (s1_xx & 1) * 2;
 
     // ---- this lane in the GEMMs (v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5]): tile lane & 31, channels
-    // 8 kh .. 8 kh + 7 of the chunk; 16-lane groups of a 16-byte LDS read hold tiles of both tile rows: rows are 0 (mod 64) apart
+    // 8 kh .. 8 kh + 7 of the chunk = pairs 4 kh .. 4 kh + 3
     const int kh = lane >> 5;
     const int m_tile = lane & 31;
-    const int t_src = (8 * kh) * X_PL + (m_tile >> 4) * X_TYS + (3 * pa) * X_RWP + 4 * (m_tile & 15);
+    const int t_srcA = (4 * kh) * X_PL + ((m_tile >> 4) * 6 + 3 * pa) * X_ROWP + 4 * (m_tile & 15);
+    const int t_srcB = t_srcA + ((m_tile >> 4) ? X_BOFF1 : X_BOFF0);
+    const x_f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f};
 
     const unsigned u_lane = (unsigned)lane * 16u;
     // packed filters: [cout/32][chunk][pos 36][half][lane][4]
@@ -171,23 +211,25 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
         for (int r = 0; r < 6; ++r)
             rr[r] = __builtin_bit_cast(x_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase + (unsigned)r * rowstep + coff) | (unsigned)__builtin_amdgcn_sbfe(rm, r, 1), 0, 0));
     };
-    // row transform B^T d of channel k of the quad, written to V1 rows 0..5
-    auto s1_piece = [&](float* buf, int k) {
+    // row transform B^T d of channel pair pr of the quad (rows 0..2 when half == 0, rows 3..5 when half == 1), packed over the pair
+    auto s1_piece = [&](float* buf, int pr, int half) {
         if constexpr (ABL & 2) return;
-        const float d0 = rr[0][k], d1 = rr[1][k], d2 = rr[2][k], d3 = rr[3][k], d4 = rr[4][k], d5 = rr[5][k];
-        float t1 = __builtin_fmaf(-4.f, d2, d4);
-        asm("" : "+v"(t1));
-        const float t2 = __builtin_fmaf(-4.f, d1, d3);
-        float t3 = d4 - d2;
-        asm("" : "+v"(t3));
-        const float t4 = d3 - d1;
-        float* w = buf + s1_lds + k * X_PL;
-        w[0 * X_RWP] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-        w[1 * X_RWP] = t1 + t2;
-        w[2 * X_RWP] = t1 - t2;
-        w[3 * X_RWP] = __builtin_fmaf(2.f, t4, t3);
-        w[4 * X_RWP] = __builtin_fmaf(-2.f, t4, t3);
-        w[5 * X_RWP] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+        auto D = [&](int r) { return pr ? X_HI(rr[r]) : X_LO(rr[r]); };
+        float* w = buf + s1_lds + pr * X_PL;
+        auto put = [&](int i, x_f32x2 v) { *reinterpret_cast<x_f32x2*>(w + i * X_ROWP) = v; };
+        if (half == 0) {
+            const x_f32x2 t1 = x_pk_nk(k4, D(2), D(4));
+            const x_f32x2 t2 = x_pk_nk(k4, D(1), D(3));
+            put(0, x_pk_k(k4, D(0), x_pk_nk(k5, D(2), D(4))));
+            put(1, x_pk_add(t1, t2));
+            put(2, x_pk_sub(t1, t2));
+        } else {
+            const x_f32x2 t3 = x_pk_sub(D(4), D(2));
+            const x_f32x2 t4 = x_pk_sub(D(3), D(1));
+            put(3, x_pk_k(k2, t4, t3));
+            put(4, x_pk_nk(k2, t4, t3));
+            put(5, x_pk_k(k4, D(1), x_pk_nk(k5, D(3), D(5))));
+        }
     };
     auto lds_barrier = [&]() {       // __syncthreads() minus its global-memory fence (it would drain every prefetch in flight)
         if constexpr (ABL & 16) return;
@@ -225,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
         u_issue(0, 0, 0);
         u_issue(1, 0, 1);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s1_piece(smem, k);
+        for (int k = 0; k < 4; ++k) s1_piece(smem, k >> 1, k & 1);
         X_STAMP(8);
         lds_barrier();
         X_STAMP(1);
@@ -275,45 +317,45 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     auto kloop = [&](auto bc) {
         constexpr int B = decltype(bc)::value;          // column block of this wave (compile time: the column transform differs)
         prologue();
-        x_f32x4 rd[2][2];
-        float av[2][3];
+        x_f32x4 rd[3];                                   // the window row of one pair step: A[tx], B[tx], A[tx + 1]
+        x_f32x2 av[2][3];
         if constexpr (ABL & (4 | 8)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                rd[i][0] = rd[i][1] = (x_f32x4){(float)lane, 1.f, 2.f, 3.f};
-                av[i][0] = av[i][1] = av[i][2] = (float)(lane + i);
-            }
+            for (int i = 0; i < 3; ++i) rd[i] = (x_f32x4){(float)lane, 1.f, 2.f, 3.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i][0] = av[i][1] = av[i][2] = (x_f32x2){(float)(lane + i), 1.f};
         }
-        // step m of a chunk = (half h = m / 12, position row g = (m / 4) % 3, channel e = m % 4)
-        auto rd_issue = [&](const float* buf, int m, int slot) {
+        // pair step M of a chunk = (half h = M / 6, position row g = (M / 2) % 3, channel pair e2 = M % 2 of the half's four channels):
+        // two MFMA steps (channels 2 e2, 2 e2 + 1) x three positions
+        auto rd_issue = [&](const float* buf, int M) {
             if constexpr (ABL & 8) return;
-            const int h = m / 12, g = (m / 4) % 3, e = m % 4;
-            const float* src = buf + t_src + (4 * h + e) * X_PL + g * X_RWP;
-            rd[slot][0] = *reinterpret_cast<const x_f32x4*>(src);
-            rd[slot][1] = *reinterpret_cast<const x_f32x4*>(src + 4);
+            const int h = M / 6, g = (M / 2) % 3, e2 = M % 2;
+            const int off = (2 * h + e2) * X_PL + g * X_ROWP;
+            rd[0] = *reinterpret_cast<const x_f32x4*>(buf + t_srcA + off);
+            rd[1] = *reinterpret_cast<const x_f32x4*>(buf + t_srcB + off);
+            rd[2] = *reinterpret_cast<const x_f32x4*>(buf + t_srcA + off + 4);
         };
+        // column transform of the window row in rd -> the three A operands of this wave's column block, both channels of the pair
         auto xf = [&](int slot) {
             if constexpr (ABL & 4) return;
-            const float x0 = rd[slot][0][0], x1 = rd[slot][0][1], x2 = rd[slot][0][2], x3 = rd[slot][0][3];
-            const float x4 = rd[slot][1][0], x5 = rd[slot][1][1];
+            const x_f32x2 x0 = X_LO(rd[0]), x1 = X_HI(rd[0]), x2 = X_LO(rd[1]), x3 = X_HI(rd[1]), x4 = X_LO(rd[2]), x5 = X_HI(rd[2]);
             if constexpr (B == 0) {
-                float s1 = __builtin_fmaf(-4.f, x2, x4);
-                asm("" : "+v"(s1));                     // keeps hipcc from pairing s1 / s2 into v_pk_fma_f32 (+ 2 v_mov each): packed
-                const float s2 = __builtin_fmaf(-4.f, x1, x3);     // fp32 does not co-issue with the matrix pipe
-                av[slot][0] = __builtin_fmaf(4.f, x0, __builtin_fmaf(-5.f, x2, x4));
-                av[slot][1] = s1 + s2;
-                av[slot][2] = s1 - s2;
+                const x_f32x2 s1 = x_pk_nk(k4, x2, x4);
+                const x_f32x2 s2 = x_pk_nk(k4, x1, x3);
+                av[slot][0] = x_pk_k(k4, x0, x_pk_nk(k5, x2, x4));
+                av[slot][1] = x_pk_add(s1, s2);
+                av[slot][2] = x_pk_sub(s1, s2);
             } else {
-                const float s3 = x4 - x2, s4 = x3 - x1;
-                av[slot][0] = __builtin_fmaf(2.f, s4, s3);
-                av[slot][1] = __builtin_fmaf(-2.f, s4, s3);
-                av[slot][2] = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));
+                const x_f32x2 s3 = x_pk_sub(x4, x2), s4 = x_pk_sub(x3, x1);
+                av[slot][0] = x_pk_k(k2, s4, s3);
+                av[slot][1] = x_pk_nk(k2, s4, s3);
+                av[slot][2] = x_pk_k(k4, x1, x_pk_nk(k5, x3, x5));
             }
         };
-        rd_issue(smem, 0, 0);
-        rd_issue(smem, 1, 1);
+        rd_issue(smem, 0);
         xf(0);
-        // one chunk = 24 steps.  MORE (compile time): a chunk follows -- its row transform, its first two steps' operands and its
+        rd_issue(smem, 1);
+        // one chunk = 12 pair steps.  MORE (compile time): a chunk follows -- its row transform, its first two steps' operands and its
         // filters are produced inside this one.  The last chunk is a second copy without them: branches inside the stream cost
         // more than the code (tried: +19 % K-loop time), and nothing stays in flight in front of the epilogue's barrier.
         auto chunk = [&](int c, auto more_c) {
@@ -322,36 +364,42 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
             float* bn = smem + ((c + 1) & 1) * X_V1F;           // chunk c + 1 (written during this chunk)
             const int c2 = c + 2 < p.nchunk ? c + 2 : c + 1;    // (the last but one chunk re-requests its successor's rows: unused)
 #pragma unroll
-            for (int m = 0; m < 24; ++m) {
-                const int G = m / 4, g = G % 3, e = m % 4;
+            for (int M = 0; M < 12; ++M) {
+                const int G = M / 2, g = G % 3, e2 = M % 2;
                 __builtin_amdgcn_sched_barrier(0);
-                if (m + 2 < 24) rd_issue(bc_, m + 2, m & 1);            // (slot m & 1 was consumed by the previous step's xf)
-                else if (MORE) rd_issue(bn, m + 2 - 24, m & 1);
-                if (m + 1 < 24 || MORE) xf((m + 1) & 1);
-                if (e == 0) {                                    // first step of a group: the filters of group G + 2
+                // operands of the next pair step from the row in rd (requested a step ago), then the request of the row after it
+                if (M + 1 < 12 || MORE) xf((M + 1) & 1);
+                if (M + 2 < 12) rd_issue(bc_, M + 2);
+                else if (MORE) rd_issue(bn, M + 2 - 12);
+                if (e2 == 0) {                                   // first step of a group: the filters of group G + 2
                     if (G + 2 < 6) u_issue((G + 2) % 3, c, G + 2);
                     else if (MORE) u_issue((G + 2) % 3, c + 1, G + 2 - 6);
                 }
+#if X_SCHED == 1
+                __builtin_amdgcn_sched_barrier(0);               // the requests go out in front of the step's six MFMAs
+#endif
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    acc[g][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m & 1][s], u[G % 3][s][e], acc[g][s], 0, 0, 0);
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        acc[g][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[M & 1][s][e], u[G % 3][s][2 * e2 + e], acc[g][s], 0, 0, 0);
                 if constexpr (!MORE) {
-                    if (m == 13) { epi_setup(); row_offsets(0); }
-                    if (m == 14) res_col(0);
-                    if (m == 16) res_col(1);
-                    if (m == 18) res_col(2);
-                    if (m == 20) res_col(3);
+                    if (M == 6) { epi_setup(); row_offsets(0); }
+                    if (M == 7) res_col(0);
+                    if (M == 8) res_col(1);
+                    if (M == 9) res_col(2);
+                    if (M == 10) res_col(3);
                 }
                 if constexpr (MORE) {
-                    // stage 1 of chunk c + 1 between the MFMAs of steps 8..14 (its rows were requested a chunk ago)
-                    if (m == 8) s1_piece(bn, 0);
-                    if (m == 10) s1_piece(bn, 1);
-                    if (m == 12) s1_piece(bn, 2);
-                    if (m == 14) s1_piece(bn, 3);
-                    // behind step 16's filter loads: buffer loads return in order, the next filter wait (8 steps on) covers these too
-                    if (m == 17) raw_issue(c2);
-                    // every V1 read of chunk c has been issued (step 23's, two steps ahead); behind the barrier chunk c + 1 is read
-                    if (m == 21) { __builtin_amdgcn_sched_barrier(0); lds_barrier(); }
+                    // stage 1 of chunk c + 1 between the MFMAs of steps 4..7 (its rows were requested a chunk ago)
+                    if (M == 4) s1_piece(bn, 0, 0);
+                    if (M == 5) s1_piece(bn, 0, 1);
+                    if (M == 6) s1_piece(bn, 1, 0);
+                    if (M == 7) s1_piece(bn, 1, 1);
+                    // behind step 8's filter loads: buffer loads return in order, the next filter wait (4 steps on) covers these too
+                    if (M == 8) raw_issue(c2);
+                    // every V1 read of chunk c has been issued (step 11's, two steps ahead); behind the barrier chunk c + 1 is read
+                    if (M == 9) { __builtin_amdgcn_sched_barrier(0); lds_barrier(); }
                 }
             }
         };

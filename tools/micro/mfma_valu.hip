@@ -12,6 +12,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, unsign
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float a = a0 + threadIdx.x * 1e-9f, b = a0;
     float f[8] = {a0, a0 * 2, a0 * 3, a0 * 4, a0 * 5, a0 * 6, a0 * 7, a0 * 8};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 p[4] = {{a0, a0 * 2}, {a0 * 3, a0 * 4}, {a0 * 5, a0 * 6}, {a0 * 7, a0 * 8}};
+    const f32x2 pc = {1.0001f, 0.9999f};
     unsigned x[4] = {seed + threadIdx.x, seed * 3 + 1, seed * 5 + 2, seed * 7 + 3};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -21,6 +24,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, unsign
             for (int v = 0; v < NV; ++v) {
                 if (KIND == 0) x[v & 3] = (x[v & 3] + 0x9E3779B9u) ^ x[(v + 1) & 3];
                 else if (KIND == 2) { f[v & 7] = __builtin_fmaf(f[v & 7], 1.0001f, f[(v + 3) & 7]); }   // independent-ish fp32 FMAs
+                else if (KIND == 3) {      // v_pk_fma_f32 on aligned register pairs (round 5: does the packed form cost one issue slot or two?)
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(p[v & 3]) : "v"(p[v & 3]), "v"(pc), "v"(p[(v + 1) & 3]));
+                } else if (KIND == 4) {
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[v & 3]) : "v"(p[v & 3]), "v"(p[(v + 1) & 3]));
+                }
                 else x[v & 3] = x[v & 3] * 0x9E3779B1u + 1u;
             }
         }
@@ -30,6 +38,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, unsign
     for (int r = 0; r < 16; ++r) s += acc[r];
     unsigned xs = x[0] ^ x[1] ^ x[2] ^ x[3];
     for (int i = 0; i < 8; ++i) s += f[i] * 1e-30f;
+    for (int i = 0; i < 4; ++i) s += (p[i][0] + p[i][1]) * 1e-30f;
     if (s == 12345.678f || xs == 0x12345u) out[threadIdx.x] = s + xs;
 }
 
@@ -56,6 +65,9 @@ int main() {
         run<0, 0>(wps, d); run<2, 0>(wps, d); run<4, 0>(wps, d); run<8, 0>(wps, d); run<12, 0>(wps, d); run<16, 0>(wps, d);
         run<1, 1>(wps, d); run<2, 1>(wps, d); run<4, 1>(wps, d);
         run<2, 2>(wps, d); run<4, 2>(wps, d); run<6, 2>(wps, d); run<8, 2>(wps, d); run<12, 2>(wps, d);
+        run<1, 3>(wps, d); run<2, 3>(wps, d); run<3, 3>(wps, d); run<4, 3>(wps, d); run<6, 3>(wps, d); run<8, 3>(wps, d);
+        run<2, 4>(wps, d); run<4, 4>(wps, d);
+        run<1, 2>(wps, d); run<3, 2>(wps, d);
     }
     return 0;
 }
