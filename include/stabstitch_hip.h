@@ -339,6 +339,15 @@ SS_API int ss_three_view_align(const float* w12_m1, const float* w12_m2, const f
                         void* stream);
 SS_API int ss_three_view_finish(const float* n1, const float* n3, const float* mid, const float* bbox, float* mesh1,
                          float* middle, float* mesh3, long long n_points, void* stream);
+/* Streaming mode (stabstitch2_amd/online.py): the reference sizes the canvas from ALL frames of the clip (test_online_tra.py:
+ * 106-120); a live stream fixes it after its first window, so a mesh that drifts past it later would be cropped silently.  This
+ * launch (one wave per stream, capturable) looks at the push's control points src [streams][views][63][2], already normalised to
+ * each stream's canvas ([-1, 1] = inside), and updates device-resident state that is read only when asked for:
+ *   watch_i [streams][4] int32 = {frames seen, frames with a point outside the canvas, index of the first such frame (-1 = none),
+ *                                 frames with a point within `guard` (normalised units) of an edge or outside}
+ *   watch_f [streams][4] fp32  = running {xmin, xmax, ymin, ymax} of the normalised coordinates (what a grown canvas must cover)
+ * Initialise to {0, 0, -1, 0} / {+inf, -inf, +inf, -inf}. */
+SS_API int ss_canvas_watch(const float* src, int streams, int views, float guard, int* watch_i, float* watch_f, void* stream);
 /* the same for view `view` of `views` of a clip, mesh [frames][63][2], written into the render's source layout
  * out [frames][views][63][2] (one call per view assembles it; test_online_tra.py:129-136) */
 SS_API int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,

@@ -86,6 +86,7 @@ SIGNATURES = {
     'ss_render_linear_clip_u8': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_fp] + [c_i] * 7 + [c_fp, c_st]),
     'ss_mesh_bbox': (c_i, [c_fp, c_i, c_f, c_f, c_fp, c_i, c_st]),
     'ss_mesh_normalize': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
+    'ss_canvas_watch': (c_i, [c_fp, c_i, c_i, c_f, c_fp, c_fp, c_st]),
     'ss_mesh_normalize_views': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_st]),
     'ss_mesh_normalize_views_boxes': (c_i, [c_fp, c_ll, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_st]),
     'ss_fill_f32': (c_i, [c_fp, c_f, c_ll, c_st]),

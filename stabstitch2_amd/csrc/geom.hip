@@ -661,6 +661,42 @@ extern "C" int ss_mesh_normalize_views_boxes(const float* mesh, long long mesh_f
     return ss_launch_status();
 }
 
+// Streaming mode: does the current frame of every live stream still fit its FIXED canvas?  The reference sizes the canvas from ALL
+// frames of the clip (test_online_tra.py:106-120); a stream fixes it after the first window, so a mesh that later drifts past it is
+// cropped.  src [streams][views][63][2] = this push's control points, already normalised to each stream's canvas ([-1, 1] = inside):
+// per stream (one wave) the extremes of both coordinates; watch_i [streams][4] = {frames seen, frames with a point outside the
+// canvas, index of the first such frame (-1), frames with a point closer than `guard` to an edge or outside}, watch_f [streams][4] =
+// running {xmin, xmax, ymin, ymax} of the normalised coordinates over all frames seen -- what a grown canvas must cover.  State
+// lives on the device and is only read when somebody asks (no sync on the push path); capturable (one fixed-size launch).
+__global__ __launch_bounds__(64) void canvas_watch_kernel(const float* __restrict__ src, int npts, float guard, int* __restrict__ watch_i,
+                                                          float* __restrict__ watch_f) {
+    const float* s = src + (long long)blockIdx.x * npts * 2;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int i = threadIdx.x; i < npts; i += 64) {
+        const float x = s[2 * i], y = s[2 * i + 1];
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+        ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+    }
+    xmin = ss_wave_min(xmin); xmax = ss_wave_max(xmax); ymin = ss_wave_min(ymin); ymax = ss_wave_max(ymax);
+    if (threadIdx.x == 0) {
+        int* wi = watch_i + blockIdx.x * 4;
+        float* wf = watch_f + blockIdx.x * 4;
+        const float lo = fminf(xmin, ymin), hi = fmaxf(xmax, ymax);
+        const int seen = wi[0];
+        // (half a pixel of a 4096-wide canvas: the canvas is the first window's OWN bbox when margin = 0, its extremes sit on +-1)
+        const bool out = lo < -1.0f - 2.5e-4f || hi > 1.0f + 2.5e-4f || !(lo == lo) || !(hi == hi);
+        const bool near = out || lo < -1.0f + guard || hi > 1.0f - guard;
+        if (out) { wi[1] += 1; if (wi[2] < 0) wi[2] = seen; }
+        if (near) wi[3] += 1;
+        wi[0] = seen + 1;
+        wf[0] = fminf(wf[0], xmin); wf[1] = fmaxf(wf[1], xmax); wf[2] = fminf(wf[2], ymin); wf[3] = fmaxf(wf[3], ymax);
+    }
+}
+extern "C" int ss_canvas_watch(const float* src, int streams, int views, float guard, int* watch_i, float* watch_f, void* stream) {
+    if (!src || !watch_i || !watch_f || streams <= 0 || views <= 0 || !(guard >= 0.f)) return SS_ERR_ARG;
+    hipLaunchKernelGGL(canvas_watch_kernel, dim3(streams), dim3(64), 0, (hipStream_t)stream, src, views * SS_NV, guard, watch_i, watch_f);
+    return ss_launch_status();
+}
 extern "C" int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,
                                        float img_h, float img_w, void* stream) {
     if (!mesh || !bbox || !out || frames <= 0 || views <= 0 || view < 0 || view >= views) return SS_ERR_ARG;

@@ -77,6 +77,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(const float* base, uns
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// Staged accumulators [conv pixel][32 channels]: a row is 32 dwords = half of the 64 LDS banks, so rows of equal parity collide.  The
+// two halves of a wave write rows R and R + 4 in one instruction, a 16-lane group of the pool's 16-byte reads covers two conv pixels:
+// with row m stored at m ^ bit 2 of m (rows swap inside pairs when bit 2 is set) two rows 4 apart always differ in parity -- both
+// accesses conflict-free (round 4: 0.41 of this kernel's LDS cycles were bank conflicts, all of them here).
+__device__ __forceinline__ int sp_row(int m) { return m ^ ((m >> 2) & 1); }
+
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
     // the input patch [43][172] during the K loop; the staged accumulators [512][32] in the epilogue
     __shared__ __attribute__((aligned(16))) float smem[512 * 32];
@@ -230,13 +236,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
             const int item = tid + 256 * it;
             const int q = item & 7;
             int pp = item >> 3;
+            // a 16-lane group of the 16-byte reads = 8 channel quads x 2 pooled pixels: pixels b and b + 2 of a row (the middle two of
+            // every four swapped; SP_PC = 12 is a multiple of 4), i.e. conv pixels 4 apart -- with the staged rows' parity swizzle
+            // (sp_row) the two land on different bank halves, all nine taps alike
+            pp = (pp & ~3) | ((pp & 1) << 1) | ((pp >> 1) & 1);
             pp = pp < SP_PR * SP_PC ? pp : SP_PR * SP_PC - 1;
             const int a = pp / SP_PC, b = pp - a * SP_PC;
             const int py = py0 + a, px = px0 + b;
-            const float* sp = smem + ((2 * a) * SP_CC + 2 * b) * 32 + 4 * q;
+            const int m0 = (2 * a) * SP_CC + 2 * b;
             sp_f32x4 v[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const sp_f32x4*>(sp + ((t / 3) * SP_CC + (t % 3)) * 32);
+            for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const sp_f32x4*>(smem + sp_row(m0 + (t / 3) * SP_CC + (t % 3)) * 32 + 4 * q);
             if constexpr (MASKED) {
                 bool rok[3], cok[3];
 #pragma unroll
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * (4 * wave + mt) + 8 * (r >> 2) + (r & 3) + 4 * h2;
-                smem[row * 32 + ln] = acc[mt][nt][r];
+                smem[sp_row(row) * 32 + ln] = acc[mt][nt][r];
             }
         __syncthreads();
         if (nt == 0) SP_STAMP(4); else SP_STAMP(6);

@@ -8,6 +8,13 @@ complete (bbox of its 7 frames grown by `margin`), or given by the caller; with 
 reproduces the offline frames (tests/test_gpu_parity.py::test_online_matches_offline).  Per pushed pair the arithmetic is
 exactly the reference's per-frame arithmetic (test_online_tra.py:284-392 with k = t).
 
+Canvas overflow (round 5): the reference would have sized the canvas from ALL frames; here every push also runs a one-wave watcher
+(`ss_canvas_watch`) that records, on the device, whether the frame's mesh left the fixed canvas (`clipped_frames`,
+`overflow_report()`: read lazily, no sync on the push path).  `grow='never'` (default) keeps the canvas and counts;
+`grow='recapture'` re-fixes the canvas (union of the old one and everything seen, plus the margin) and re-captures the graph as soon
+as a frame comes within half the margin of an edge -- checked through an asynchronous copy of the watcher state one push later, so
+a gradual drift grows the canvas BEFORE anything is cropped (an abrupt jump still crops the frames in between; they are counted).
+
 Once the window is full every push runs the same ~150 small kernels on buffers of fixed size, so the steady state is
 captured ONCE into a HIP graph (state lives in static tensors: the rings are shifted, not rotated) and each push is
 two input copies + one graph launch: the Python / ctypes launch overhead (~1 ms per pair, more than the kernels'
@@ -53,8 +60,19 @@ def _spatial_temporal_heads(spatial, temporal, f64, prev_feat, feat, b, tm_out):
 
 class OnlineStitcher:
     def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True):
-        """canvas: optional (wmin, wmax, hmin, hmax) in HR pixels (e.g. the offline bbox)."""
+                 use_graph=True, grow='never'):
+        """canvas: optional (wmin, wmax, hmin, hmax) in HR pixels (e.g. the offline bbox).
+        grow: 'never' -- the canvas fixed after the first window stays (frames whose mesh leaves it are cropped and COUNTED:
+        `clipped_frames`); 'recapture' -- the canvas grows (and the steady-state graph is captured again) when a mesh comes within
+        half the margin of its edge; `canvas_epoch` counts the growths, `hc` / `wc` / `bbox` change with them."""
+        if grow not in ('never', 'recapture'):
+            raise ValueError("grow must be 'never' or 'recapture'")
+        self.grow = grow
+        self.canvas_epoch = 0
+        self.watch_i = self.watch_f = None          # device-side overflow state of the current canvas (ops.canvas_watch)
+        self._watch_totals = [0, 0, -1]             # frames seen / clipped / first clipped frame on EARLIER canvases
+        self._host_watch = self._host_event = None  # grow='recapture': pinned copy of the state, one push behind
+        self._near_handled = 0
         self.spatial, self.temporal, self.smooth = nets
         self.dev = next(self.spatial.parameters()).device
         self.h, self.w = height, width
@@ -79,11 +97,88 @@ class OnlineStitcher:
         bb = self.bbox.cpu()
         self.hc = int((bb[3] - bb[2]).int())
         self.wc = int((bb[1] - bb[0]).int())
+        self.watch_i, self.watch_f = ops.canvas_watch_state(1, self.dev)
+        self._near_handled = 0
+        self._host_event = None
+
+    # ------------------------------------------------------------------ canvas overflow
+    def _guard(self):
+        """`near` threshold of the watcher in canvas-normalised units: half the margin the canvas was grown by."""
+        return max(0.0, float(self.margin)) * 0.5 / (1.0 + 2.0 * max(0.0, float(self.margin))) * 2.0
+
+    def overflow_report(self):
+        """Synchronises.  -> {'frames_seen', 'clipped_frames', 'first_clipped_frame' (stream frame index, -1 = none), 'near_frames'
+        (current canvas), 'canvas_epoch', 'needed_bbox' (wmin, wmax, hmin, hmax in HR px: the current canvas united with every
+        mesh seen on it)}."""
+        seen, clipped, first = self._watch_totals
+        rep = {'frames_seen': seen, 'clipped_frames': clipped, 'first_clipped_frame': first, 'near_frames': 0,
+               'canvas_epoch': self.canvas_epoch, 'needed_bbox': None}
+        if self.watch_i is None:
+            return rep
+        wi = self.watch_i[0].cpu().tolist()
+        if wi[1] > 0 and first < 0:
+            rep['first_clipped_frame'] = seen + wi[2]
+        rep['frames_seen'] = seen + wi[0]
+        rep['clipped_frames'] = clipped + wi[1]
+        rep['near_frames'] = wi[3]
+        rep['needed_bbox'] = tuple(float(x) for x in self._needed_bbox(self.watch_f[0].cpu()))
+        return rep
+
+    @property
+    def clipped_frames(self):
+        """Frames emitted so far whose mesh reached outside the canvas they were rendered on (synchronises)."""
+        return self.overflow_report()['clipped_frames']
+
+    def _needed_bbox(self, wf):
+        """Running normalised extents [xmin, xmax, ymin, ymax] on the current canvas -> union with the canvas, HR pixels."""
+        bb = self.bbox.cpu()
+        ow, oh = float(bb[1] - bb[0]), float(bb[3] - bb[2])
+        x0 = float(bb[0]) + (min(float(wf[0]), -1.0) + 1.0) * ow / 2.0
+        x1 = float(bb[0]) + (max(float(wf[1]), 1.0) + 1.0) * ow / 2.0
+        y0 = float(bb[2]) + (min(float(wf[2]), -1.0) + 1.0) * oh / 2.0
+        y1 = float(bb[2]) + (max(float(wf[3]), 1.0) + 1.0) * oh / 2.0
+        return x0, x1, y0, y1
+
+    def _regrow(self, wi, wf):
+        """grow='recapture': re-fix the canvas around everything seen so far (+ margin), fresh watcher state, new output buffer,
+        the steady-state graph captured again at the next push."""
+        x0, x1, y0, y1 = self._needed_bbox(wf)
+        gw, gh = self.margin * (x1 - x0), self.margin * (y1 - y0)
+        seen, clipped, first = self._watch_totals
+        if wi[1] > 0 and first < 0:
+            first = seen + wi[2]
+        self._watch_totals = [seen + wi[0], clipped + wi[1], first]
+        self.bbox = torch.tensor([x0 - gw, x1 + gw, y0 - gh, y1 + gh], dtype=torch.float32, device=self.dev)
+        self._set_canvas()
+        self.canvas_epoch += 1
+        if self.static is not None:
+            self.static['out'] = torch.empty((3, self.hc, self.wc), device=self.dev)
+        self.graph = None
+
+    def _poll_growth(self):
+        """Start of a steady-state push (grow='recapture'): look at the watcher state of the push before, copied to pinned memory
+        behind it -- no wait: if the copy has not landed yet the check happens one push later."""
+        if self._host_event is None or not self._host_event.query():
+            return
+        if int(self._host_watch[0][0, 3]) > self._near_handled:
+            # (rare path, synchronises: the device state may be a push ahead of the pinned copy -- take everything seen so far)
+            self._regrow(self.watch_i[0].cpu().tolist(), self.watch_f[0].cpu())
+
+    def _post_watch_copy(self):
+        if self._host_watch is None:
+            self._host_watch = (torch.empty((1, 4), dtype=torch.int32).pin_memory(), torch.empty((1, 4), dtype=torch.float32).pin_memory())
+        self._host_watch[0].copy_(self.watch_i, non_blocking=True)
+        self._host_watch[1].copy_(self.watch_f, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._host_event = ev
 
     @torch.no_grad()
     def _render(self, hr1, hr2, mesh1, mesh2, out=None):
         """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc] (written to `out` if given)."""
-        src = ops.mesh_normalize_views([mesh1, mesh2], self.bbox, self.h, self.w)[0]          # [2,63,2]
+        src4 = ops.mesh_normalize_views([mesh1, mesh2], self.bbox, self.h, self.w)            # [1,2,63,2]
+        ops.canvas_watch(src4, self.watch_i, self.watch_f, self._guard())
+        src = src4[0]
         T = ops.tps_solve_shared(src, self.nrigid)
         return self._render_solved(hr1, hr2, src, T, out)
 
@@ -154,6 +249,8 @@ class OnlineStitcher:
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static
+        if self.grow == 'recapture':
+            self._poll_growth()
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
             # a net was reloaded / moved since the twin trunk was stacked and the graph captured: both hold the OLD
             # weights (the graph by address); rebuild and recapture instead of silently stitching with stale filters
@@ -166,6 +263,7 @@ class OnlineStitcher:
         elif self.graph is None:
             # capture: the eager warm-up runs on a copy of the state so that this push is applied exactly once
             keep = {k: v.clone() for k, v in st.items() if k in self._STATE}
+            keep_w = (self.watch_i.clone(), self.watch_f.clone())       # (the watcher counts every run of the step)
             side = _warmup_stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -173,6 +271,7 @@ class OnlineStitcher:
             torch.cuda.current_stream(self.dev).wait_stream(side)
             for k, v in keep.items():
                 st[k].copy_(v)
+            self.watch_i.copy_(keep_w[0]); self.watch_f.copy_(keep_w[1])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step_static()
@@ -183,6 +282,8 @@ class OnlineStitcher:
         else:
             self.graph.replay()
         self.frames_in += 1
+        if self.grow == 'recapture':
+            self._post_watch_copy()
         return [st['out'].clone()]
 
     @torch.no_grad()
@@ -256,7 +357,13 @@ class MultiOnlineStitcher:
     is independent of its neighbours bit for bit (tests/test_gpu_round4.py)."""
 
     def __init__(self, nets, height, width, streams, canvases=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True):
+                 use_graph=True, grow='never'):
+        """grow: as OnlineStitcher -- 'never' counts the frames whose mesh left their stream's canvas (`clipped_frames`, per
+        stream), 'recapture' re-fixes the canvases of the streams that come near an edge and captures the graph again."""
+        if grow not in ('never', 'recapture'):
+            raise ValueError("grow must be 'never' or 'recapture'")
+        self.grow = grow
+        self._host_watch = self._host_event = None
         self.nets = nets
         self.spatial, self.temporal, self.smooth = nets
         self.dev = next(self.spatial.parameters()).device
@@ -267,7 +374,7 @@ class MultiOnlineStitcher:
             raise ValueError('one canvas per stream')
         self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
         self.single = [OnlineStitcher(nets, height, width, None if canvases is None else canvases[s], margin, warp_mode,
-                                      fusion_mode, use_graph=False) for s in range(self.S)]
+                                      fusion_mode, use_graph=False) for s in range(self.S)]       # (growth is handled here, batched)
         self.use_graph = use_graph
         self.static = None
         self.graph = None
@@ -299,15 +406,73 @@ class MultiOnlineStitcher:
               'ring': torch.stack([o['ring'] for o in one], 1).contiguous(),               # [4,S,7,126]
               'ts_out': torch.empty((2, 4 * S, e), device=d),
               'bboxes': torch.stack([s.bbox for s in self.single], 0).contiguous(),        # [S,4] the streams' fixed canvases
+              'watch_i': torch.cat([s.watch_i for s in self.single], 0).contiguous(),       # [S,4] overflow state (ops.canvas_watch)
+              'watch_f': torch.cat([s.watch_f for s in self.single], 0).contiguous(),
               'out': None, 'out_all': None}
+        self.static = st
+        self._alloc_outputs()
+        for s in self.single:                     # the per-stream buffers are not needed any more (bbox / canvas stay)
+            s.static = None
+
+    def _alloc_outputs(self):
+        st, S, d = self.static, self.S, self.dev
+        st['out_all'] = None
         if len({(s.hc, s.wc) for s in self.single}) == 1:       # equal canvas sizes: one render launch for all streams
             st['out_all'] = torch.empty((S, 3, self.single[0].hc, self.single[0].wc), device=d)
             st['out'] = [st['out_all'][s] for s in range(S)]
         else:
             st['out'] = [torch.empty((3, s.hc, s.wc), device=d) for s in self.single]
-        self.static = st
-        for s in self.single:                     # the per-stream buffers are not needed any more (bbox / canvas stay)
-            s.static = None
+
+    # ------------------------------------------------------------------ canvas overflow (per stream)
+    def overflow_report(self):
+        """Synchronises.  -> one dict per stream (OnlineStitcher.overflow_report)."""
+        if self.static is None:
+            return [one.overflow_report() for one in self.single]
+        wi, wf = self.static['watch_i'].cpu(), self.static['watch_f'].cpu()
+        reps = []
+        for s, one in enumerate(self.single):
+            seen, clipped, first = one._watch_totals
+            w = wi[s].tolist()
+            if w[1] > 0 and first < 0:
+                first = seen + w[2]
+            reps.append({'frames_seen': seen + w[0], 'clipped_frames': clipped + w[1], 'first_clipped_frame': first,
+                         'near_frames': w[3], 'canvas_epoch': one.canvas_epoch,
+                         'needed_bbox': tuple(float(x) for x in one._needed_bbox(wf[s]))})
+        return reps
+
+    @property
+    def clipped_frames(self):
+        """Per stream: frames emitted so far whose mesh reached outside the canvas they were rendered on (synchronises)."""
+        return [r['clipped_frames'] for r in self.overflow_report()]
+
+    def _poll_growth(self):
+        if self._host_event is None or not self._host_event.query():
+            return
+        near = self._host_watch[0][:, 3].tolist()
+        grown = [s for s, one in enumerate(self.single) if near[s] > 0]
+        if not grown:
+            return
+        st = self.static
+        wi, wf = st['watch_i'].cpu(), st['watch_f'].cpu()              # (rare path: synchronises)
+        fresh_i, fresh_f = ops.canvas_watch_state(1, self.dev)
+        for s in grown:
+            one = self.single[s]
+            one._regrow(wi[s].tolist(), wf[s])
+            st['bboxes'][s].copy_(one.bbox)
+            st['watch_i'][s].copy_(fresh_i[0]); st['watch_f'][s].copy_(fresh_f[0])
+        self._alloc_outputs()
+        self.graph = None
+        self._host_event = None
+
+    def _post_watch_copy(self):
+        st = self.static
+        if self._host_watch is None:
+            self._host_watch = (torch.empty((self.S, 4), dtype=torch.int32).pin_memory(), torch.empty((self.S, 4), dtype=torch.float32).pin_memory())
+        self._host_watch[0].copy_(st['watch_i'], non_blocking=True)
+        self._host_watch[1].copy_(st['watch_f'], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._host_event = ev
 
     def _step_static(self):
         st, S, e = self.static, self.S, 126
@@ -337,6 +502,7 @@ class MultiOnlineStitcher:
         # every stream's newest smoothed mesh on its own canvas: one normalisation launch per view and ONE batched TPS solve for
         # the 2 S splines (a solve is latency-bound, ~48 us whether it holds 2 systems or 16), then the render stream by stream
         src = ops.mesh_normalize_views_boxes([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w)     # [S,2,63,2]
+        ops.canvas_watch(src, st['watch_i'], st['watch_f'], self.single[0]._guard())
         T = ops.tps_solve_shared(src.view(2 * S, 63, 2), self.single[0].nrigid).view(S, 2, 2, 66)
         if st['out_all'] is not None:
             # all streams render onto canvases of ONE size (e.g. the caller fixed them): the S current frames are a clip
@@ -352,6 +518,8 @@ class MultiOnlineStitcher:
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static
+        if self.grow == 'recapture':
+            self._poll_growth()
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
             self.trunk_pair = None           # a net was reloaded / moved: restack the twin trunk and recapture
             self.graph = None
@@ -359,7 +527,7 @@ class MultiOnlineStitcher:
         if not self.use_graph:
             self._step_static()
         elif self.graph is None:
-            keep = {k: st[k].clone() for k in self._STATE}
+            keep = {k: st[k].clone() for k in self._STATE + ('watch_i', 'watch_f')}
             side = _warmup_stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -377,6 +545,8 @@ class MultiOnlineStitcher:
         else:
             self.graph.replay()
         self.frames_in += 1
+        if self.grow == 'recapture':
+            self._post_watch_copy()
         return [[o.clone()] for o in st['out']]
 
     @torch.no_grad()

@@ -864,6 +864,21 @@ def mesh_normalize_views(meshes, bbox, img_h, img_w):
     return out
 
 
+def canvas_watch_state(streams, device):
+    """Fresh (watch_i [S,4] int32, watch_f [S,4] fp32) for ops.canvas_watch."""
+    wi = torch.tensor([[0, 0, -1, 0]] * streams, dtype=torch.int32, device=device)
+    inf = float('inf')
+    wf = torch.tensor([[inf, -inf, inf, -inf]] * streams, dtype=torch.float32, device=device)
+    return wi, wf
+
+
+def canvas_watch(src, watch_i, watch_f, guard):
+    """src [S,V,63,2] canvas-normalised control points of one push -> updates the streams' overflow state (ss_canvas_watch)."""
+    s, v = src.shape[0], src.shape[1]
+    assert src.is_contiguous() and tuple(watch_i.shape) == (s, 4) and tuple(watch_f.shape) == (s, 4)
+    H.call('ss_canvas_watch', H.dptr(src), s, v, float(guard), H.dptr(watch_i, dtype=torch.int32), H.dptr(watch_f), H.stream())
+
+
 def mesh_normalize_views_boxes(meshes, frame_stride, bboxes, img_h, img_w):
     """Per-frame canvases: meshes = list of V tensors whose frame f starts `frame_stride` floats after frame f - 1 (the tensor
     handed in starts at frame 0's mesh); bboxes [n,4] -> [n,V,63,2]."""
