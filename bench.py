@@ -630,13 +630,16 @@ def main():
         dev = torch.device('cpu')
     else:
         assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+        local_rank = local
         if args.share_device:
             local = 0
         torch.cuda.set_device(local)
         dev = torch.device('cuda', local)
-        # this rank's launch thread, copy threads and pinned buffers on the GPU's NUMA node (before anything is pinned)
+        # this rank's launch thread, copy threads and pinned buffers on the GPU's NUMA node (before anything is pinned); ranks that
+        # share one device split that node's CPUs into disjoint slices
         from stabstitch2_amd import hostbind
-        host = hostbind.bind_to_gpu(dev, local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+        host = hostbind.bind_to_gpu(dev, local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)),
+                                    share=world if args.share_device else 0)
     if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -761,7 +764,9 @@ def main():
     rec = torch.tensor([float(args.frames * args.steps), dt, float(hc), float(wc), float(rank), float(local),
                         float(-1 if not host or host.get('numa_node') is None else host['numa_node']),
                         float(0 if not host or not host.get('cpus_bound') else host['cpus_bound']),
-                        float(int(vis.split(',')[0]) if vis.split(',')[0].strip().isdigit() else -1)], dtype=torch.float64)
+                        float(int(vis.split(',')[0]) if vis.split(',')[0].strip().isdigit() else -1),
+                        float(-1 if not host or host.get('cpu_first') is None else host['cpu_first']),
+                        float(-1 if not host or host.get('cpu_last') is None else host['cpu_last'])], dtype=torch.float64)
     # the only collective: result gather (RCCL takes the record from device memory, gloo from the host)
     allrec = ssdist.gather_records(rec, dist, dev if args.backend == 'nccl' else None, args.force_collective)
     if rank != 0:
@@ -848,6 +853,7 @@ def main():
         result['per_rank_numa_node'] = [int(x) for x in allrec[:, 6]]
         result['per_rank_cpus_bound'] = [int(x) for x in allrec[:, 7]]
         result['per_rank_first_visible_device'] = [int(x) for x in allrec[:, 8]]
+        result['per_rank_cpu_range'] = [[int(a), int(b)] for a, b in zip(allrec[:, 9], allrec[:, 10])]
         if args.share_device:
             result['share_device'] = True
     result['host'] = {'placement': host, 'HIP_VISIBLE_DEVICES': vis or None, 'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),

@@ -840,7 +840,8 @@ extern "C" long long ss_linear_clip_workspace_floats(int frames, int views, int 
     if (frames <= 0 || (views != 2 && views != 3) || hc <= 1 || wc <= 1) return 0;
     const long long ohw = (long long)hc * wc, p = views - 1;
     const long long tiles = (long long)ss_cdiv(wc, 64) * ss_cdiv(hc, 8);
-    return (long long)frames * (views * 4 * ohw + (views == 3 ? 3 * ohw : 0) + p * 32 + tiles * 4 * p * LBC_PW);
+    // (+ 1: the 64-bit scalars block starts on an even float behind W / F whatever the parity of frames * hc * wc)
+    return (long long)frames * (views * 4 * ohw + (views == 3 ? 3 * ohw : 0) + p * 32 + tiles * 4 * p * LBC_PW) + 1;
 }
 
 // sum of the lane indices whose bit is set (scalar unit: six popcounts)
@@ -1246,7 +1247,10 @@ static int render_linear_clip_launch(const void* const* views_base, const float*
     const int P = views - 1, nbx = ss_cdiv(wc, 64), tiles = nbx * ss_cdiv(hc, 8);
     float* W = ws;
     float* F = W + (long long)frames * views * 4 * ohw;
-    unsigned long long* scalars = reinterpret_cast<unsigned long long*>(F + (views == 3 ? (long long)frames * 3 * ohw : 0));
+    long long sc_off = (long long)frames * views * 4 * ohw + (views == 3 ? (long long)frames * 3 * ohw : 0);
+    sc_off += sc_off & 1;                                  // 8-byte alignment of the u64 block by construction (ws is 8-byte aligned)
+    if (reinterpret_cast<unsigned long long>(ws) & 7ull) return SS_ERR_ARG;
+    unsigned long long* scalars = reinterpret_cast<unsigned long long*>(ws + sc_off);
     unsigned* partials = reinterpret_cast<unsigned*>(scalars + (long long)frames * P * 16);
     const long long img_fs = u8 ? 3ll * h * w : 12ll * h * w;
     const dim3 ga(tiles, frames);

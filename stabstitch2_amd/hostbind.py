@@ -5,7 +5,10 @@ The reference is one process on one GPU and never thinks about this (test_online
 runs on a 2-socket host (MI355X boxes: 2 x 64 cores, 4 GPUs per socket): a pinned buffer that the kernel placed on the far
 socket is reached by the GPU's DMA engines through the inter-socket fabric, and 8 ranks whose Python launch loops float over
 256 logical CPUs migrate between sockets.  `bind_to_gpu(device)` is called once per process BEFORE the pinned buffers are
-allocated (bench.py, HostClipRunner): CPU affinity = the CPUs of the GPU's node, memory policy = prefer that node.
+allocated -- by bench.py for every rank, and by `pipeline.HostClipRunner` (hence `LongVideoStitcher`) when it is constructed, unless
+the process was bound before: CPU affinity of the CALLING THREAD (and of the threads it starts afterwards: torch's copy threads,
+the runner's workers; threads that already run keep theirs) = the CPUs of the GPU's node, memory policy = prefer that node.
+Ranks that share one device (`bench.py --share-device`) or are told to (`SS_NUMA_SLICE=1`) take disjoint slices of the node's CPUs.
 
 Everything is read from sysfs; where the platform does not expose NUMA (a single-node VM, `numa_node` = -1) the call reports
 that and changes nothing.  SS_NUMA_BIND=0 disables binding; SS_NUMA_NODE=k forces node k.
@@ -13,11 +16,14 @@ that and changes nothing.  SS_NUMA_BIND=0 disables binding; SS_NUMA_NODE=k force
 import ctypes
 import glob
 import os
+import platform
 
 import torch
 
 MPOL_DEFAULT, MPOL_PREFERRED, MPOL_BIND = 0, 1, 2
-_SYS_SET_MEMPOLICY = 238        # x86_64
+# set_mempolicy(2) has no libc wrapper outside libnuma: raw syscall number per architecture (238 is migrate_pages on aarch64)
+_SYS_SET_MEMPOLICY = {'x86_64': 238, 'aarch64': 237}.get(platform.machine())
+ENOSYS = 38
 
 
 def _read(path):
@@ -87,6 +93,8 @@ def gpu_numa_node(device):
 def set_mempolicy(mode, node=None):
     """set_mempolicy(2) of the calling thread through libc's syscall(); -> 0 or -errno.  Pages this thread faults in
     afterwards (the driver pins a hipHostMalloc'ed buffer in the caller's context) come from `node`."""
+    if _SYS_SET_MEMPOLICY is None:
+        return -ENOSYS                   # unknown architecture: leave the memory policy alone rather than guess a syscall number
     libc = ctypes.CDLL(None, use_errno=True)
     if node is None or mode == MPOL_DEFAULT:
         r = libc.syscall(_SYS_SET_MEMPOLICY, MPOL_DEFAULT, None, 0)
@@ -102,12 +110,15 @@ def set_mempolicy(mode, node=None):
 _bound = {}
 
 
-def bind_to_gpu(device, local_rank=None, local_world=None):
-    """Pin this process (all its current threads' future children included) to the CPUs of `device`'s NUMA node and prefer
-    that node for memory.  When `local_world` ranks share the node's CPUs each takes its slice of them round-robin by
-    `local_rank` only if SS_NUMA_SLICE=1 (default: the whole node -- the launch loop needs one core, torch's copy threads
-    the rest).  -> report dict (also kept for `report()`): numa_node, cpus bound, nodes seen, why nothing was done."""
-    rep = {'requested': True, 'numa_node': None, 'cpus_bound': None, 'nodes': None, 'pci_bus_id': gpu_pci_bus_id(device)}
+def bind_to_gpu(device, local_rank=None, local_world=None, share=0):
+    """Pin the calling thread (and the threads it starts from now on) to the CPUs of `device`'s NUMA node and prefer that node
+    for memory.  Default: the whole node -- the launch loop needs one core, torch's copy threads the rest.  Disjoint slices
+    instead when `share` > 1 ranks drive THIS device (each takes slice `local_rank % share` of `share`), or, with
+    SS_NUMA_SLICE=1, when `local_world` ranks are spread over the host's nodes (slice by `local_rank`).
+    -> report dict (also kept for `report()`): numa_node, cpus_bound (count), cpu_first / cpu_last, nodes seen, why nothing was
+    done."""
+    rep = {'requested': True, 'numa_node': None, 'cpus_bound': None, 'cpu_first': None, 'cpu_last': None, 'nodes': None,
+           'pci_bus_id': gpu_pci_bus_id(device)}
     if os.environ.get('SS_NUMA_BIND', '1') == '0':
         rep['skipped'] = 'SS_NUMA_BIND=0'
         _bound[str(device)] = rep
@@ -126,14 +137,20 @@ def bind_to_gpu(device, local_rank=None, local_world=None):
     except OSError:
         allowed = set(nodes[node])
     cpus = sorted(set(nodes[node]) & set(allowed)) or sorted(nodes[node])
-    if os.environ.get('SS_NUMA_SLICE', '0') == '1' and local_world and local_rank is not None:
+    peers = 1
+    if share and share > 1 and local_rank is not None:
+        peers = int(share)
+    elif os.environ.get('SS_NUMA_SLICE', '0') == '1' and local_world and local_rank is not None:
         peers = max(1, local_world // max(len(nodes), 1))
+    if peers > 1:
         k = local_rank % peers
         per = max(1, len(cpus) // peers)
         cpus = cpus[k * per:(k + 1) * per] or cpus
+        rep['slice'] = '%d of %d' % (k, peers)
     try:
         os.sched_setaffinity(0, cpus)
         rep['cpus_bound'] = len(cpus)
+        rep['cpu_first'], rep['cpu_last'] = cpus[0], cpus[-1]
     except OSError as e:
         rep['affinity_error'] = str(e)
     r = set_mempolicy(MPOL_PREFERRED, node)

@@ -726,11 +726,17 @@ class HostClipRunner:
         # them from the caching allocator per clip meant blocks of three streams' pools, released only when the recorded
         # events had passed: now and then a clip needed a fresh 88-130 MB hipMalloc inside a run (10-20 ms each -- the
         # 3070-3570 frames/s spread of the bench's run totals at an unchanged steady state).
-        self._in, self._in_free, self._in_k = [], [], 0
+        self._in, self._in_free, self._in_k, self._in_gen = [], [], 0, 0
         self._out, self._out_done, self._out_k = [], [], 0
+        # host placement (hostbind): the pinned result slots and torch's copy threads belong on the GPU's NUMA node.  Done here,
+        # before anything is pinned, unless the process bound itself already (bench.py does, per rank) or SS_NUMA_BIND=0.
+        from . import hostbind
+        if self.dev.type == 'cuda' and hostbind.report(self.dev) is None:
+            hostbind.bind_to_gpu(self.dev)
 
     class _Staged(list):
         slot = None
+        gen = 0
 
     def _in_slot(self, shapes):
         nbuf = self.prefetch + 2
@@ -744,12 +750,20 @@ class HostClipRunner:
             self._in = [[torch.empty((cap,) + tuple(sh[1:]), dtype=torch.uint8, device=self.dev) for sh in shapes]
                         for _ in range(nbuf)]
             self._in_free = [None] * nbuf
+            self._in_gen += 1                            # clips already staged in the OLD ring keep it alive (see `consumed`)
         j = self._in_k % len(self._in)
         self._in_k += 1
         return j
 
     def consumed(self, d, ev):
-        """The compute that reads the uploaded clip `d` has been enqueued; `ev` (recorded behind it) frees d's staging slot."""
+        """The compute that reads the uploaded clip `d` has been enqueued; `ev` (recorded behind it) frees d's staging slot.
+        A clip staged in a ring that has been replaced since (a longer clip or another geometry arrived while it waited in the
+        prefetch queue) has no slot in the new ring: its buffers are handed back to the allocator, which must not reuse them
+        before the compute stream's readers are done -- record_stream, not the new ring's events."""
+        if d.gen != self._in_gen:
+            for t in d:
+                t.record_stream(self.comp)
+            return
         self._in_free[d.slot] = ev
 
     def out_buffer(self, shape):
@@ -803,6 +817,7 @@ class HostClipRunner:
                 self.up.wait_event(self._in_free[j])
             d = self._Staged(buf[:t.shape[0]] for buf, t in zip(self._in[j], src))
             d.slot = j
+            d.gen = self._in_gen
             self._timed_copy('h2d', self.up, sum(t.numel() * t.element_size() for t in src),
                              lambda: [dst.copy_(t, non_blocking=True) for dst, t in zip(d, src)])
             ev = torch.cuda.Event()

@@ -314,3 +314,33 @@ def test_multi_stream_canvas_overflow(dev, hip_nets, clip16):
     assert all(g[1] > s[1] + 20 for g, s in zip(mg.canvas_sizes, sizes0)), (mg.canvas_sizes, sizes0)
     assert all(tuple(outs[-1][s][0].shape) == (3,) + tuple(mg.canvas_sizes[s]) for s in range(2))
     assert all(bool(torch.isfinite(outs[-1][s][0]).all()) for s in range(2))
+
+
+def test_bench_eight_ranks_share_one_gpu():
+    """`bench.py --gpus 8 --backend gloo --share-device` -- the eight launch loops, clip seeds, host placement
+    and the gather of configs[3] on ONE host and ONE device (RCCL refuses eight ranks on a device; its one-rank all_gather is
+    test_rccl_one_rank_all_gather): 8 ranks, 8 distinct seeds, the GPU's NUMA node split into 8 DISJOINT CPU slices (hostbind),
+    a whole-job value = all ranks' frames / slowest rank."""
+    import json
+    env = dict(os.environ)
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--share-device',
+                        '--steps', '2', '--warmup', '1', '--frames', '8', '--no-cpu-baseline', '--no-other-configs'],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['ranks'] == 8 and d['backend'] == 'gloo' and d['share_device'] is True
+    assert d['clip_seeds'] == list(range(8)) and d['per_rank_device'] == [0] * 8
+    assert len(d['per_rank_seconds']) == 8 and all(s > 0 for s in d['per_rank_seconds'])
+    assert abs(d['value'] - 8 * 8 * 2 / max(d['per_rank_seconds'])) < 1e-2 * d['value']
+    assert d['scaling'] == 'weak' and 'x 8 GPUs = configs[3]' in d['config']['workload']
+    assert d['host']['GPU_MAX_HW_QUEUES'] == '16'                       # every rank's runtime has its own 16 hardware queues
+    ranges = d['per_rank_cpu_range']
+    if all(a >= 0 for a, _ in ranges):                                   # (hosts without NUMA information bind nothing: -1)
+        assert len(set(d['per_rank_numa_node'])) == 1                   # one device -> one node ...
+        spans = sorted(ranges)
+        assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), ranges      # ... split into disjoint CPU slices
+        assert all(c >= 1 for c in d['per_rank_cpus_bound'])
+    print('\n[8 ranks on one GPU] %.1f frames/s aggregate, per-rank seconds %s, cpu slices %s' % (d['value'], d['per_rank_seconds'], ranges))

@@ -265,7 +265,7 @@ def test_package_import_raises_the_hw_queue_budget():
 def test_round4_entry_points_validate_arguments(built_lib):
     """Argument validation of the round-4 entry points happens before any device work."""
     L = built_lib
-    assert L.ss_linear_clip_workspace_floats(32, 2, 740, 1882) == 32 * (2 * 4 * 740 * 1882 + 32 + 30 * 93 * 4 * 8)
+    assert L.ss_linear_clip_workspace_floats(32, 2, 740, 1882) == 32 * (2 * 4 * 740 * 1882 + 32 + 30 * 93 * 4 * 8) + 1
     assert L.ss_linear_clip_workspace_floats(1, 4, 100, 100) == 0
     assert L.ss_render_linear_clip(None, None, None, None, None, 1, 2, 8, 8, 32, 32, 0, None, None) == -1
     assert L.ss_linear_grouped(None, 0, None, None, None, 4, 1, 8, 8, 0, None) == -1
