@@ -64,22 +64,39 @@ struct W43P {
 #endif
 
 namespace {
-constexpr int X_TXU = 15;                    // tiles per tile row that carry pixels (slot 15 idles)
-constexpr int X_BH = 8, X_BW = 4 * X_TXU;    // output pixels of a block
-constexpr int X_RW = X_BW + 2;               // raw columns (62)
-// V1 (row-transformed input of one chunk) in LDS: [channel PAIR 8][tile row 2][transform row 6][X_ROWP], the two channels of a pair
-// interleaved so that both transforms run on v_pk_*_f32 over aligned register pairs.  A row holds its 62 columns as 16-byte entries
-// (x, x + 1) x (c0, c1): entries of x = 0, 1 (mod 4) -- "A", dwords 0..67 -- and of x = 2, 3 (mod 4) -- "B", from dword 72 (tile row 0)
-// / 76 (tile row 1).  Tile tx's window x = 4 tx .. 4 tx + 5 is A[tx], B[tx], A[tx + 1]: three 16-byte reads, a 16-lane group reads 64
-// consecutive dwords each time (conflict-free).  Stage-1 writes (8 bytes per lane: 8 columns x 4 channel quads per half wave) hit all
-// 64 banks once: quads are 2 planes = 16 banks apart (X_PL = 8 mod 32), B sits 8 banks behind A for the columns a half wave covers
-// (they start at x = 0 mod 8 in tile row 0, at x = 2 mod 8 in tile row 1: hence the two B offsets).
-constexpr int X_ROWP = 140;                  // dwords of a V1 row
-constexpr int X_BOFF0 = 72, X_BOFF1 = 76;    // B entries of tile row 0 / 1
-constexpr int X_PL = 12 * X_ROWP + 24;       // channel-pair plane (1704 = 8 mod 32)
-constexpr int X_V1F = 8 * X_PL;              // dwords of one V1 buffer
+// Two block geometries of the 32 tile slots a workgroup's MFMA rows hold (template parameter GEO):
+//   GEO 0: 2 tile rows x 16 slots (15 carry pixels) = 8 x 60 output pixels -- the 60 / 120-wide maps of layer1 / layer2;
+//   GEO 1: 4 tile rows x 8 slots = 16 x 32 output pixels, for maps up to 31 columns wide (layer3's 23 x 30: one block column; the
+//          512 stage-1 threads cover raw columns -1 .. 30, the window's last two columns lie past every such map and are zeros
+//          written once) -- on a 30-wide map GEO 0 would leave half of every tile row idle.
+template <int GEO> struct XG;
+// V1 (row-transformed input of one chunk) in LDS: [channel PAIR 8][tile row][transform row 6][ROWP], the two channels of a pair
+// interleaved so that both transforms run on v_pk_*_f32 over aligned register pairs.  A row holds its columns as 16-byte entries
+// (x, x + 1) x (c0, c1): entries of x = 0, 1 (mod 4) -- "A", from dword 0 -- and of x = 2, 3 (mod 4) -- "B", from dword BOFF.
+// Tile tx's window x = 4 tx .. 4 tx + 5 is A[tx], B[tx], A[tx + 1]: three 16-byte reads; a 16-lane group of a read (GEO 0: 16 tiles of
+// a tile row; GEO 1: 8 tiles of two tile rows, 6 ROWP = 32 (mod 64) dwords apart) covers 64 consecutive banks -- conflict-free.
+// GEO 0 stage-1 writes (8 bytes per lane: 8 columns x 4 channel quads per half wave) hit all 64 banks once: quads are 2 planes =
+// 16 banks apart (PL = 8 mod 32), B sits 8 banks behind A for the columns a half wave covers (they start at x = 0 mod 8 in tile
+// row 0, at x = 2 mod 8 in tile row 1: hence the two B offsets).
+template <> struct XG<0> {
+    static constexpr int TYN = 2, TXS = 16, TXU = 15;           // tile rows, tile slots per row, slots that carry pixels
+    static constexpr int BH = 4 * TYN, BW = 4 * TXU;            // output pixels of a block
+    static constexpr int RW = BW + 2;                           // raw columns staged by threads (62; threads 496..511 idle)
+    static constexpr int ROWP = 140;
+    static constexpr int PL = 6 * TYN * ROWP + 24;              // channel-pair plane (1704 = 8 mod 32)
+    __device__ static constexpr int boff(int ty) { return ty ? 76 : 72; }
+};
+template <> struct XG<1> {
+    static constexpr int TYN = 4, TXS = 8, TXU = 8;
+    static constexpr int BH = 4 * TYN, BW = 4 * TXU;            // 16 x 32
+    static constexpr int RW = 32;                               // raw columns -1 .. 30 of the block (4 tile rows x 32 x 4 quads = 512 items)
+    static constexpr int ROWP = 80;                             // A: 9 entries (36 dwords), B from 40: 8 entries; 6 * 80 = 32 (mod 64)
+    static constexpr int PL = 6 * TYN * ROWP + 8;               // 1928 = 8 (mod 32)
+    __device__ static constexpr int boff(int) { return 40; }
+};
+constexpr int X_V1F_MAX = 8 * XG<0>::PL > 8 * XG<1>::PL ? 8 * XG<0>::PL : 8 * XG<1>::PL;
 constexpr int X_DUMPF = 36 * 32 * 32;        // epilogue stage: [position][tile][cout of one 32-channel block]
-constexpr int X_SMEMF = X_DUMPF > 2 * X_V1F ? X_DUMPF : 2 * X_V1F;
+constexpr int X_SMEMF = X_DUMPF > 2 * X_V1F_MAX ? X_DUMPF : 2 * X_V1F_MAX;
 constexpr unsigned X_UPOS = 2048u;           // bytes of one packed position (2 halves x 64 lanes x 16 B)
 constexpr unsigned X_UCHUNK = 36u * X_UPOS;  // bytes per (32-cout block, chunk)
 }
@@ -123,9 +140,11 @@ __device__ __forceinline__ x_f32x2 x_pk_sub(x_f32x2 a, x_f32x2 b) {             
 // loads, row transform, LDS writes), 4 no stage-2 arithmetic, 8 no LDS reads, 16 no barrier
 // ONE: cin == 16, the single chunk is the last one (its own instantiation: with the K loop's zero-trip case in the same code hipcc
 // kept the prologue's prefetches alive on a second path around the loop and spilled 47 registers to scratch for it)
-template <bool RES, int ABL = 0, bool ONE = false>
+template <bool RES, int ABL = 0, bool ONE = false, int GEO = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    using Gm = XG<GEO>;
+    constexpr int X_ROWP = Gm::ROWP, X_PL = Gm::PL, X_V1F = 8 * Gm::PL, X_RW = Gm::RW, X_TXU = Gm::TXU;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     const int bx = (int)(mb - t1 * p.nbx);
     const unsigned img = ss_div32(t1, p.divBy);
     const int by = (int)(t1 - img * p.nby);
-    const int oy0 = by * X_BH, ox0 = bx * X_BW;
+    const int oy0 = by * Gm::BH, ox0 = bx * Gm::BW;
     const int grp = blockIdx.z;
 
     const __amdgpu_buffer_rsrc_t rin = x_rsrc(p.in + (long long)grp * p.in_gs, p.in_bytes);
@@ -162,9 +181,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     // loads are out of range (zeros) and their writes land in the two pad columns of V1
     const int s1_q = tid & 3;
     const int s1_pix = tid >> 2;
-    const bool s1_real = s1_pix < 2 * X_RW;
-    const int s1_ty = s1_real ? (s1_pix >= X_RW ? 1 : 0) : ((s1_pix >> 1) & 1);
-    const int s1_xx = s1_real ? s1_pix - s1_ty * X_RW : X_RW + (s1_pix & 1);
+    const bool s1_real = GEO == 1 || s1_pix < 2 * X_RW;
+    const int s1_ty = GEO == 1 ? (s1_pix >> 5) : (s1_real ? (s1_pix >= X_RW ? 1 : 0) : ((s1_pix >> 1) & 1));
+    const int s1_xx = GEO == 1 ? (s1_pix & 31) : (s1_real ? s1_pix - s1_ty * X_RW : X_RW + (s1_pix & 1));
     const int s1_iy0 = oy0 - 1 + 4 * s1_ty, s1_ix = ox0 - 1 + s1_xx;
     const unsigned rowstep = (unsigned)p.W * (unsigned)p.C * 4u;
     const unsigned rbase = ((((unsigned)img * p.H + (unsigned)s1_iy0) * p.W + (unsigned)s1_ix) * (unsigned)p.C + 4u * s1_q) * 4u;
@@ -173,14 +192,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
         rmask |= (s1_real && (unsigned)(s1_iy0 + r) < (unsigned)p.H && (unsigned)s1_ix < (unsigned)p.W) ? 0 : (1 << r);
-    const int s1_lds = (2 * s1_q) * X_PL + (6 * s1_ty) * X_ROWP + ((s1_xx & 2) ? (s1_ty ? X_BOFF1 : X_BOFF0) : 0) + (s1_xx >> 2) * 4 + (s1_xx & 1) * 2;
+    const int s1_lds = (2 * s1_q) * X_PL + (6 * s1_ty) * X_ROWP + ((s1_xx & 2) ? Gm::boff(s1_ty) : 0) + (s1_xx >> 2) * 4 + (s1_xx & 1) * 2;
+    if constexpr (GEO == 1) {
+        // window columns 32, 33 (image columns 31, 32: past every map this geometry takes) = entry A[8] of every V1 row of both
+        // buffers: zeros, written once -- 2 buffers x 8 pairs x 4 tile rows x 6 rows = 384 entries (made visible by the prologue's barrier)
+        if (tid < 384) {
+            const int bufi = tid / 192, r = tid - bufi * 192;          // r = (pair, tile row, row)
+            *reinterpret_cast<x_f32x4*>(smem + bufi * X_V1F + (r / 24) * X_PL + (r % 24) * X_ROWP + 4 * Gm::TXS) = (x_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     // ---- this lane in the GEMMs (v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5]): tile lane & 31, channels
     // 8 kh .. 8 kh + 7 of the chunk = pairs 4 kh .. 4 kh + 3
     const int kh = lane >> 5;
     const int m_tile = lane & 31;
-    const int t_srcA = (4 * kh) * X_PL + ((m_tile >> 4) * 6 + 3 * pa) * X_ROWP + 4 * (m_tile & 15);
-    const int t_srcB = t_srcA + ((m_tile >> 4) ? X_BOFF1 : X_BOFF0);
+    const int m_ty = GEO == 1 ? (m_tile >> 3) : (m_tile >> 4), m_tx = GEO == 1 ? (m_tile & 7) : (m_tile & 15);
+    const int t_srcA = (4 * kh) * X_PL + (m_ty * 6 + 3 * pa) * X_ROWP + 4 * m_tx;
+    const int t_srcB = t_srcA + Gm::boff(m_ty);
     const x_f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f};
 
     const unsigned u_lane = (unsigned)lane * 16u;
@@ -294,16 +322,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
         kh_e = lane_e >> 5;
         // pixel offsets: row part per a -- 0xFFFF0000 (past every buffer the launcher admits) for rows outside the image -- plus
         // y * pixel pitch, or-ed with the column's out-of-range mask (columns past the image, the idle tile slot)
-        const int oxb = ox0 + 4 * tx;
+        // tile `tx` of a phase's 16: GEO 0 -- column tx of tile row `phase`; GEO 1 -- column tx & 7 of tile row 2 phase + (tx >> 3)
+        const int txc = GEO == 1 ? (tx & 7) : tx;
+        const int oxb = ox0 + 4 * txc;
         pixb = (unsigned)p.out_cs * 4u;
         rowb = pixb * (unsigned)p.W;
         base = ((((unsigned)img * p.H + oy0) * p.W + oxb) * (unsigned)p.out_cs + cbk * 64 + 2 * e_n) * 4u;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) cinv[y] = (tx < X_TXU && oxb + y < p.W) ? 0u : 0xFFFFFFFFu;
+        for (int y = 0; y < 4; ++y) cinv[y] = (txc < X_TXU && oxb + y < p.W) ? 0u : 0xFFFFFFFFu;
     };
     auto row_offsets = [&](int ty) {
+        const int trow = GEO == 1 ? 2 * ty + (tx >> 3) : ty;        // tile row of this thread's tile in phase ty
 #pragma unroll
-        for (int a = 0; a < 4; ++a) roff[a] = oy0 + 4 * ty + a < p.H ? base + (unsigned)(4 * ty + a) * rowb : 0xFFFF0000u;
+        for (int a = 0; a < 4; ++a) roff[a] = oy0 + 4 * trow + a < p.H ? base + (unsigned)(4 * trow + a) * rowb : 0xFFFF0000u;
     };
     // residual of output column y of the current phase's rows (roff)
     auto res_col = [&](int y) {
@@ -548,21 +579,28 @@ extern "C" int ss_wino43_pack(const float* wgt, float* packed, int cout, int cin
     return ss_launch_status();
 }
 
+// Block geometry of a launch: the 16 x 32 blocks (GEO 1) for maps up to 31 columns wide, else 8 x 60 (GEO 0)
+static inline int x_geo(int wo) { return wo <= 31 ? 1 : 0; }
+
 // The engine's dispatch rule for this kernel (host/ops.py applies it; bench.py counts executed flops with it): geometry the kernel
-// takes at all, then -- one workgroup per CU -- at least `min_wgs` workgroups (default 512: two rounds of the chip), >= 85 % of the
-// 8 x 60 tile slots used, K long enough to carry the un-overlapped prologue / epilogue (cin >= 64; tools/bench_wino43.py).
-// images = images per group, groups = launch groups.  min_wgs / min_cin / min_fill_pct <= 0: the defaults (512 / 64 / 85); all
-// three at 1 = "wherever the kernel runs at all".
+// takes at all, then -- one workgroup per CU -- at least `min_wgs` workgroups (default 512: two rounds of the chip), enough of the
+// block's tile slots on real pixels (default: 85 % of the 8 x 60 blocks; 60 % of the 16 x 32 blocks of narrow maps, where the
+// alternative -- F(2x2,3x3) -- spends 1.78x the MFMA flops: layer3's 23 x 30 maps fill 67 %), K long enough to carry the
+// un-overlapped prologue / epilogue (cin >= 64; tools/bench_wino43.py).
+// images = images per group, groups = launch groups.  min_wgs / min_cin / min_fill_pct <= 0: the defaults; all three at 1 =
+// "wherever the kernel runs at all".
 extern "C" int ss_conv_uses_wino43(int kt, int kh, int kw, int stride, int cin, int cout, int ho, int wo, int images, int groups,
                                    int min_wgs, int min_cin, int min_fill_pct) {
     if (kt != 1 || kh != 3 || kw != 3 || stride != 1 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 63)) return 0;
     if (ho <= 0 || wo <= 0 || images <= 0 || groups <= 0) return 0;
     if ((long long)images * ho * wo * (cin > cout ? cin : cout) * 4 >= 0xFFFF0000ll) return 0;   // the kernel's 32-bit buffer offsets
+    const int geo = x_geo(wo);
+    const int bh = geo ? XG<1>::BH : XG<0>::BH, bw = geo ? XG<1>::BW : XG<0>::BW;
     if (min_wgs <= 0) min_wgs = 512;
     if (min_cin <= 0) min_cin = 64;
-    if (min_fill_pct <= 0) min_fill_pct = 85;
-    const long long nby = ss_cdiv(ho, X_BH), nbx = ss_cdiv(wo, X_BW);
-    const double eff = (double)ho * wo / (double)(nby * X_BH * nbx * X_BW);
+    if (min_fill_pct <= 0) min_fill_pct = geo ? 60 : 85;
+    const long long nby = ss_cdiv(ho, bh), nbx = ss_cdiv(wo, bw);
+    const double eff = (double)ho * wo / (double)(nby * bh * nbx * bw);
     return eff * 100.0 >= (double)min_fill_pct && (long long)images * nby * nbx * (cout / 64) * groups >= min_wgs && cin >= min_cin;
 }
 
@@ -586,8 +624,9 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     p.N = n; p.H = h; p.W = w; p.C = cin; p.Co = cout;
     p.nchunk = cin / 16;
     p.relu = relu; p.out_cs = out_cs;
-    p.nbx = (unsigned)ss_cdiv(w, X_BW);
-    p.nby = (unsigned)ss_cdiv(h, X_BH);
+    const int geo = x_geo(w);
+    p.nbx = (unsigned)ss_cdiv(w, geo ? XG<1>::BW : XG<0>::BW);
+    p.nby = (unsigned)ss_cdiv(h, geo ? XG<1>::BH : XG<0>::BH);
     p.ncb = (unsigned)(cout / 64);
     p.divBx = ss_div32_make(p.nbx);
     p.divBy = ss_div32_make(p.nby);
@@ -615,7 +654,11 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
             if (!ok) (void)hipGetLastError();
             attr_state[dev].store(ok ? 2 : 3, std::memory_order_release);
         }
@@ -625,7 +668,7 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
 #ifdef SS_TUNING
-    if (g_w43_ablate && !res) {         // tools/diag_wino43.py <layers> <ablation masks>
+    if (g_w43_ablate && !res && !geo) {         // tools/diag_wino43.py <layers> <ablation masks>
         switch (g_w43_ablate) {
 #define X_ABL_CASE(m) case m: (void)hipFuncSetAttribute((const void*)conv_wino43_kernel<false, m>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((conv_wino43_kernel<false, m>), g, dim3(512), lds, st, p); return ss_launch_status();
@@ -635,12 +678,15 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
         }
     }
 #endif
-    if (p.nchunk == 1) {
-        if (res) hipLaunchKernelGGL((conv_wino43_kernel<true, 0, true>), g, dim3(512), lds, st, p);
-        else hipLaunchKernelGGL((conv_wino43_kernel<false, 0, true>), g, dim3(512), lds, st, p);
+#define X_LAUNCH(RES_, ONE_, GEO_) hipLaunchKernelGGL((conv_wino43_kernel<RES_, 0, ONE_, GEO_>), g, dim3(512), lds, st, p)
+    const bool one = p.nchunk == 1;
+    if (geo) {
+        if (one) { if (res) X_LAUNCH(true, true, 1); else X_LAUNCH(false, true, 1); }
+        else { if (res) X_LAUNCH(true, false, 1); else X_LAUNCH(false, false, 1); }
     } else {
-        if (res) hipLaunchKernelGGL((conv_wino43_kernel<true, 0, false>), g, dim3(512), lds, st, p);
-        else hipLaunchKernelGGL((conv_wino43_kernel<false, 0, false>), g, dim3(512), lds, st, p);
+        if (one) { if (res) X_LAUNCH(true, true, 0); else X_LAUNCH(false, true, 0); }
+        else { if (res) X_LAUNCH(true, false, 0); else X_LAUNCH(false, false, 0); }
     }
+#undef X_LAUNCH
     return ss_launch_status();
 }

@@ -529,7 +529,8 @@ def test_wino43_dispatch_rule_and_pipeline_agreement(dev, hip_nets):
     from stabstitch2_amd import ops, pipeline
     assert ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 128, 128, 45, 60, 64)
     assert ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 64, 64, 90, 120, 64)
-    assert not ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 256, 256, 23, 30, 64)      # 30-wide map: half of every tile block idles
+    assert ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 256, 256, 23, 30, 64)          # 30-wide map: the 16 x 32 block geometry (round 5)
+    assert not ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 128, 128, 11, 15, 64)      # regressor maps fill a third of such a block
     assert not ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 128, 128, 45, 60, 2)       # streaming-sized launch
     assert not ops._uses_wino43(1, 3, 3, 2, (0, 1, 1), 64, 128, 45, 60, 64)       # strided
     assert not ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), 4, 64, 90, 120, 64)        # cin % 16

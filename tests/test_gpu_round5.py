@@ -344,3 +344,13 @@ def test_bench_eight_ranks_share_one_gpu():
         assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), ranges      # ... split into disjoint CPU slices
         assert all(c >= 1 for c in d['per_rank_cpus_bound'])
     print('\n[8 ranks on one GPU] %.1f frames/s aggregate, per-rank seconds %s, cpu slices %s' % (d['value'], d['per_rank_seconds'], ranges))
+
+
+@pytest.mark.parametrize('shape', [(4, 23, 30, 256, 256, True, True), (2, 33, 31, 32, 64, True, False), (1, 16, 29, 16, 128, False, True),
+                                   (3, 17, 5, 64, 64, True, True), (2, 47, 24, 48, 192, False, False)])
+def test_conv_wino43_narrow_map_geometry_against_fp64(dev, shape):
+    """The F(4x4,3x3) kernel's second block geometry (16 x 32 output pixels, maps up to 31 columns wide: layer3's 23 x 30, round 5)
+    against fp64 -- one / two / three row blocks, rows ending inside a tile and inside a block, every width class up to the limit 31,
+    one and several K chunks, residual / ReLU / channel-padded destination (the checks of test_conv_wino43_against_fp64)."""
+    from test_gpu_round4 import test_conv_wino43_against_fp64 as check
+    check(dev, shape)

@@ -220,7 +220,9 @@ def test_default_switches_are_the_measured_configuration():
         assert rule(1, 3, 3, 1, 128, 128, 45, 60, 16, 1, 0, 0, 0) == 0          # 384 workgroups < 512
         assert rule(1, 3, 3, 1, 128, 128, 45, 60, 16, 1, 1, 1, 1) == 1          # thresholds pinned to 1: geometry only
         assert rule(1, 3, 3, 1, 32, 64, 90, 120, 64, 1, 0, 0, 0) == 0           # cin < 64
-        assert rule(1, 3, 3, 1, 256, 256, 23, 30, 64, 1, 0, 0, 0) == 0          # 30-wide map: half of every tile block idles
+        assert rule(1, 3, 3, 1, 256, 256, 23, 30, 64, 1, 0, 0, 0) == 1          # narrow map: the 16 x 32 block geometry (67 % filled >= 60 %)
+        assert rule(1, 3, 3, 1, 256, 256, 23, 30, 32, 1, 0, 0, 0) == 0          # ... when the launch is deep enough (256 workgroups < 512)
+        assert rule(1, 3, 3, 1, 128, 128, 11, 15, 248, 1, 0, 0, 0) == 0         # 11 x 15 fills 32 % of a 16 x 32 block
         assert rule(1, 3, 3, 2, 64, 128, 45, 60, 64, 1, 0, 0, 0) == 0 and rule(1, 3, 3, 1, 24, 64, 90, 120, 64, 1, 1, 1, 1) == 0
         assert rule(1, 3, 3, 1, 64, 64, 90, 120, 16, 4, 0, 0, 0) == 1           # groups count towards the launch depth
     assert pipeline.SKIP_OUTSIDE is True and pipeline.U8_FUSED is True
@@ -291,7 +293,8 @@ def test_wino43_dispatch_rule(monkeypatch):
     yes = lambda *a, **k: ops._uses_wino43(1, 3, 3, 1, (0, 1, 1), *a, **k)
     assert yes(128, 128, 45, 60, 64) and yes(64, 64, 90, 120, 64) and yes(64, 64, 90, 120, 32)
     assert not yes(128, 128, 45, 60, 32)            # 384 workgroups: less than two rounds of the chip
-    assert not yes(256, 256, 23, 30, 64)            # half of every tile block idle
+    assert yes(256, 256, 23, 30, 64)                # layer3: the 16 x 32 block geometry of narrow maps
+    assert not yes(256, 256, 23, 30, 32) and not yes(128, 128, 11, 15, 248)
     assert not yes(128, 128, 45, 60, 2)             # streaming
     assert not yes(120, 128, 45, 60, 64) and not yes(128, 96, 45, 60, 64)
     assert not ops._uses_wino43(1, 3, 3, 2, (0, 1, 1), 64, 128, 45, 60, 64)
