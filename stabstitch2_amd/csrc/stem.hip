@@ -77,10 +77,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(const float* base, uns
     return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-// Staged accumulators [conv pixel][32 channels]: a row is 32 dwords = half of the 64 LDS banks, so rows of equal parity collide.  The
-// two halves of a wave write rows R and R + 4 in one instruction, a 16-lane group of the pool's 16-byte reads covers two conv pixels:
-// with row m stored at m ^ bit 2 of m (rows swap inside pairs when bit 2 is set) two rows 4 apart always differ in parity -- both
-// accesses conflict-free (round 4: 0.41 of this kernel's LDS cycles were bank conflicts, all of them here).
+// Staged accumulators [conv pixel][32 channels]: a row is 32 dwords = half of the 64 LDS banks, so in the pool's 16-byte reads rows of
+// equal parity collide (round 4: 0.41 of this kernel's LDS cycles were bank conflicts, all of them there: every lane group read the
+// same 16 dwords of two even rows).  With row m stored at m ^ bit 2 of m (rows swap inside pairs when bit 2 is set) two rows exactly 4
+// apart always differ in parity; the pool's lane map pairs such rows in every lane group.
 __device__ __forceinline__ int sp_row(int m) { return m ^ ((m >> 2) & 1); }
 
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
@@ -236,10 +236,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
             const int item = tid + 256 * it;
             const int q = item & 7;
             int pp = item >> 3;
-            // a 16-lane group of the 16-byte reads = 8 channel quads x 2 pooled pixels: pixels b and b + 2 of a row (the middle two of
-            // every four swapped; SP_PC = 12 is a multiple of 4), i.e. conv pixels 4 apart -- with the staged rows' parity swizzle
-            // (sp_row) the two land on different bank halves, all nine taps alike
-            pp = (pp & ~3) | ((pp & 1) << 1) | ((pp >> 1) & 1);
+            // a ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: channel quads 0-3 of the pixels
+            // of lanes 0-7 and 24-31 with quads 4-7 of those of lanes 8-15 and 16-23 (and vice versa).  Pixels b, b + 1, b + 3, b + 2
+            // in that lane order (the last two of every four swapped; SP_PC = 12 is a multiple of 4) pair conv pixels exactly 4
+            // apart -- with the staged rows' parity swizzle (sp_row) each pair lands on different bank halves, all nine taps alike
+            pp ^= (pp >> 1) & 1;
             pp = pp < SP_PR * SP_PC ? pp : SP_PR * SP_PC - 1;
             const int a = pp / SP_PC, b = pp - a * SP_PC;
             const int py = py0 + a, px = px0 + b;
