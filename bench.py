@@ -567,6 +567,20 @@ def other_configs(nets, dev, args):
     res['720p 2-view streaming (batch 1, one pair per push)']['fps_steady'] = round(200 / dts, 1)
     res['720p 2-view streaming (batch 1, one pair per push)']['ms_per_push_steady'] = round(dts / 200 * 1e3, 4)
     del st1
+    # the three-view script as a stream: two pair chains + per-frame composition + three-image render, one HIP graph per push
+    from stabstitch2_amd.online import ThreeViewOnlineStitcher
+    st3 = ThreeViewOnlineStitcher(nets, 720, 1280)
+    for t in range(12):
+        st3.push(hr[0][t:t + 1], hr[1][t:t + 1], hr[2][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1], lr[2][t:t + 1])
+    sync()
+    t0 = time.perf_counter()
+    for t in range(100):
+        i = t % n
+        st3.push(hr[0][i:i + 1], hr[1][i:i + 1], hr[2][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1], lr[2][i:i + 1])
+    sync()
+    entry('720p 3-view streaming (batch 1, one triple per push)', 100, time.perf_counter() - t0, 1, st3.hc, st3.wc,
+          note='ThreeViewOnlineStitcher, steady state (graph replays), 100 pushes')
+    del st3
     # batch of S independent live streams advancing together (one graph launch per push of S pairs)
     from stabstitch2_amd.online import MultiOnlineStitcher
     S = 8
@@ -893,7 +907,7 @@ def main():
                 'three_view_fps': pick('configs[4]'), 'three_view_linear_fps': oc.get('720p 3-view fusion LINEAR', {}).get('fps'),
                 'configs1_360x480_fps': pick('configs[1]'), 'warp_fast_fps': oc.get('720p 2-view warp FAST', {}).get('fps'),
                 'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
-                'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push')}
+                'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push')}
         for k, v in summ.items():
             result['config']['summary_' + k] = v
     if base and not args.no_cpu_baseline:

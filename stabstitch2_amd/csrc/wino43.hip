@@ -50,6 +50,7 @@ struct W43P {
     unsigned in_bytes, out_bytes, u_bytes;
 #ifdef SS_TUNING
     unsigned long long* dbg;            // per-workgroup phase stamps (tools/diag_wino43.py)
+    int stagger;                        // experiment (ss_debug_set key 17): first-round workgroups start slot * stagger clocks late
 #endif
 };
 
@@ -165,6 +166,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     X_STAMP(0);
+#ifdef SS_TUNING
+    // experiment: all 256 CUs start their first workgroup together and, with workgroups of equal length, stay in lock-step: every
+    // round's prologue is one HBM burst of the whole chip.  Spread the first round over `stagger` clocks per CU slot of the XCD.
+    if (p.stagger > 0 && blockIdx.x < 256u) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 31u) * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
 
     // XCD-aware block order (as wino.hip): every XCD gets one contiguous run of tile blocks
     unsigned lin = blockIdx.x;
@@ -619,6 +629,7 @@ extern "C" int ss_conv_uses_wino43(int kt, int kh, int kw, int stride, int cin, 
 
 #ifdef SS_TUNING
 int g_w43_ablate = 0;                    // ss_debug_set key 21
+extern int g_wino_knob[4];               // [1] (key 17): first-round stagger of this kernel, clocks per CU slot
 #endif
 
 extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, const float* bias, const float* res, float* out,
@@ -650,6 +661,7 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     p.u_bytes = (unsigned)(u_floats * 4);
 #ifdef SS_TUNING
     p.dbg = ss_tuning_dbg;
+    p.stagger = g_wino_knob[1];
 #endif
     const long long wgs = (long long)n * p.nbx * p.nby * p.ncb;
     if (wgs >= (1ll << 31)) return SS_ERR_UNSUPPORTED;

@@ -60,14 +60,18 @@ def _spatial_temporal_heads(spatial, temporal, f64, prev_feat, feat, b, tm_out):
 
 class OnlineStitcher:
     def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True, grow='never'):
+                 use_graph=True, grow='never', meshes_only=False):
         """canvas: optional (wmin, wmax, hmin, hmax) in HR pixels (e.g. the offline bbox).
+        meshes_only: no canvas, no render -- `push` returns the newly smoothed meshes (m1, m2) [k,7,9,2] (k = 7 on the 7th push,
+        then 1) or None; the building block of ThreeViewOnlineStitcher, which captures the graph itself (use_graph is ignored).
         grow: 'never' -- the canvas fixed after the first window stays (frames whose mesh leaves it are cropped and COUNTED:
         `clipped_frames`); 'recapture' -- the canvas grows (and the steady-state graph is captured again) when a mesh comes within
         half the margin of its edge; `canvas_epoch` counts the growths, `hc` / `wc` / `bbox` change with them."""
         if grow not in ('never', 'recapture'):
             raise ValueError("grow must be 'never' or 'recapture'")
         self.grow = grow
+        self.meshes_only = bool(meshes_only)
+        self.last_meshes = None
         self.canvas_epoch = 0
         self.watch_i = self.watch_f = None          # device-side overflow state of the current canvas (ops.canvas_watch)
         self._watch_totals = [0, 0, -1]             # frames seen / clipped / first clipped frame on EARLIER canvases
@@ -213,7 +217,7 @@ class OnlineStitcher:
               'lr2': torch.empty((1, 3, pipeline.LR_H, pipeline.LR_W), device=d),
               'prev_feat': self.prev_feat.clone(), 'pair_s': pair_s, 'pair_t': torch.zeros((2, 2, e), device=d),
               'ring': ring, 'ts_out': torch.empty((2, 4, e), device=d),
-              'out': torch.empty((3, self.hc, self.wc), device=d)}
+              'out': None if self.meshes_only else torch.empty((3, self.hc, self.wc), device=d)}
         self.static = st
 
     def _step_static(self):
@@ -242,6 +246,9 @@ class OnlineStitcher:
         r = st['ring'].view(4, WINDOW, 7, 9, 2)
         outs, _ = self.smooth.run_windows(r[0], r[1], r[2], r[3], 1, WINDOW, 1, 1)
         m1, m2 = outs['smooth_mesh1'][0], outs['smooth_mesh2'][0]
+        if self.meshes_only:
+            self.last_meshes = (m1[-1:], m2[-1:])
+            return
         self._render(st['hr1'], st['hr2'], m1[-1:], m2[-1:], out=st['out'])
 
     def _versions(self):
@@ -317,15 +324,20 @@ class OnlineStitcher:
             self.ring_tsm[v] = (self.ring_tsm[v] + [tsm])[-WINDOW:]
         self.prev_smotion = smotion
         self.frames_in += 1
-        if self.hc is None:
+        if self.hc is None and not self.meshes_only:
             self.ring_hr.append((hr1, hr2))
         if self.frames_in < WINDOW:
-            return []
+            return None if self.meshes_only else []
         # smooth the current window (first tsmotion of the window counts as zero)
         sm = [torch.cat(self.ring_smesh[v], 0).contiguous() for v in range(2)]
         ts = [torch.cat(self.ring_tsm[v], 0).contiguous() for v in range(2)]
         outs, _ = self.smooth.run_windows(sm[0], sm[1], ts[0], ts[1], 1, WINDOW, 1, 1)
         m1, m2 = outs['smooth_mesh1'][0], outs['smooth_mesh2'][0]                   # [7,7,9,2]
+        if self.meshes_only:                                                       # first window: 7 meshes, then the static step
+            self.ring_hr = []
+            self._init_static()
+            self.last_meshes = (m1, m2)
+            return self.last_meshes
         if self.hc is None:                                                        # first window: fix the canvas, emit 7
             if self.bbox is None:
                 bb = ops.mesh_bbox([m1, m2], self.h, self.w).cpu()
@@ -563,3 +575,161 @@ class MultiOnlineStitcher:
         if self.single[0].static is not None:      # every stream's first window is complete: switch to the batched step
             self._init_static()
         return outs
+
+
+class ThreeViewOnlineStitcher:
+    """Streaming form of the three-view script (test_online_tra_threeview.py:154-505, whose frame loops run the same sliding
+    windows as the two-view script): one frame TRIPLE per push.  Two pair chains -- (view 1, view 2) and (view 2, view 3), each an
+    `OnlineStitcher(meshes_only=True)`: ring buffers, cached TemporalNet features, sliding SmoothNet window -- deliver the newest
+    smoothed meshes; the composition (mesh alignment, middle plane, TPS re-projection of the outer views: threeview:345-420) and the
+    three-image render (:421-505) run per frame on two FIXED boxes: the composition's "first canvas" (the box the reference takes
+    over all frames of the aligned meshes) and the output canvas.  Both are fixed when the first window is complete (its 7 frames'
+    boxes grown by `margin`) or given by the caller; with the offline boxes passed in the stream reproduces the offline frames
+    (tests/test_gpu_round5.py).  The steady state -- both chains, composition, render -- is ONE HIP graph.
+
+        st = ThreeViewOnlineStitcher(nets, H, W)
+        for frame in st.push(hr1, hr2, hr3, lr1, lr2, lr3): ...      # [], ..., 7 frames on the 7th push, then 1: [3,Hc,Wc] fp32
+
+    Overflow of the fixed output canvas is watched as in OnlineStitcher (`clipped_frames`, `overflow_report()`); the canvas does not
+    grow (grow='never')."""
+
+    def __init__(self, nets, height, width, canvas=None, first_canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
+                 use_graph=True):
+        self.nets = nets
+        self.dev = next(nets[0].parameters()).device
+        self.h, self.w = height, width
+        self.margin = margin
+        self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
+        self.use_graph = use_graph
+        mk = lambda: OnlineStitcher(nets, height, width, margin=margin, warp_mode=warp_mode, fusion_mode=fusion_mode,
+                                    use_graph=False, meshes_only=True)
+        self.chain12, self.chain23 = mk(), mk()
+        box = lambda b: None if b is None else torch.tensor(b, dtype=torch.float32, device=self.dev)
+        self.bbox, self.first_canvas = box(canvas), box(first_canvas)
+        self.hc = self.wc = None
+        self.nrigid = get_norm_mesh(get_rigid_mesh(1, height, width, device=self.dev), height, width).contiguous()
+        self.ring_hr = []
+        self.frames_in = 0
+        self.static = None
+        self.graph = None
+        self.watch_i = self.watch_f = None
+        self.versions = None
+
+    # ------------------------------------------------------------------ composition + render of k frames
+    def _compose(self, m12, m23):
+        """Pair meshes (m1, m2) [k,7,9,2] of both chains -> (mesh1, middle, mesh3) [1,k,7,9,2] in first-canvas pixels."""
+        k = m12[0].shape[0]
+        sh = lambda m: m.reshape(1, k, 7, 9, 2)
+        return pipeline.three_view_compose(sh(m12[0]), sh(m12[1]), sh(m23[0]), sh(m23[1]), self.h, self.w,
+                                           first_canvas=self.first_canvas)
+
+    def _grown(self, bb):
+        bb = bb.cpu()
+        gw, gh = self.margin * (bb[1] - bb[0]), self.margin * (bb[3] - bb[2])
+        return torch.stack((bb[0] - gw, bb[1] + gw, bb[2] - gh, bb[3] + gh)).to(self.dev)
+
+    def _render(self, imgs, meshes, out=None):
+        """imgs: three [1,3,H,W]; meshes: (mesh1, middle, mesh3) [1,1,7,9,2] in first-canvas pixels -> [3,Hc,Wc]."""
+        src4 = ops.mesh_normalize_views(list(meshes), self.bbox, 0.0, 0.0)            # [1,3,63,2] on the output canvas
+        ops.canvas_watch(src4, self.watch_i, self.watch_f, 0.0)
+        src = src4[0]
+        T = ops.tps_solve_shared(src, self.nrigid)
+        if self.fusion_mode == 'AVERAGE':
+            fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc)[0] if pipeline.SKIP_OUTSIDE else None
+            return ops.render_average(imgs, src, T, self.hc, self.wc, self.warp_mode, out=out, footprint=fp)
+        w = ops.tps_warp_views(imgs, src, T, self.hc, self.wc, self.warp_mode)        # [3,4,Hc,Wc]
+        f = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
+        res = ops.linear_blend(f, w[2, 0:3], ops.mask_union(w[0, 3], w[1, 3]), w[2, 3])
+        return res if out is None else out.copy_(res)
+
+    # ------------------------------------------------------------------ overflow (as OnlineStitcher, no growth)
+    def overflow_report(self):
+        rep = {'frames_seen': 0, 'clipped_frames': 0, 'first_clipped_frame': -1, 'near_frames': 0, 'canvas_epoch': 0}
+        if self.watch_i is not None:
+            wi = self.watch_i[0].cpu().tolist()
+            rep.update(frames_seen=wi[0], clipped_frames=wi[1], first_clipped_frame=wi[2], near_frames=wi[3])
+        return rep
+
+    @property
+    def clipped_frames(self):
+        return self.overflow_report()['clipped_frames']
+
+    # ------------------------------------------------------------------ steady state
+    def _versions(self):
+        return tuple(n.weights_version for n in self.nets)
+
+    def _step_static(self):
+        a, b, st = self.chain12, self.chain23, self.static
+        a._step_static()
+        b._step_static()
+        meshes = self._compose(a.last_meshes, b.last_meshes)
+        self._render([a.static['hr1'], a.static['hr2'], st['hr3']], meshes, out=st['out'])
+
+    def _state(self):
+        keep = []
+        for c in (self.chain12, self.chain23):
+            keep += [c.static[k] for k in OnlineStitcher._STATE]
+        return keep + [self.watch_i, self.watch_f]
+
+    def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3):
+        a, b, st = self.chain12.static, self.chain23.static, self.static
+        if self.versions != self._versions():         # a net was reloaded / moved: stale twin trunks and graph
+            self.chain12.trunk_pair = self.chain23.trunk_pair = None
+            self.graph = None
+            self.versions = self._versions()
+        for dst, src in ((a['hr1'], hr1), (a['hr2'], hr2), (a['lr1'], lr1), (a['lr2'], lr2), (b['hr1'], hr2), (b['hr2'], hr3),
+                         (b['lr1'], lr2), (b['lr2'], lr3), (st['hr3'], hr3)):
+            dst.copy_(src.reshape(dst.shape))
+        if not self.use_graph:
+            self._step_static()
+        elif self.graph is None:
+            state = self._state()
+            keep = [t.clone() for t in state]
+            side = _warmup_stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self._step_static()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            for t, v in zip(state, keep):
+                t.copy_(v)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_static()
+            self.graph = g
+            for t, v in zip(state, keep):          # capture does not execute: state is still the pre-push state
+                t.copy_(v)
+            self.graph.replay()
+        else:
+            self.graph.replay()
+        self.frames_in += 1
+        return [st['out'].clone()]
+
+    @torch.no_grad()
+    def push(self, hr1, hr2, hr3, lr1, lr2, lr3):
+        """One frame triple: hr* [1,3,H,W] (0..255), lr* [1,3,360,480] ([-1,1]), device tensors.
+        -> list of newly stitched frames (empty for the first 6 pushes, 7 frames on the 7th, then one per push)."""
+        if self.static is not None:
+            return self._push_static(hr1, hr2, hr3, lr1, lr2, lr3)
+        m12 = self.chain12.push(hr1, hr2, lr1, lr2)
+        m23 = self.chain23.push(hr2, hr3, lr2, lr3)
+        self.ring_hr.append((hr1, hr2, hr3))
+        self.frames_in += 1
+        if m12 is None:
+            return []
+        # first window complete: fix the first canvas and the output canvas, render its 7 frames, switch to the static step
+        if self.first_canvas is None:
+            k = m12[0].shape[0]
+            sh = lambda m: m.reshape(1, k, 7, 9, 2)
+            a1, a2, b1, b2, _ = ops.three_view_align(sh(m12[0]), sh(m12[1]), sh(m23[0]), sh(m23[1]), self.h, self.w)
+            self.first_canvas = self._grown(ops.mesh_bbox([a1, a2, b1, b2], 0.0, 0.0))
+        meshes = self._compose(m12, m23)                                           # three x [1,7,7,9,2]
+        if self.bbox is None:
+            self.bbox = self._grown(pipeline.canvas_bbox(meshes, self.h, self.w, prescaled=True))
+        self.hc, self.wc = pipeline.canvas_size(self.bbox)
+        self.watch_i, self.watch_f = ops.canvas_watch_state(1, self.dev)
+        frames = [self._render(list(hr), [m[:, i:i + 1] for m in meshes]) for i, hr in enumerate(self.ring_hr)]
+        self.ring_hr = []
+        self.static = {'hr3': torch.empty((1, 3, self.h, self.w), device=self.dev),
+                       'out': torch.empty((3, self.hc, self.wc), device=self.dev)}
+        self.versions = self._versions()
+        return frames

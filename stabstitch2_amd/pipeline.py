@@ -559,13 +559,14 @@ def run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode='NORMAL', fusion_mode='AVER
 
 # ------------------------------------------------------------------ three-view (threeview:345-505)
 @torch.no_grad()
-def three_view_compose(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w):
+def three_view_compose(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w, first_canvas=None):
     """Mesh alignment, middle plane and TPS re-projection of the outer views (test_online_tra_threeview.py:345-420).
     Inputs [1,N,7,9,2] (LR scale) -> (mesh1, middle, mesh3) in first-canvas HR pixels.  All of it on the HIP kernels:
     `ss_three_view_align` (scale, per-frame mean offset, middle mesh), `ss_mesh_bbox` / `ss_mesh_normalize` (first canvas),
-    `ss_tps_solve` / `ss_tps_points` (re-projection), `ss_three_view_finish` (back to canvas pixels); no host sync."""
+    `ss_tps_solve` / `ss_tps_points` (re-projection), `ss_three_view_finish` (back to canvas pixels); no host sync.
+    first_canvas: device box [4] to use as the first canvas instead of the box of these frames (streaming mode: fixed once)."""
     a1, a2, b1, b2, mid = ops.three_view_align(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w)
-    bbox = ops.mesh_bbox([a1, a2, b1, b2], 0.0, 0.0)             # first canvas (meshes are HR pixels already)
+    bbox = first_canvas if first_canvas is not None else ops.mesh_bbox([a1, a2, b1, b2], 0.0, 0.0)   # (meshes are HR pixels already)
     nrm = lambda m: ops.mesh_normalize(m, bbox, 0.0, 0.0)          # [N,63,2]
     nmid, na2, nb1 = nrm(mid), nrm(a2), nrm(b1)
     n1 = ops.tps_points(nrm(a1), na2, ops.tps_solve(na2, nmid))
