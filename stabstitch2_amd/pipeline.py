@@ -910,7 +910,9 @@ class LongVideoStitcher:
       pass 2  `render`: uint8 upload -> fused TPS warp + fusion onto the shared canvas -> uint8 video frames -> host.
     Device memory is that of one chunk plus O(N) mesh-sized tensors (504 bytes per frame, view and motion kind); uploads,
     compute and downloads of neighbouring chunks overlap on three HIP streams.  The meshes equal those of the resident
-    path bit for bit (same launches), hence so do the canvas and the frames."""
+    path bit for bit -- PROVIDED both run the same chunking (`chunk` = the resident path's 32-pair chunks): the conv engine picks its
+    kernel per launch size (ss_conv_uses_wino43 / ss_conv_uses_winograd / split-K), and another chunk length sums in another order
+    (~1e-5 px; set SS_WINO43_MIN_WGS=1 to pin the kernel choice per layer) -- hence so do the canvas and the frames."""
 
     def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', chunk=None):
         self.nets, self.dev = nets, torch.device(device)
