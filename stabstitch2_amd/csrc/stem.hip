@@ -44,6 +44,9 @@ typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
 #define SP_PFLOATS (6 * (SP_CC - 1) + 24)    // 168 floats of an input row
 #define SP_PITCH 172                     // LDS pitch of a patch row (floats; 16-byte multiple)
 #define SP_NG 21                         // K groups of 8
+#ifndef SP_SPLIT_DEFAULT
+#define SP_SPLIT_DEFAULT true            // which of the two kernels ss_stem_pool launches (measured: see stem_pool_kernel_half)
+#endif
 
 struct StemP {
     const float* in;             // [n][h][w + 8][3]
@@ -51,8 +54,8 @@ struct StemP {
     const float* bias;           // [groups][64] or nullptr
     float* out;                  // [groups][n][hp][wp][64]
     int n, h, w, ho, wo, hp, wp, groups;
-    unsigned ntx, nty;
-    SsDiv32 divTx, divTy, divG;
+    unsigned ntx, nty, ntiles;
+    SsDiv32 divTx, divTy, divG, divG2;
     long long out_gs;
     unsigned in_bytes, pk_bytes;
 #ifdef SS_TUNING
@@ -299,6 +302,163 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemP p) {
 #endif
 }
 
+// The same stem with ONE 32-channel half per workgroup (round 5; the kernel ss_stem_pool launches: 1065 against 1088 us for 64 images
+// x 2 banks, tools/ab_stem_split.py; the two-halves kernel above stays for the tuning build's A/B): 4 accumulator tiles per wave instead of 8
+// (~120 registers: four waves per SIMD), a 32 KB stage (two 16-channel passes): four to five workgroups per CU instead of two, so
+// that a workgroup's prologue (patch staging) and epilogue (pool) overlap THREE neighbours' K loops.  Price: every patch is staged by
+// two workgroups (the halves of a tile are consecutive workgroups: the second finds it in L2) and an A operand read from LDS feeds one
+// MFMA instead of two.  Same arithmetic per output: results equal stem_pool_kernel's bit for bit.
+__global__ __launch_bounds__(256, 4) void stem_pool_kernel_half(StemP p) {
+    __shared__ __attribute__((aligned(16))) float smem[512 * 16];           // the patch [43][172] (7396 floats), then the stage [512][16]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h2 = lane >> 5, ln = lane & 31;
+    __builtin_amdgcn_s_setprio(3);
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The 2 x groups workgroups that read ONE patch (its
+    // filter banks x channel halves) are consecutive workgroups OF ONE XCD: the first stages the patch from HBM, the others find it in
+    // that XCD's L2 (dealt out in plain order they would sit on 2 x groups different XCDs and each fetch it again).
+    const unsigned xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3;
+    const unsigned tq = ss_div32(jx, p.divG2), sub = jx - tq * 2u * (unsigned)p.groups;
+    const unsigned tile = tq * 8u + xcd;
+    if (tile >= p.ntiles) return;
+    const unsigned nt0 = sub & 1u;                         // this workgroup's 32-channel half
+    const unsigned grp = sub >> 1;
+    const unsigned t1 = ss_div32(tile, p.divTx);
+    const int tx = (int)(tile - t1 * p.ntx);
+    const unsigned img = ss_div32(t1, p.divTy);
+    const int ty = (int)(t1 - img * p.nty);
+    const int py0 = ty * SP_PR, px0 = tx * SP_PC;
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;
+    const __amdgpu_buffer_rsrc_t rin = sp_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rpk = sp_rsrc(p.packed, p.pk_bytes);
+    {
+        constexpr int Q = SP_PFLOATS / 4;
+        const int slot = tid / Q, q = tid - slot * Q;
+        const long long rowf = (long long)(p.w + 8) * 3;
+        const int iy0 = 2 * cy0 - 3 + slot;
+        long long off = ((long long)img * p.h + iy0) * rowf + 6 * cx0 + 4 * q;
+        float* dst = smem + slot * SP_PITCH + 4 * q;
+#pragma unroll
+        for (int i = 0; i < (SP_PROWS + 5) / 6; ++i) {
+            const int pr = slot + 6 * i, iy = iy0 + 6 * i;
+            const bool ok = slot < 6 && pr < SP_PROWS && (unsigned)iy < (unsigned)p.h && off >= 0;
+            const sp_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (unsigned)(off * 4) : 0xFFFFFFFFu, 0, 0);
+            if (slot < 6 && pr < SP_PROWS) *reinterpret_cast<sp_u32x4*>(dst) = v;
+            off += 6 * rowf;
+            dst += 6 * SP_PITCH;
+        }
+    }
+    int abase[4], abase3[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int m = 32 * (4 * wave + mt) + ln;
+        m = m < SP_M ? m : SP_M - 1;
+        const int r = m / SP_CC, c = m - r * SP_CC;
+        abase[mt] = (2 * r) * SP_PITCH + 6 * c + 4 * h2;
+        abase3[mt] = (2 * r) * SP_PITCH + 6 * c + 16 + 3 * h2;
+    }
+    const unsigned pk_lane = (unsigned)lane * 16u;
+    const unsigned pk_grp = grp * (2u * SP_NG * 1024u) + nt0 * (SP_NG * 1024u);
+    sp_f32x16 acc[4];
+    const sp_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    sp_f32x4 a_cur[4], b_cur, a_nxt[4], b_nxt;
+    auto load = [&](int g, sp_f32x4 (&a)[4], sp_f32x4& b) {
+        if (g % 3 == 2) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float* ap = smem + abase3[mt] + (g / 3) * SP_PITCH;
+                a[mt] = (sp_f32x4){ap[0], ap[1], ap[2], 0.f};
+            }
+        } else {
+            const int koff = (g / 3) * SP_PITCH + (g % 3) * 8;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float* ap = smem + abase[mt] + koff;
+                const sp_f32x2 lo = *reinterpret_cast<const sp_f32x2*>(ap);
+                const sp_f32x2 hi = *reinterpret_cast<const sp_f32x2*>(ap + 2);
+                a[mt] = (sp_f32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
+        }
+        const int so = (int)__builtin_amdgcn_readfirstlane(pk_grp + (unsigned)g * 1024u);
+        b = __builtin_bit_cast(sp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpk, pk_lane, so, 0));
+    };
+    load(0, a_cur, b_cur);
+#pragma unroll
+    for (int g = 0; g < SP_NG; ++g) {
+        if (g + 1 < SP_NG) load(g + 1, a_nxt, b_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < (g % 3 == 2 ? 3 : 4); ++s)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const sp_f32x16 c0 = (g == 0 && s == 0) ? zero16 : acc[mt];
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][s], b_cur[s], c0, 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a_cur[mt] = a_nxt[mt];
+        b_cur = b_nxt;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    __syncthreads();
+    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + SP_CR <= p.ho && cx0 + SP_CC <= p.wo;
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {                       // channels 32 nt0 + 16 qp .. + 15
+        if ((ln >> 4) == qp) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * (4 * wave + mt) + 8 * (r >> 2) + (r & 3) + 4 * h2;
+                    smem[row * 16 + (ln & 15)] = acc[mt][r];
+                }
+        }
+        __syncthreads();
+        const int cbase = 32 * (int)nt0 + 16 * qp;
+#pragma unroll
+        for (int it = 0; it < (SP_PR * SP_PC * 4 + 255) / 256; ++it) {
+            const int item = tid + 256 * it;
+            const int q = item & 3;
+            int pp = item >> 2;
+            pp = pp < SP_PR * SP_PC ? pp : SP_PR * SP_PC - 1;
+            const int a = pp / SP_PC, b = pp - a * SP_PC;
+            const int py = py0 + a, px = px0 + b;
+            const int m0 = (2 * a) * SP_CC + 2 * b;
+            // one window row at a time (three 16-byte reads in flight, running maximum): 12 registers of taps instead of 36 -- the
+            // second half's 64 accumulators are still live here and the kernel must stay within 128 registers
+            sp_f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int tr = 0; tr < 3; ++tr) {
+                sp_f32x4 v[3];
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc) v[tc] = *reinterpret_cast<const sp_f32x4*>(smem + (m0 + tr * SP_CC + tc) * 16 + 4 * q);
+                if (!interior) {
+                    const bool rok = (unsigned)(cy0 + 2 * a + tr) < (unsigned)p.ho;
+#pragma unroll
+                    for (int tc = 0; tc < 3; ++tc) {
+                        const bool ok = rok && (unsigned)(cx0 + 2 * b + tc) < (unsigned)p.wo;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[tc][k] = ok ? v[tc][k] : -INFINITY;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]));
+            }
+            sp_f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bb = *reinterpret_cast<const sp_f32x4*>(p.bias + grp * 64 + cbase + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k] + bb[k], 0.f);
+            if (item < SP_PR * SP_PC * 4 && py < p.hp && px < p.wp)
+                *reinterpret_cast<sp_f32x4*>(out + (((long long)img * p.hp + py) * p.wp + px) * 64 + cbase + 4 * q) = mx;
+        }
+        if (qp == 0) __syncthreads();
+    }
+}
+
 // filters [groups][64][7][24] (layers.pack_stem3: w[co][dh][3 dw + c], entries 21..23 of a row zero, BN folded) ->
 // packed [groups][2][21][64 lanes][4]: lane (n = lane & 31, h = lane >> 5), float s = w[32 nt + n][k]: filter row g / 3, within
 // it k = 8 (g % 3) + 4 h + s for the two 8-k groups and 16 + 3 h + s (s < 3) for the 6-k group
@@ -342,6 +502,7 @@ extern "C" int ss_stem_pool(const float* in_padded, const float* packed, const f
     p.divTx = ss_div32_make(p.ntx);
     p.divTy = ss_div32_make(p.nty);
     p.divG = ss_div32_make((unsigned)groups);
+    p.divG2 = ss_div32_make(2u * (unsigned)groups);
     p.out_gs = out_gs;
     const long long in_bytes = (long long)n * h * (w + 8) * 12;
     const long long wgs = (long long)n * p.nty * p.ntx * groups;
@@ -356,6 +517,19 @@ extern "C" int ss_stem_pool(const float* in_padded, const float* packed, const f
 #else
     const unsigned dyn = 0u;
 #endif
-    hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)wgs), dim3(256), dyn, (hipStream_t)stream, p);
+#ifdef SS_TUNING
+    const bool split = g_wino_knob[2] != 2;                  // ss_debug_set(18, 2): the two-halves-per-workgroup kernel
+#else
+    const bool split = SP_SPLIT_DEFAULT;
+#endif
+    if (split) {
+        const long long tiles = (long long)n * p.nty * p.ntx;
+        const long long grid = 8ll * ((tiles + 7) / 8) * 2 * groups;         // (tile slots past the last tile exit at once)
+        if (grid >= (1ll << 31)) return SS_ERR_UNSUPPORTED;
+        p.ntiles = (unsigned)tiles;
+        hipLaunchKernelGGL(stem_pool_kernel_half, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)wgs), dim3(256), dyn, (hipStream_t)stream, p);
+    }
     return ss_launch_status();
 }
