@@ -178,8 +178,13 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
                     v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
                 }
                 if (NV % 4) {
-                    float2 t = *reinterpret_cast<const float2*>(row + roff[NV / 4]);
-                    v[NV - 2] = t.x; v[NV - 1] = t.y;
+                    // the last two values as a full 16-byte read too (the row's 7th slot exists: 26 floats live in 7 slots of 4): an
+                    // 8-byte read is served in 32-lane groups, where this kernel's lane map puts two window rows on the same banks;
+                    // the 16-byte groups were laid out conflict-free above.  (The opaque asm keeps hipcc from shortening it again.)
+                    typedef float cv_f4 __attribute__((ext_vector_type(4)));
+                    cv_f4 t = *reinterpret_cast<const cv_f4*>(row + roff[NV / 4]);
+                    asm volatile("" : "+v"(t));
+                    v[NV - 2] = t[0]; v[NV - 1] = t[1];
                 }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
