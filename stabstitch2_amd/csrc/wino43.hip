@@ -461,7 +461,16 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
             int c = 0;
             do { chunk(c, std::true_type{}); } while (++c + 1 < p.nchunk);
         }
+#ifdef SS_TUNING
+        // experiment (ss_debug_set(17, -1 / -2)): the two waves of a SIMD (w, w + 4) drift apart inside a chunk (the older one wins
+        // the matrix pipe); behind the last chunk nothing re-aligns them but the epilogue's barrier.  Priority to the younger wave
+        // (-1: in the last chunk, -2: in every chunk's second half) -- does the skew ("wait" in tools/diag_wino43.py) shrink?
+        if (p.stagger == -1 && wave >= 4) __builtin_amdgcn_s_setprio(2);
+#endif
         chunk(p.nchunk - 1, std::false_type{});
+#ifdef SS_TUNING
+        if (p.stagger == -1) __builtin_amdgcn_s_setprio(0);
+#endif
     };
     if (pbb == 0) kloop(std::integral_constant<int, 0>{});
     else kloop(std::integral_constant<int, 1>{});
