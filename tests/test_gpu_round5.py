@@ -401,3 +401,4 @@ def test_three_view_streaming_matches_offline(dev, hip_nets):
         got += own.push(hrd[0][t], hrd[1][t], hrd[2][t], lrd[0][t], lrd[1][t], lrd[2][t])
     assert len(got) == 9 and all(bool(torch.isfinite(f).all()) for f in got) and own.hc >= hc and own.wc >= wc
     assert own.clipped_frames == 0 and own.overflow_report()['frames_seen'] == 9
+
