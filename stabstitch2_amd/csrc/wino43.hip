@@ -6,24 +6,28 @@
 // entries 4, -5, 2 instead of +-1 and every VALU instruction takes ~4 clocks of the SIMD the matrix pipe shares
 // (tools/micro/mfma_valu: at ANY occupancy), so the transform is organised to run ONCE per workgroup and value:
 //
-//   workgroup = 512 threads = 8 waves, ONE per CU (144 KB of LDS); tile = 2 x 15 output tiles of 4x4 pixels (8 rows x 60
-//   columns of ONE image: the maps of this network are 60 / 120 wide; slots 15 and 31 of the MFMA's 32 rows idle) x 64
-//   output channels x all 36 positions.  Wave (a, b, blk) owns the 3 x 3 block of positions (3a .. 3a+2, 3b .. 3b+2) for
-//   the 32-channel block `blk`: 9 accumulator tiles of v_mfma_f32_32x32x2_f32 = 144 registers.
-//   K loop over cin in chunks of 16:
-//     stage 1 (cooperative, once per workgroup): thread (pixel column x, tile row ty, channel quad) loads its 6 raw rows
-//       (16-byte buffer loads, halo / image border through the descriptor's bounds check) one chunk ahead, applies the
-//       ROW transform B^T d (12 fma/add per channel) and writes V1[channel][ty][i][x] to LDS (two buffers, one barrier
-//       per chunk);
-//     stage 2 (per wave): lane (tile, k half) reads the 6 floats of row 3a+g of its tile's window (two conflict-free
-//       16-byte LDS reads) and forms the 3 A operands of its column block (6 fma/add) -- one channel per step;
-//     72 MFMAs per wave and chunk: B operand = transformed filters PRE-PACKED in the instruction's register layout (global ->
-//       VGPR, 1 KB coalesced loads, two groups of 12 MFMAs ahead).
-//   epilogue: the accumulators of one 32-channel block at a time go to LDS ([position][tile][cout]); every thread then owns
-//   (tile, cout) items: 36 LDS reads, A^T m A (100 fma/add), bias (folded BatchNorm), residual, ReLU, 16 dword stores
-//   (a wave writes 128-byte runs of 32 channels).
-// Results differ from wino.hip / the direct form by fp32 rounding of the larger transform constants; simulated end to end
-// against the reference goldens in tools/sim_wino43.py (profiles/r03_f43_simulation.txt) and gated in tests/.
+//   workgroup = 512 threads = 8 waves, ONE per CU (144 KB of LDS); tile = 32 output tiles of 4x4 pixels -- GEO 0: 2 x 15 tiles = 8 rows x
+//   60 columns of ONE image (the trunk's maps are 60 / 120 wide; slots 15 and 31 of the MFMA's 32 rows idle), GEO 1: 4 x 8 tiles = 16 x 32
+//   pixels for maps up to 31 columns wide (layer3's 23 x 30) -- x 64 output channels x all 36 positions.  Wave (a, b, blk) owns the 3 x 3
+//   block of positions (3a .. 3a+2, 3b .. 3b+2) for the 32-channel block `blk`: 9 accumulator tiles of v_mfma_f32_32x32x2_f32 = 144 registers.
+//   K loop over cin in chunks of 16 = 8 channel PAIRS; both transforms run on packed fp32 (v_pk_fma_f32 / v_pk_add_f32) over the two
+//   channels of a pair (inline asm: hipcc unpacks packed fp32 between MFMAs):
+//     stage 1 (cooperative, once per workgroup): thread (pixel column x, tile row ty, channel quad) loads its 6 raw rows (16-byte buffer
+//       loads, halo / image border through the descriptor's bounds check) one chunk ahead, applies the ROW transform B^T d (12 packed
+//       ops per pair) and writes V1[pair][ty][i][x][2] to LDS with 8-byte stores (two buffers, one barrier per chunk);
+//     stage 2 (per wave and pair step = 2 MFMA steps x 3 positions): lane (tile, k half) reads its window row of V1 as three 16-byte
+//       entries (A[tx], B[tx], A[tx+1]; laid out for the ds_read_b128 lane groups, see XG) and forms the 3 A operands of its column block
+//       for both channels in 6 packed ops -- .x / .y of a result pair feed the two MFMA steps;
+//     72 MFMAs per wave and chunk against 124 VALU: B operand = transformed filters PRE-PACKED in the instruction's register layout
+//       (global -> VGPR, 1 KB coalesced loads, two groups of 12 MFMAs ahead).
+//   The K loop exists in two compile-time copies (column block B = 0 / 1 of the wave); the prologue (first rows, first filters, chunk 0's
+//   row transform) runs INSIDE each copy: hipcc lays the wave-uniform branch out as "copy 0, then maybe copy 1", and whatever a shared
+//   prologue left in registers for copy 1 was spilled around copy 0 (47 registers, 114 KB of scratch stores per workgroup in round 4).
+//   epilogue in two phases of 16 tiles: all eight waves stage their accumulators ([position][tile][64 cout], 144 KB), then a thread owns a
+//   (tile, cout pair): 36 8-byte LDS reads, A^T m A on packed fp32, bias (folded BatchNorm), residual (requested inside the last chunk /
+//   while the first phase stores), ReLU, 8-byte stores (a wave writes 256-byte runs of a pixel's channels).
+// Results differ from wino.hip / the direct form by fp32 rounding of the larger transform constants; gated in tests/ against fp64, the
+// reference goldens (G8 / G9 forced everywhere, G14 under trained-like weights in three dispatch modes) and the oracle at 720p.
 #include "common.h"
 #include <atomic>
 #include <thread>
