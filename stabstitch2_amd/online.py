@@ -369,12 +369,17 @@ class MultiOnlineStitcher:
     is independent of its neighbours bit for bit (tests/test_gpu_round4.py)."""
 
     def __init__(self, nets, height, width, streams, canvases=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True, grow='never'):
+                 use_graph=True, grow='never', meshes_only=False):
         """grow: as OnlineStitcher -- 'never' counts the frames whose mesh left their stream's canvas (`clipped_frames`, per
-        stream), 'recapture' re-fixes the canvases of the streams that come near an edge and captures the graph again."""
+        stream), 'recapture' re-fixes the canvases of the streams that come near an edge and captures the graph again.
+        meshes_only: no canvases, no render -- `push` returns the S streams' newly smoothed meshes (m1, m2) [S,k,7,9,2] (k = 7 on the
+        7th push, then 1) or None; ThreeViewOnlineStitcher runs its two pair chains as such a batch of two and captures the graph
+        itself (use_graph is ignored)."""
         if grow not in ('never', 'recapture'):
             raise ValueError("grow must be 'never' or 'recapture'")
         self.grow = grow
+        self.meshes_only = bool(meshes_only)
+        self.last_meshes = None
         self._host_watch = self._host_event = None
         self.nets = nets
         self.spatial, self.temporal, self.smooth = nets
@@ -386,7 +391,7 @@ class MultiOnlineStitcher:
             raise ValueError('one canvas per stream')
         self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
         self.single = [OnlineStitcher(nets, height, width, None if canvases is None else canvases[s], margin, warp_mode,
-                                      fusion_mode, use_graph=False) for s in range(self.S)]       # (growth is handled here, batched)
+                                      fusion_mode, use_graph=False, meshes_only=meshes_only) for s in range(self.S)]   # (growth is handled here, batched)
         self.use_graph = use_graph
         self.static = None
         self.graph = None
@@ -417,12 +422,13 @@ class MultiOnlineStitcher:
               'pair_t': torch.zeros((2, 2, S, e), device=d),
               'ring': torch.stack([o['ring'] for o in one], 1).contiguous(),               # [4,S,7,126]
               'ts_out': torch.empty((2, 4 * S, e), device=d),
-              'bboxes': torch.stack([s.bbox for s in self.single], 0).contiguous(),        # [S,4] the streams' fixed canvases
-              'watch_i': torch.cat([s.watch_i for s in self.single], 0).contiguous(),       # [S,4] overflow state (ops.canvas_watch)
-              'watch_f': torch.cat([s.watch_f for s in self.single], 0).contiguous(),
               'out': None, 'out_all': None}
         self.static = st
-        self._alloc_outputs()
+        if not self.meshes_only:
+            st['bboxes'] = torch.stack([s.bbox for s in self.single], 0).contiguous()        # [S,4] the streams' fixed canvases
+            st['watch_i'] = torch.cat([s.watch_i for s in self.single], 0).contiguous()       # [S,4] overflow state (ops.canvas_watch)
+            st['watch_f'] = torch.cat([s.watch_f for s in self.single], 0).contiguous()
+            self._alloc_outputs()
         for s in self.single:                     # the per-stream buffers are not needed any more (bbox / canvas stay)
             s.static = None
 
@@ -511,6 +517,9 @@ class MultiOnlineStitcher:
         r = st['ring'].view(4, S * WINDOW, 7, 9, 2)
         outs, _ = self.smooth.run_windows(r[0], r[1], r[2], r[3], S, WINDOW, WINDOW, 1)       # S windows, one per stream
         m1, m2 = outs['smooth_mesh1'], outs['smooth_mesh2']                                    # [S,7,7,9,2]
+        if self.meshes_only:
+            self.last_meshes = (m1[:, -1:], m2[:, -1:])                                       # [S,1,7,9,2]
+            return
         # every stream's newest smoothed mesh on its own canvas: one normalisation launch per view and ONE batched TPS solve for
         # the 2 S splines (a solve is latency-bound, ~48 us whether it holds 2 systems or 16), then the render stream by stream
         src = ops.mesh_normalize_views_boxes([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w)     # [S,2,63,2]
@@ -539,7 +548,7 @@ class MultiOnlineStitcher:
         if not self.use_graph:
             self._step_static()
         elif self.graph is None:
-            keep = {k: st[k].clone() for k in self._STATE + ('watch_i', 'watch_f')}
+            keep = {k: st[k].clone() for k in self._STATE + (() if self.meshes_only else ('watch_i', 'watch_f'))}
             side = _warmup_stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -574,14 +583,19 @@ class MultiOnlineStitcher:
         self.frames_in += 1
         if self.single[0].static is not None:      # every stream's first window is complete: switch to the batched step
             self._init_static()
+        if self.meshes_only:
+            if outs[0] is None:
+                return None
+            self.last_meshes = (torch.stack([o[0] for o in outs], 0), torch.stack([o[1] for o in outs], 0))   # [S,7,7,9,2]
+            return self.last_meshes
         return outs
 
 
 class ThreeViewOnlineStitcher:
     """Streaming form of the three-view script (test_online_tra_threeview.py:154-505, whose frame loops run the same sliding
-    windows as the two-view script): one frame TRIPLE per push.  Two pair chains -- (view 1, view 2) and (view 2, view 3), each an
-    `OnlineStitcher(meshes_only=True)`: ring buffers, cached TemporalNet features, sliding SmoothNet window -- deliver the newest
-    smoothed meshes; the composition (mesh alignment, middle plane, TPS re-projection of the outer views: threeview:345-420) and the
+    windows as the two-view script): one frame TRIPLE per push.  Two pair chains -- (view 1, view 2) and (view 2, view 3), run as ONE
+    batch of two streams (`MultiOnlineStitcher(streams=2, meshes_only=True)`: ring buffers, cached TemporalNet features, sliding
+    SmoothNet windows; every launch serves both pairs) -- deliver the newest smoothed meshes; the composition (mesh alignment, middle plane, TPS re-projection of the outer views: threeview:345-420) and the
     three-image render (:421-505) run per frame on two FIXED boxes: the composition's "first canvas" (the box the reference takes
     over all frames of the aligned meshes) and the output canvas.  Both are fixed when the first window is complete (its 7 frames'
     boxes grown by `margin`) or given by the caller; with the offline boxes passed in the stream reproduces the offline frames
@@ -601,9 +615,9 @@ class ThreeViewOnlineStitcher:
         self.margin = margin
         self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
         self.use_graph = use_graph
-        mk = lambda: OnlineStitcher(nets, height, width, margin=margin, warp_mode=warp_mode, fusion_mode=fusion_mode,
-                                    use_graph=False, meshes_only=True)
-        self.chain12, self.chain23 = mk(), mk()
+        # the two pair chains as a batch of two streams: (view 1, view 2) and (view 2, view 3) share every launch
+        self.chains = MultiOnlineStitcher(nets, height, width, streams=2, margin=margin, warp_mode=warp_mode, fusion_mode=fusion_mode,
+                                          use_graph=False, meshes_only=True)
         box = lambda b: None if b is None else torch.tensor(b, dtype=torch.float32, device=self.dev)
         self.bbox, self.first_canvas = box(canvas), box(first_canvas)
         self.hc = self.wc = None
@@ -659,26 +673,24 @@ class ThreeViewOnlineStitcher:
         return tuple(n.weights_version for n in self.nets)
 
     def _step_static(self):
-        a, b, st = self.chain12, self.chain23, self.static
-        a._step_static()
-        b._step_static()
-        meshes = self._compose(a.last_meshes, b.last_meshes)
-        self._render([a.static['hr1'], a.static['hr2'], st['hr3']], meshes, out=st['out'])
+        ch, st = self.chains, self.static
+        ch._step_static()
+        m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
+        meshes = self._compose((m1[0], m2[0]), (m1[1], m2[1]))
+        c = ch.static
+        self._render([c['hr1'][0:1], c['hr2'][0:1], c['hr2'][1:2]], meshes, out=st['out'])
 
     def _state(self):
-        keep = []
-        for c in (self.chain12, self.chain23):
-            keep += [c.static[k] for k in OnlineStitcher._STATE]
-        return keep + [self.watch_i, self.watch_f]
+        return [self.chains.static[k] for k in MultiOnlineStitcher._STATE] + [self.watch_i, self.watch_f]
 
     def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3):
-        a, b, st = self.chain12.static, self.chain23.static, self.static
-        if self.versions != self._versions():         # a net was reloaded / moved: stale twin trunks and graph
-            self.chain12.trunk_pair = self.chain23.trunk_pair = None
+        c, st = self.chains.static, self.static
+        if self.versions != self._versions():         # a net was reloaded / moved: stale twin trunk and graph
+            self.chains.trunk_pair = None
             self.graph = None
             self.versions = self._versions()
-        for dst, src in ((a['hr1'], hr1), (a['hr2'], hr2), (a['lr1'], lr1), (a['lr2'], lr2), (b['hr1'], hr2), (b['hr2'], hr3),
-                         (b['lr1'], lr2), (b['lr2'], lr3), (st['hr3'], hr3)):
+        for dst, src in ((c['hr1'][0:1], hr1), (c['hr1'][1:2], hr2), (c['hr2'][0:1], hr2), (c['hr2'][1:2], hr3),
+                         (c['lr1'][0:1], lr1), (c['lr1'][1:2], lr2), (c['lr2'][0:1], lr2), (c['lr2'][1:2], lr3)):
             dst.copy_(src.reshape(dst.shape))
         if not self.use_graph:
             self._step_static()
@@ -710,12 +722,12 @@ class ThreeViewOnlineStitcher:
         -> list of newly stitched frames (empty for the first 6 pushes, 7 frames on the 7th, then one per push)."""
         if self.static is not None:
             return self._push_static(hr1, hr2, hr3, lr1, lr2, lr3)
-        m12 = self.chain12.push(hr1, hr2, lr1, lr2)
-        m23 = self.chain23.push(hr2, hr3, lr2, lr3)
+        got = self.chains.push(torch.cat((hr1, hr2), 0), torch.cat((hr2, hr3), 0), torch.cat((lr1, lr2), 0), torch.cat((lr2, lr3), 0))
         self.ring_hr.append((hr1, hr2, hr3))
         self.frames_in += 1
-        if m12 is None:
+        if got is None:
             return []
+        m12, m23 = (got[0][0], got[1][0]), (got[0][1], got[1][1])                  # per chain: (m1, m2) [7,7,9,2]
         # first window complete: fix the first canvas and the output canvas, render its 7 frames, switch to the static step
         if self.first_canvas is None:
             k = m12[0].shape[0]
@@ -729,7 +741,6 @@ class ThreeViewOnlineStitcher:
         self.watch_i, self.watch_f = ops.canvas_watch_state(1, self.dev)
         frames = [self._render(list(hr), [m[:, i:i + 1] for m in meshes]) for i, hr in enumerate(self.ring_hr)]
         self.ring_hr = []
-        self.static = {'hr3': torch.empty((1, 3, self.h, self.w), device=self.dev),
-                       'out': torch.empty((3, self.hc, self.wc), device=self.dev)}
+        self.static = {'out': torch.empty((3, self.hc, self.wc), device=self.dev)}
         self.versions = self._versions()
         return frames
