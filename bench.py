@@ -564,6 +564,7 @@ def other_configs(nets, dev, args):
         st1.push(hr[0][i:i + 1], hr[1][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1])
     sync()
     dts = time.perf_counter() - t0
+    res['720p 2-view streaming (batch 1, one pair per push)']['canvas_overflow'] = st1.overflow_report()      # device-side watcher (read after the clock)
     res['720p 2-view streaming (batch 1, one pair per push)']['fps_steady'] = round(200 / dts, 1)
     res['720p 2-view streaming (batch 1, one pair per push)']['ms_per_push_steady'] = round(dts / 200 * 1e3, 4)
     del st1
