@@ -125,12 +125,14 @@ def lib():
 
 
 class HipError(RuntimeError):
-    pass
+    code = 0
 
 
 def check(code, what):
     if code != 0:
-        raise HipError('%s failed: %s (%d)' % (what, lib().ss_error_string(code).decode(), code))
+        err = HipError('%s failed: %s (%d)' % (what, lib().ss_error_string(code).decode(), code))
+        err.code = code
+        raise err
 
 
 class DevPtr(ctypes.c_void_p):

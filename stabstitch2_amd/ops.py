@@ -174,6 +174,20 @@ def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
                                             1 if forced else WINO43_MIN_CIN, 1 if forced else 0))
 
 
+def _try_wino43(x, wgt, bias, res, relu, out):
+    """ops.conv's use of the F(4x4,3x3) kernel.  The kernel needs 144 KB of LDS per workgroup; a device that cannot give it (not
+    gfx950) makes the library answer SS_ERR_UNSUPPORTED at the first launch, nothing has been launched then: the rule is switched off
+    for the process and the caller falls through to F(2x2,3x3) / the implicit GEMM.  -> the result, or None."""
+    global WINO43
+    try:
+        return conv_winograd43(x, wgt, bias, res, relu, out)
+    except H.HipError as e:
+        if e.code != -3 or WINO43 == '1':          # (SS_WINO43=1 = "force it": then the error is the answer)
+            raise
+        WINO43 = '0'
+        return None
+
+
 def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
     return bool(WINOGRAD and kt == 1 and tuple(pad) == (0, 1, 1) and
                 H.lib().ss_conv_uses_winograd(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho),
@@ -374,7 +388,9 @@ def conv(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=False, out=N
         shape = (n, to, ho, wo, cout) if five else (n, ho, wo, cout)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
     if not five and _uses_wino43(kt, kh, kw, stride, pad, c, cout, ho, wo, n):
-        return conv_winograd43(x, wgt, bias, res, relu, out)
+        y = _try_wino43(x, wgt, bias, res, relu, out)
+        if y is not None:
+            return y
     if not five and _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n):
         return conv_winograd(x, wgt, bias, res, relu, out)
     global last_conv_path
@@ -414,7 +430,9 @@ def conv_grouped(x, wgt, bias=None, res=None, stride=1, pad=(0, 1, 1), relu=Fals
         out = torch.empty((g, n, ho, wo, cout), device=x.device, dtype=torch.float32)
     assert tuple(out.shape) == (g, n, ho, wo, cout) and out.is_contiguous()
     if _uses_wino43(kt, kh, kw, stride, pad, c, cout, ho, wo, n, g):
-        return conv_winograd43(x, wgt, bias, res, relu, out)
+        y = _try_wino43(x, wgt, bias, res, relu, out)
+        if y is not None:
+            return y
     if _uses_winograd(kt, kh, kw, stride, pad, c, cout, ho, wo, n * g):
         return conv_winograd(x, wgt, bias, res, relu, out)
     global last_conv_path

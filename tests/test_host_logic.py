@@ -307,3 +307,28 @@ def test_wino43_dispatch_rule(monkeypatch):
     assert not yes(128, 128, 45, 60, 64)
     monkeypatch.setattr(ops, 'WINO43', '1')
     assert yes(256, 256, 23, 30, 1) and not yes(120, 128, 45, 60, 64)
+
+
+def test_wino43_capability_fallback(monkeypatch):
+    """A device that cannot give the F(4x4,3x3) kernel its 144 KB of LDS answers SS_ERR_UNSUPPORTED at the first launch (nothing has
+    been launched): ops.conv then switches the rule off for the process and takes the next kernel; with SS_WINO43=1 (forced) the error
+    is raised; any other error is raised."""
+    from stabstitch2_amd import ops, _hip
+
+    def refuse(code):
+        def f(*a, **k):
+            e = _hip.HipError('ss_conv3x3_wino43_nhwc failed (%d)' % code)
+            e.code = code
+            raise e
+        return f
+    monkeypatch.setattr(ops, 'WINO43', 'auto')
+    monkeypatch.setattr(ops, 'conv_winograd43', refuse(-3))
+    assert ops._try_wino43(None, None, None, None, False, None) is None and ops.WINO43 == '0'
+    monkeypatch.setattr(ops, 'WINO43', '1')
+    with pytest.raises(_hip.HipError):
+        ops._try_wino43(None, None, None, None, False, None)
+    monkeypatch.setattr(ops, 'WINO43', 'auto')
+    monkeypatch.setattr(ops, 'conv_winograd43', refuse(-2))
+    with pytest.raises(_hip.HipError):
+        ops._try_wino43(None, None, None, None, False, None)
+    assert ops.WINO43 == 'auto'
