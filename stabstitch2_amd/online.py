@@ -256,7 +256,7 @@ class OnlineStitcher:
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static
-        if self.grow == 'recapture':
+        if self.grow == 'recapture' and not self.meshes_only:
             self._poll_growth()
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
             # a net was reloaded / moved since the twin trunk was stacked and the graph captured: both hold the OLD
@@ -270,7 +270,8 @@ class OnlineStitcher:
         elif self.graph is None:
             # capture: the eager warm-up runs on a copy of the state so that this push is applied exactly once
             keep = {k: v.clone() for k, v in st.items() if k in self._STATE}
-            keep_w = (self.watch_i.clone(), self.watch_f.clone())       # (the watcher counts every run of the step)
+            # (the watcher counts every run of the step; meshes_only has no canvas and no watcher)
+            keep_w = None if self.meshes_only else (self.watch_i.clone(), self.watch_f.clone())
             side = _warmup_stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -278,7 +279,8 @@ class OnlineStitcher:
             torch.cuda.current_stream(self.dev).wait_stream(side)
             for k, v in keep.items():
                 st[k].copy_(v)
-            self.watch_i.copy_(keep_w[0]); self.watch_f.copy_(keep_w[1])
+            if keep_w is not None:
+                self.watch_i.copy_(keep_w[0]); self.watch_f.copy_(keep_w[1])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step_static()
@@ -289,6 +291,8 @@ class OnlineStitcher:
         else:
             self.graph.replay()
         self.frames_in += 1
+        if self.meshes_only:             # the newest smoothed meshes (m1, m2) [1,7,9,2]: copies, the step's own tensors are reused
+            return tuple(m.clone() for m in self.last_meshes)
         if self.grow == 'recapture':
             self._post_watch_copy()
         return [st['out'].clone()]
@@ -296,7 +300,8 @@ class OnlineStitcher:
     @torch.no_grad()
     def push(self, hr1, hr2, lr1, lr2):
         """One frame pair: hr* [1,3,H,W] (0..255), lr* [1,3,360,480] ([-1,1]), device tensors.
-        -> list of newly stitched frames (empty for the first 6 pushes, 7 frames on the 7th, then one per push)."""
+        -> list of newly stitched frames (empty for the first 6 pushes, 7 frames on the 7th, then one per push).
+        meshes_only: -> None for the first 6 pushes, then (m1, m2) [k,7,9,2] (k = 7 on the 7th push, then 1)."""
         if self.static is not None:
             return self._push_static(hr1, hr2, lr1, lr2)
         t = self.frames_in
@@ -444,7 +449,7 @@ class MultiOnlineStitcher:
     # ------------------------------------------------------------------ canvas overflow (per stream)
     def overflow_report(self):
         """Synchronises.  -> one dict per stream (OnlineStitcher.overflow_report)."""
-        if self.static is None:
+        if self.static is None or self.meshes_only:          # (meshes_only: no canvases, nothing to overflow -- the empty reports)
             return [one.overflow_report() for one in self.single]
         wi, wf = self.static['watch_i'].cpu(), self.static['watch_f'].cpu()
         reps = []
@@ -539,7 +544,7 @@ class MultiOnlineStitcher:
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static
-        if self.grow == 'recapture':
+        if self.grow == 'recapture' and not self.meshes_only:
             self._poll_growth()
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
             self.trunk_pair = None           # a net was reloaded / moved: restack the twin trunk and recapture
@@ -566,6 +571,8 @@ class MultiOnlineStitcher:
         else:
             self.graph.replay()
         self.frames_in += 1
+        if self.meshes_only:             # (m1, m2) [S,1,7,9,2]: copies of the step's own tensors
+            return tuple(m.clone() for m in self.last_meshes)
         if self.grow == 'recapture':
             self._post_watch_copy()
         return [[o.clone()] for o in st['out']]
