@@ -31,7 +31,8 @@ extern "C" {
 #define SS_OK 0
 #define SS_ERR_ARG (-1)          /* bad dimension / null pointer / unsupported combination */
 #define SS_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch */
-#define SS_ERR_UNSUPPORTED (-3)
+#define SS_ERR_UNSUPPORTED (-3)  /* this launch's sizes are outside what the kernel addresses; nothing was launched */
+#define SS_ERR_DEVICE (-4)       /* the DEVICE cannot run the kernel (e.g. no 144 KB of LDS per workgroup); nothing was launched */
 
 #define SS_WARP_NORMAL 0         /* the reference's clamped-index bilinear (utils/torch_tps_transform.py:30-106) */
 #define SS_WARP_FAST 1           /* F.grid_sample(bilinear, zeros, align_corners=True) (:158-162) */
@@ -143,7 +144,7 @@ SS_API long long ss_wino43_packed_floats(int cout, int cin);
  * ops._uses_wino43; the counterpart of ss_conv_uses_winograd): 1 when the geometry is one the kernel takes (1x3x3, stride 1,
  * cin % 16 == 0, cout % 64 == 0, 32-bit buffer offsets) AND the launch pays -- one 8 x 60-pixel x 64-channel tile per workgroup,
  * one workgroup per CU: >= min_wgs workgroups (<= 0: 512, two rounds of the chip), >= min_fill_pct % of the tile slots on real
- * pixels (<= 0: 85), cin >= min_cin (<= 0: 64); all three at 1 = wherever the kernel runs at all.  images = images per group,
+ * pixels (<= 0: 85 for the 8 x 60 geometry, 60 for the 16 x 32 one that serves maps <= 31 columns wide), cin >= min_cin (<= 0: 64); all three at 1 = wherever the kernel runs at all.  images = images per group,
  * groups = launch groups.  Results of the three 3x3 kernels agree to fp32
  * rounding, so the kernel choice (hence the launch size) shows in the last digits: pin it with min_wgs for reproducible runs. */
 SS_API int ss_conv_uses_wino43(int kt, int kh, int kw, int stride, int cin, int cout, int ho, int wo, int images, int groups,
@@ -348,6 +349,14 @@ SS_API int ss_three_view_finish(const float* n1, const float* n3, const float* m
  *   watch_f [streams][4] fp32  = running {xmin, xmax, ymin, ymax} of the normalised coordinates (what a grown canvas must cover)
  * Initialise to {0, 0, -1, 0} / {+inf, -inf, +inf, -inf}. */
 SS_API int ss_canvas_watch(const float* src, int streams, int views, float guard, int* watch_i, float* watch_f, void* stream);
+/* One streaming push's control points of ALL views + the watcher above in ONE launch (one wave per stream; a batch-1 push is
+ * bound by its launch count): meshes[v] = view v's newest LR-scale meshes, stream s at meshes[v] + s * mesh_frame_stride floats;
+ * bboxes [4] (bbox_frame_stride 0: one canvas) or [streams][4] (4: a canvas per stream); out [streams][views][63][2] = what `views`
+ * calls of ss_mesh_normalize_views(_boxes) write, bit for bit; watch_i / watch_f as ss_canvas_watch (both NULL: no watcher).
+ * A NaN control point counts as outside the canvas; a guard below the 2.5e-4 rounding slack makes `near` coincide with `outside`. */
+SS_API int ss_stream_normalize_watch(const float* const* meshes, int views, long long mesh_frame_stride, const float* bboxes,
+                              int bbox_frame_stride, float* out, int streams, float img_h, float img_w, float guard,
+                              int* watch_i, float* watch_f, void* stream);
 /* the same for view `view` of `views` of a clip, mesh [frames][63][2], written into the render's source layout
  * out [frames][views][63][2] (one call per view assembles it; test_online_tra.py:129-136) */
 SS_API int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,

@@ -87,6 +87,7 @@ SIGNATURES = {
     'ss_mesh_bbox': (c_i, [c_fp, c_i, c_f, c_f, c_fp, c_i, c_st]),
     'ss_mesh_normalize': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
     'ss_canvas_watch': (c_i, [c_fp, c_i, c_i, c_f, c_fp, c_fp, c_st]),
+    'ss_stream_normalize_watch': (c_i, [ctypes.c_void_p, c_i, c_ll, c_fp, c_i, c_fp, c_i, c_f, c_f, c_f, c_fp, c_fp, c_st]),
     'ss_mesh_normalize_views': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_st]),
     'ss_mesh_normalize_views_boxes': (c_i, [c_fp, c_ll, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_st]),
     'ss_fill_f32': (c_i, [c_fp, c_f, c_ll, c_st]),

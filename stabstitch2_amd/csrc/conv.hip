@@ -1071,6 +1071,7 @@ extern "C" const char* ss_error_string(int code) {
         case SS_ERR_ARG: return "bad argument";
         case SS_ERR_LAUNCH: return "kernel launch failed";
         case SS_ERR_UNSUPPORTED: return "unsupported size";
+        case SS_ERR_DEVICE: return "kernel not available on this device";
         default: return "unknown error";
     }
 }

@@ -668,33 +668,93 @@ extern "C" int ss_mesh_normalize_views_boxes(const float* mesh, long long mesh_f
 // canvas, index of the first such frame (-1), frames with a point closer than `guard` to an edge or outside}, watch_f [streams][4] =
 // running {xmin, xmax, ymin, ymax} of the normalised coordinates over all frames seen -- what a grown canvas must cover.  State
 // lives on the device and is only read when somebody asks (no sync on the push path); capturable (one fixed-size launch).
-__global__ __launch_bounds__(64) void canvas_watch_kernel(const float* __restrict__ src, int npts, float guard, int* __restrict__ watch_i,
-                                                          float* __restrict__ watch_f) {
-    const float* s = src + (long long)blockIdx.x * npts * 2;
-    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-    for (int i = threadIdx.x; i < npts; i += 64) {
-        const float x = s[2 * i], y = s[2 * i + 1];
-        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
-        ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
-    }
+// (the wave's running extremes, NaN flag OR-ed over the lanes -> the stream's watcher state; lane 0 writes)
+__device__ __forceinline__ void canvas_watch_update(float xmin, float xmax, float ymin, float ymax, bool bad, float guard, int* wi,
+                                                    float* wf) {
     xmin = ss_wave_min(xmin); xmax = ss_wave_max(xmax); ymin = ss_wave_min(ymin); ymax = ss_wave_max(ymax);
+    // fminf / fmaxf drop a NaN operand: a NaN control point would vanish from the extremes, so it is carried as a flag of its own
+    const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
     if (threadIdx.x == 0) {
-        int* wi = watch_i + blockIdx.x * 4;
-        float* wf = watch_f + blockIdx.x * 4;
         const float lo = fminf(xmin, ymin), hi = fmaxf(xmax, ymax);
         const int seen = wi[0];
-        // (half a pixel of a 4096-wide canvas: the canvas is the first window's OWN bbox when margin = 0, its extremes sit on +-1)
-        const bool out = lo < -1.0f - 2.5e-4f || hi > 1.0f + 2.5e-4f || !(lo == lo) || !(hi == hi);
-        const bool near = out || lo < -1.0f + guard || hi > 1.0f - guard;
+        // (half a pixel of a 4096-wide canvas: the canvas is the first window's OWN bbox when margin = 0, its extremes sit on +-1;
+        // `near` gets the same slack when the guard is smaller than it, else fp32 rounding alone would ask for a growth)
+        const float slack = 2.5e-4f;
+        const bool out = anybad || lo < -1.0f - slack || hi > 1.0f + slack;
+        const float g = guard > slack ? guard : -slack;
+        const bool near = out || lo < -1.0f + g || hi > 1.0f - g;
         if (out) { wi[1] += 1; if (wi[2] < 0) wi[2] = seen; }
         if (near) wi[3] += 1;
         wi[0] = seen + 1;
         wf[0] = fminf(wf[0], xmin); wf[1] = fmaxf(wf[1], xmax); wf[2] = fminf(wf[2], ymin); wf[3] = fmaxf(wf[3], ymax);
     }
 }
+
+__global__ __launch_bounds__(64) void canvas_watch_kernel(const float* __restrict__ src, int npts, float guard, int* __restrict__ watch_i,
+                                                          float* __restrict__ watch_f) {
+    const float* s = src + (long long)blockIdx.x * npts * 2;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    bool bad = false;
+    for (int i = threadIdx.x; i < npts; i += 64) {
+        const float x = s[2 * i], y = s[2 * i + 1];
+        bad = bad || x != x || y != y;
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+        ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+    }
+    canvas_watch_update(xmin, xmax, ymin, ymax, bad, guard, watch_i + blockIdx.x * 4, watch_f + blockIdx.x * 4);
+}
 extern "C" int ss_canvas_watch(const float* src, int streams, int views, float guard, int* watch_i, float* watch_f, void* stream) {
     if (!src || !watch_i || !watch_f || streams <= 0 || views <= 0 || !(guard >= 0.f)) return SS_ERR_ARG;
     hipLaunchKernelGGL(canvas_watch_kernel, dim3(streams), dim3(64), 0, (hipStream_t)stream, src, views * SS_NV, guard, watch_i, watch_f);
+    return ss_launch_status();
+}
+
+// The streaming push's normalisation of ALL views + the overflow watcher as ONE launch (round 6; it was `views` launches of
+// mesh_normalize_views_kernel + canvas_watch_kernel per push): one wave per stream, same arithmetic per point, same watcher update.
+struct StreamMeshes {
+    const float* m[3];
+};
+__global__ __launch_bounds__(64) void stream_normalize_watch_kernel(StreamMeshes ms, long long mesh_fs, const float* __restrict__ bbox,
+                                                                    int bbox_fs, float* __restrict__ out, int views, float img_h,
+                                                                    float img_w, float guard, int* __restrict__ watch_i,
+                                                                    float* __restrict__ watch_f) {
+    const int f = blockIdx.x;
+    const float* bb = bbox + (long long)f * bbox_fs;
+    const float wmin = bb[0], wmax = bb[1], hmin = bb[2], hmax = bb[3];
+    const float ow = __fsub_rn(wmax, wmin), oh = __fsub_rn(hmax, hmin);
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    bool bad = false;
+    for (int v = 0; v < views; ++v) {
+        const float* mesh = v == 0 ? ms.m[0] : (v == 1 ? ms.m[1] : ms.m[2]);
+        const int k = threadIdx.x;
+        if (k < SS_NV) {
+            const float* m = mesh + (long long)f * mesh_fs + k * 2;
+            const float x = img_w > 0.f ? __fmul_rn(m[0], img_w) / 480.0f : m[0];
+            const float y = img_h > 0.f ? __fmul_rn(m[1], img_h) / 360.0f : m[1];
+            const float nx = norm1(__fsub_rn(x, wmin), ow), ny = norm1(__fsub_rn(y, hmin), oh);
+            float* o = out + (((long long)f * views + v) * SS_NV + k) * 2;
+            o[0] = nx;
+            o[1] = ny;
+            bad = bad || nx != nx || ny != ny;
+            xmin = fminf(xmin, nx); xmax = fmaxf(xmax, nx);
+            ymin = fminf(ymin, ny); ymax = fmaxf(ymax, ny);
+        }
+    }
+    if (watch_i) canvas_watch_update(xmin, xmax, ymin, ymax, bad, guard, watch_i + f * 4, watch_f + f * 4);
+}
+extern "C" int ss_stream_normalize_watch(const float* const* meshes, int views, long long mesh_frame_stride, const float* bboxes,
+                                         int bbox_frame_stride, float* out, int streams, float img_h, float img_w, float guard,
+                                         int* watch_i, float* watch_f, void* stream) {
+    if (!meshes || !bboxes || !out || streams <= 0 || views <= 0 || views > 3 || mesh_frame_stride < 0 ||
+        (bbox_frame_stride != 0 && bbox_frame_stride != 4) || !(guard >= 0.f) || (!watch_i != !watch_f))
+        return SS_ERR_ARG;
+    StreamMeshes ms;
+    for (int v = 0; v < 3; ++v) {
+        ms.m[v] = v < views ? meshes[v] : nullptr;
+        if (v < views && !ms.m[v]) return SS_ERR_ARG;
+    }
+    hipLaunchKernelGGL(stream_normalize_watch_kernel, dim3(streams), dim3(64), 0, (hipStream_t)stream, ms, mesh_frame_stride, bboxes,
+                       bbox_frame_stride, out, views, img_h, img_w, guard, watch_i, watch_f);
     return ss_launch_status();
 }
 extern "C" int ss_mesh_normalize_views(const float* mesh, const float* bbox, float* out, int frames, int view, int views,

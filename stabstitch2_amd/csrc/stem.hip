@@ -349,14 +349,15 @@ __global__ __launch_bounds__(256, 4) void stem_pool_kernel_half(StemP p) {
             dst += 6 * SP_PITCH;
         }
     }
-    int abase[4], abase3[4];
+    // (the 6-k group of a filter row starts at abase + 16 - h2 = row base + 16 + 3 h2: derived where it is used -- four registers
+    // less; at 128 registers for four workgroups per CU the allocator had parked seven values in scratch)
+    int abase[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         int m = 32 * (4 * wave + mt) + ln;
         m = m < SP_M ? m : SP_M - 1;
         const int r = m / SP_CC, c = m - r * SP_CC;
         abase[mt] = (2 * r) * SP_PITCH + 6 * c + 4 * h2;
-        abase3[mt] = (2 * r) * SP_PITCH + 6 * c + 16 + 3 * h2;
     }
     const unsigned pk_lane = (unsigned)lane * 16u;
     const unsigned pk_grp = grp * (2u * SP_NG * 1024u) + nt0 * (SP_NG * 1024u);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256, 4) void stem_pool_kernel_half(StemP p) {
         if (g % 3 == 2) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const float* ap = smem + abase3[mt] + (g / 3) * SP_PITCH;
+                const float* ap = smem + abase[mt] + (16 - h2) + (g / 3) * SP_PITCH;
                 a[mt] = (sp_f32x4){ap[0], ap[1], ap[2], 0.f};
             }
         } else {
@@ -404,24 +405,33 @@ __global__ __launch_bounds__(256, 4) void stem_pool_kernel_half(StemP p) {
     }
     __builtin_amdgcn_s_setprio(3);
     __syncthreads();
-    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    // this image's pooled map as a buffer: the store address is one 32-bit offset per item (a 64-bit pointer per item was one of
+    // the values parked in scratch), stores outside the map are dropped by the descriptor
+    const __amdgpu_buffer_rsrc_t rout = sp_rsrc(p.out + (long long)grp * p.out_gs + (long long)img * p.hp * p.wp * 64,
+                                                (unsigned)(p.hp * p.wp) * 256u);
     const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + SP_CR <= p.ho && cx0 + SP_CC <= p.wo;
+    // The thread's identity is re-derived here (lane = v_mbcnt, wave from its SGPR) instead of being kept from the kernel's entry:
+    // tid, lane & 31 and the row offsets derived from them were the values the allocator carried across the K loop in SCRATCH
+    // (7 registers, 24 bytes per lane, a scratch_load inside the unrolled MFMA stream).
+    const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int etid = wave * 64 + elane;
+    const int eh2 = elane >> 5, eln = elane & 31;
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp) {                       // channels 32 nt0 + 16 qp .. + 15
-        if ((ln >> 4) == qp) {
+        if ((eln >> 4) == qp) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * (4 * wave + mt) + 8 * (r >> 2) + (r & 3) + 4 * h2;
-                    smem[row * 16 + (ln & 15)] = acc[mt][r];
+                    const int row = 32 * (4 * wave + mt) + 8 * (r >> 2) + (r & 3) + 4 * eh2;
+                    smem[row * 16 + (eln & 15)] = acc[mt][r];
                 }
         }
         __syncthreads();
         const int cbase = 32 * (int)nt0 + 16 * qp;
 #pragma unroll
         for (int it = 0; it < (SP_PR * SP_PC * 4 + 255) / 256; ++it) {
-            const int item = tid + 256 * it;
+            const int item = etid + 256 * it;
             const int q = item & 3;
             int pp = item >> 2;
             pp = pp < SP_PR * SP_PC ? pp : SP_PR * SP_PC - 1;
@@ -452,8 +462,9 @@ __global__ __launch_bounds__(256, 4) void stem_pool_kernel_half(StemP p) {
             if (p.bias) bb = *reinterpret_cast<const sp_f32x4*>(p.bias + grp * 64 + cbase + 4 * q);
 #pragma unroll
             for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k] + bb[k], 0.f);
-            if (item < SP_PR * SP_PC * 4 && py < p.hp && px < p.wp)
-                *reinterpret_cast<sp_f32x4*>(out + (((long long)img * p.hp + py) * p.wp + px) * 64 + cbase + 4 * q) = mx;
+            const bool ok = item < SP_PR * SP_PC * 4 && py < p.hp && px < p.wp;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sp_u32x4, mx), rout,
+                                                   ok ? (unsigned)(((py * p.wp + px) * 64 + cbase + 4 * q) * 4) : 0xFFFFFFFFu, 0, 0);
         }
         if (qp == 0) __syncthreads();
     }

@@ -701,7 +701,7 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
             attr_state[dev].store(ok ? 2 : 3, std::memory_order_release);
         }
         while ((st8 = attr_state[dev].load(std::memory_order_acquire)) == 1) std::this_thread::yield();
-        if (st8 != 2) return SS_ERR_UNSUPPORTED;       // the device cannot give a workgroup 144 KB of LDS (not gfx950)
+        if (st8 != 2) return SS_ERR_DEVICE;            // the device cannot give a workgroup 144 KB of LDS (not gfx950)
     }
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;

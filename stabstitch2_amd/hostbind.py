@@ -160,7 +160,8 @@ def bind_to_gpu(device, local_rank=None, local_world=None, share=0):
 
 
 def report(device=None):
-    """What `bind_to_gpu` did for `device` (or the last call), for the bench line."""
-    if device is not None and str(device) in _bound:
-        return _bound[str(device)]
+    """What `bind_to_gpu` did for `device` (None if it was never called for THAT device: a process driving several GPUs binds per
+    device, an earlier GPU's node is no answer for a later one); device=None: the last call, for the bench line."""
+    if device is not None:
+        return _bound.get(str(device))
     return next(reversed(_bound.values()), None) if _bound else None

@@ -148,6 +148,12 @@ class OnlineStitcher:
         the steady-state graph captured again at the next push."""
         x0, x1, y0, y1 = self._needed_bbox(wf)
         gw, gh = self.margin * (x1 - x0), self.margin * (y1 - y0)
+        old = [float(v) for v in self.bbox.cpu()]
+        if max(abs(a - b) for a, b in zip(old, (x0 - gw, x1 + gw, y0 - gh, y1 + gh))) < 0.5:
+            # nothing to grow by (e.g. margin 0 and a mesh that only touches the edge): keep the canvas, the output buffer and the
+            # captured graph -- a recapture costs a sync, an allocation and a capture, and would be asked for again next push
+            self._near_handled = int(wi[3])
+            return False
         seen, clipped, first = self._watch_totals
         if wi[1] > 0 and first < 0:
             first = seen + wi[2]
@@ -158,6 +164,7 @@ class OnlineStitcher:
         if self.static is not None:
             self.static['out'] = torch.empty((3, self.hc, self.wc), device=self.dev)
         self.graph = None
+        return True
 
     def _poll_growth(self):
         """Start of a steady-state push (grow='recapture'): look at the watcher state of the push before, copied to pinned memory
@@ -180,8 +187,8 @@ class OnlineStitcher:
     @torch.no_grad()
     def _render(self, hr1, hr2, mesh1, mesh2, out=None):
         """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc] (written to `out` if given)."""
-        src4 = ops.mesh_normalize_views([mesh1, mesh2], self.bbox, self.h, self.w)            # [1,2,63,2]
-        ops.canvas_watch(src4, self.watch_i, self.watch_f, self._guard())
+        src4 = ops.stream_normalize_watch([mesh1, mesh2], 126, self.bbox, self.h, self.w, self._guard(), self.watch_i,
+                                          self.watch_f)                                      # [1,2,63,2], watcher updated
         src = src4[0]
         T = ops.tps_solve_shared(src, self.nrigid)
         return self._render_solved(hr1, hr2, src, T, out)
@@ -472,19 +479,23 @@ class MultiOnlineStitcher:
         if self._host_event is None or not self._host_event.query():
             return
         near = self._host_watch[0][:, 3].tolist()
-        grown = [s for s, one in enumerate(self.single) if near[s] > 0]
-        if not grown:
+        cand = [s for s, one in enumerate(self.single) if near[s] > one._near_handled]
+        if not cand:
             return
         st = self.static
         wi, wf = st['watch_i'].cpu(), st['watch_f'].cpu()              # (rare path: synchronises)
         fresh_i, fresh_f = ops.canvas_watch_state(1, self.dev)
-        for s in grown:
+        grown = False
+        for s in cand:
             one = self.single[s]
-            one._regrow(wi[s].tolist(), wf[s])
+            if not one._regrow(wi[s].tolist(), wf[s]):                 # nothing to grow by: canvas, outputs and graph stay
+                continue
+            grown = True
             st['bboxes'][s].copy_(one.bbox)
             st['watch_i'][s].copy_(fresh_i[0]); st['watch_f'][s].copy_(fresh_f[0])
-        self._alloc_outputs()
-        self.graph = None
+        if grown:
+            self._alloc_outputs()
+            self.graph = None
         self._host_event = None
 
     def _post_watch_copy(self):
@@ -527,8 +538,8 @@ class MultiOnlineStitcher:
             return
         # every stream's newest smoothed mesh on its own canvas: one normalisation launch per view and ONE batched TPS solve for
         # the 2 S splines (a solve is latency-bound, ~48 us whether it holds 2 systems or 16), then the render stream by stream
-        src = ops.mesh_normalize_views_boxes([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w)     # [S,2,63,2]
-        ops.canvas_watch(src, st['watch_i'], st['watch_f'], self.single[0]._guard())
+        src = ops.stream_normalize_watch([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w, self.single[0]._guard(),
+                                         st['watch_i'], st['watch_f'])                                             # [S,2,63,2]
         T = ops.tps_solve_shared(src.view(2 * S, 63, 2), self.single[0].nrigid).view(S, 2, 2, 66)
         if st['out_all'] is not None:
             # all streams render onto canvases of ONE size (e.g. the caller fixed them): the S current frames are a clip
@@ -651,8 +662,8 @@ class ThreeViewOnlineStitcher:
 
     def _render(self, imgs, meshes, out=None):
         """imgs: three [1,3,H,W]; meshes: (mesh1, middle, mesh3) [1,1,7,9,2] in first-canvas pixels -> [3,Hc,Wc]."""
-        src4 = ops.mesh_normalize_views(list(meshes), self.bbox, 0.0, 0.0)            # [1,3,63,2] on the output canvas
-        ops.canvas_watch(src4, self.watch_i, self.watch_f, 0.0)
+        src4 = ops.stream_normalize_watch([m.contiguous() for m in meshes], 126, self.bbox, 0.0, 0.0, self._guard(), self.watch_i,
+                                          self.watch_f)                              # [1,3,63,2] on the output canvas
         src = src4[0]
         T = ops.tps_solve_shared(src, self.nrigid)
         if self.fusion_mode == 'AVERAGE':
@@ -663,7 +674,10 @@ class ThreeViewOnlineStitcher:
         res = ops.linear_blend(f, w[2, 0:3], ops.mask_union(w[0, 3], w[1, 3]), w[2, 3])
         return res if out is None else out.copy_(res)
 
-    # ------------------------------------------------------------------ overflow (as OnlineStitcher, no growth)
+    # ------------------------------------------------------------------ overflow (as OnlineStitcher)
+    def _guard(self):
+        return max(0.0, float(self.margin)) * 0.5 / (1.0 + 2.0 * max(0.0, float(self.margin))) * 2.0
+
     def overflow_report(self):
         rep = {'frames_seen': 0, 'clipped_frames': 0, 'first_clipped_frame': -1, 'near_frames': 0, 'canvas_epoch': 0}
         if self.watch_i is not None:

@@ -174,17 +174,23 @@ def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
                                             1 if forced else WINO43_MIN_CIN, 1 if forced else 0))
 
 
+_WINO43_REFUSED = set()      # device indices whose first F(4x4,3x3) launch answered SS_ERR_DEVICE (no 144 KB of LDS per workgroup)
+
+
 def _try_wino43(x, wgt, bias, res, relu, out):
     """ops.conv's use of the F(4x4,3x3) kernel.  The kernel needs 144 KB of LDS per workgroup; a device that cannot give it (not
-    gfx950) makes the library answer SS_ERR_UNSUPPORTED at the first launch, nothing has been launched then: the rule is switched off
-    for the process and the caller falls through to F(2x2,3x3) / the implicit GEMM.  -> the result, or None."""
-    global WINO43
+    gfx950) makes the library answer SS_ERR_DEVICE at the first launch, nothing has been launched then: THAT device is remembered
+    and its layers go to F(2x2,3x3) / the implicit GEMM from now on (other devices of the process keep the kernel).  A launch whose
+    sizes the kernel cannot address (SS_ERR_UNSUPPORTED) falls through for this launch only.  -> the result, or None."""
+    if x.device.index in _WINO43_REFUSED:
+        return None
     try:
         return conv_winograd43(x, wgt, bias, res, relu, out)
     except H.HipError as e:
-        if e.code != -3 or WINO43 == '1':          # (SS_WINO43=1 = "force it": then the error is the answer)
+        if e.code not in (-3, -4) or WINO43 == '1':          # (SS_WINO43=1 = "force it": then the error is the answer)
             raise
-        WINO43 = '0'
+        if e.code == -4:
+            _WINO43_REFUSED.add(x.device.index)
         return None
 
 
@@ -895,6 +901,21 @@ def canvas_watch(src, watch_i, watch_f, guard):
     s, v = src.shape[0], src.shape[1]
     assert src.is_contiguous() and tuple(watch_i.shape) == (s, 4) and tuple(watch_f.shape) == (s, 4)
     H.call('ss_canvas_watch', H.dptr(src), s, v, float(guard), H.dptr(watch_i, dtype=torch.int32), H.dptr(watch_f), H.stream())
+
+
+def stream_normalize_watch(meshes, frame_stride, bboxes, img_h, img_w, guard=0.0, watch_i=None, watch_f=None):
+    """One push's render control points of all views + the overflow watcher in ONE launch: meshes = V tensors whose stream s starts
+    `frame_stride` floats after stream s - 1; bboxes [4] (one canvas) or [S,4] (a canvas per stream) -> [S,V,63,2]; equal, bit for
+    bit, to mesh_normalize_views(_boxes) (+ canvas_watch when the watcher state is given)."""
+    v = len(meshes)
+    s = 1 if bboxes.dim() == 1 else bboxes.shape[0]
+    for m in meshes:
+        assert m.is_contiguous() and m.dtype == torch.float32
+    out = torch.empty((s, v, 63, 2), device=bboxes.device, dtype=torch.float32)
+    arr = H.ptr_array(list(meshes))
+    H.call('ss_stream_normalize_watch', arr, v, int(frame_stride), H.dptr(bboxes), 0 if bboxes.dim() == 1 else 4, H.dptr(out), s,
+           float(img_h), float(img_w), float(guard), H.dptr(watch_i, True, dtype=torch.int32), H.dptr(watch_f, True), H.stream())
+    return out
 
 
 def mesh_normalize_views_boxes(meshes, frame_stride, bboxes, img_h, img_w):

@@ -710,7 +710,11 @@ class HostClipRunner:
     uint8 tensor [N,Hc,Wc,3], Hc, Wc) one clip late at most; a yielded tensor stays valid until `depth` more clips
     have been yielded."""
 
-    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', depth=2, streams=None, prefetch=2):
+    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', depth=2, streams=None, prefetch=2,
+                 numa_bind=False):
+        """numa_bind: True = pin the CALLING thread (and the threads it starts later) to the CPUs of this GPU's NUMA node and prefer
+        that node for memory before the pinned buffers are allocated (hostbind.bind_to_gpu: process-affecting, so it is the
+        application's decision -- bench.py binds every rank itself; measured irrelevant on the MI355X hosts of this pool)."""
         self.nets, self.dev = nets, torch.device(device)
         self.warp_mode, self.fusion_mode, self.depth = warp_mode, fusion_mode, depth
         self.up, self.comp, self.down = streams if streams is not None else io_streams(self.dev)
@@ -729,11 +733,12 @@ class HostClipRunner:
         # 3070-3570 frames/s spread of the bench's run totals at an unchanged steady state).
         self._in, self._in_free, self._in_k, self._in_gen = [], [], 0, 0
         self._out, self._out_done, self._out_k = [], [], 0
-        # host placement (hostbind): the pinned result slots and torch's copy threads belong on the GPU's NUMA node.  Done here,
-        # before anything is pinned, unless the process bound itself already (bench.py does, per rank) or SS_NUMA_BIND=0.
-        from . import hostbind
-        if self.dev.type == 'cuda' and hostbind.report(self.dev) is None:
-            hostbind.bind_to_gpu(self.dev)
+        # host placement (hostbind): opt-in, before anything is pinned; a process that bound itself to THIS device already (bench.py
+        # does, per rank) is left alone
+        if numa_bind and self.dev.type == 'cuda':
+            from . import hostbind
+            if hostbind.report(self.dev) is None:
+                hostbind.bind_to_gpu(self.dev)
 
     class _Staged(list):
         slot = None
@@ -914,11 +919,11 @@ class LongVideoStitcher:
     kernel per launch size (ss_conv_uses_wino43 / ss_conv_uses_winograd / split-K), and another chunk length sums in another order
     (~1e-5 px; set SS_WINO43_MIN_WGS=1 to pin the kernel choice per layer) -- hence so do the canvas and the frames."""
 
-    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', chunk=None):
+    def __init__(self, nets, device='cuda', warp_mode='NORMAL', fusion_mode='AVERAGE', chunk=None, numa_bind=False):
         self.nets, self.dev = nets, torch.device(device)
         self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
         self.chunk = chunk or SPATIAL_CHUNK
-        self.io = HostClipRunner(nets, device, warp_mode, fusion_mode)
+        self.io = HostClipRunner(nets, device, warp_mode, fusion_mode, numa_bind=numa_bind)
         self.acc = self.meshes = self.bbox = self.hc = self.wc = None
         self.prescaled = False
 

@@ -1,0 +1,103 @@
+"""Round-6 GPU tests: the streaming push's fused normalisation + watcher, meshes_only streams past their first window, the
+three-view stream against the oracle.
+    python -m pytest tests -m gpu"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from stabstitch2_amd import synth
+from test_gpu_parity import dev, hip_nets, close, close_boxes, clip16  # noqa: F401  (fixtures / helpers)
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stream_normalize_watch_equals_the_separate_launches(dev):
+    """ss_stream_normalize_watch (one launch per push) == ss_mesh_normalize_views(_boxes) per view + ss_canvas_watch, bit for bit:
+    control points and watcher state, one canvas and a canvas per stream, two and three views; a NaN control point counts as
+    outside the canvas (fminf / fmaxf dropped it); a guard below the rounding slack makes `near` coincide with `out`."""
+    from stabstitch2_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(11)
+    for S, V, boxes in ((1, 2, False), (1, 3, False), (5, 2, True)):
+        rigid = torch.stack(torch.meshgrid(torch.linspace(0, 360, 7), torch.linspace(0, 480, 9), indexing='ij'), -1).flip(-1)
+        meshes = [(rigid[None, None] + 9 * torch.randn((S, 7, 7, 9, 2), generator=g)).to(dev).contiguous() for _ in range(V)]
+        newest = [m[0, -1] for m in meshes]                       # stream 0's newest mesh; stream s is 7 * 126 floats further
+        if boxes:
+            bb = torch.tensor([[-20.0 - s, 1300.0 + 3 * s, -15.0, 745.0 + s] for s in range(S)], device=dev)
+        else:
+            bb = torch.tensor([-20.0, 1300.0, -15.0, 745.0], device=dev)
+        for guard in (0.0, 0.02):
+            wi0, wf0 = ops.canvas_watch_state(S, dev)
+            wi1, wf1 = ops.canvas_watch_state(S, dev)
+            for _ in range(3):                                     # the watcher accumulates over pushes
+                if boxes:
+                    ref = ops.mesh_normalize_views_boxes(newest, 7 * 126, bb, 720, 1280)
+                else:
+                    ref = ops.mesh_normalize_views([m[0, -1:] for m in meshes], bb, 720, 1280)
+                ops.canvas_watch(ref, wi0, wf0, guard)
+                got = ops.stream_normalize_watch(newest, 7 * 126, bb, 720, 1280, guard, wi1, wf1)
+                assert torch.equal(got, ref)
+                assert torch.equal(wi0, wi1) and torch.equal(wf0, wf1)
+            assert int(wi1[0, 0]) == 3
+    # a NaN control point: outside (both kernels), whatever the other points say
+    m = [rigid[None].to(dev).contiguous(), rigid[None].to(dev).clone().contiguous()]
+    m[1][0, 3, 4, 1] = float('nan')
+    bb = torch.tensor([-10.0, 1290.0, -10.0, 730.0], device=dev)
+    wi, wf = ops.canvas_watch_state(1, dev)
+    src = ops.stream_normalize_watch(m, 126, bb, 720, 1280, 0.0, wi, wf)
+    assert wi[0].tolist() == [1, 1, 0, 1]
+    wi2, wf2 = ops.canvas_watch_state(1, dev)
+    ops.canvas_watch(src, wi2, wf2, 0.0)
+    assert wi2[0].tolist() == [1, 1, 0, 1]
+    # a mesh that touches the edge of its own bbox (margin 0): inside, and with guard 0 not `near` either
+    m = [rigid[None].to(dev).contiguous(), rigid[None].to(dev).contiguous()]
+    bb = torch.tensor([0.0, 1280.0, 0.0, 720.0], device=dev)
+    wi, wf = ops.canvas_watch_state(1, dev)
+    ops.stream_normalize_watch(m, 126, bb, 720, 1280, 0.0, wi, wf)
+    assert wi[0].tolist() == [1, 0, -1, 0]
+    wi, wf = ops.canvas_watch_state(1, dev)
+    ops.stream_normalize_watch(m, 126, bb, 720, 1280, 0.01, wi, wf)
+    assert wi[0].tolist() == [1, 0, -1, 1]
+
+
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_meshes_only_streams_past_the_first_window(dev, hip_nets, clip16, use_graph):
+    """`push` of a meshes_only stitcher crashed after the first window (st['out'] / watch_i are None in that
+    mode).  12 pairs through OnlineStitcher and MultiOnlineStitcher(streams=2) with meshes_only=True: None for six pushes, 7 meshes
+    on the 7th, then one per push -- equal to the offline clip's smoothed meshes (same sliding windows) within the kernel-choice
+    tolerance, graph and eager alike."""
+    from stabstitch2_amd import pipeline
+    from stabstitch2_amd.online import OnlineStitcher, MultiOnlineStitcher
+    hr, lr = clip16
+    n = 12
+    d = lambda frames: torch.cat([f.to(dev) for f in frames[:n]], 0)
+    H1, H2, L1, L2 = d(hr[0]), d(hr[1]), d(lr[0]), d(lr[1])
+    _, _, _, m1, m2 = pipeline.run_two_view(H1, H2, L1, L2, hip_nets)            # [1,n,7,9,2]
+    st = OnlineStitcher(hip_nets, 360, 480, use_graph=use_graph, meshes_only=True)
+    got1, got2 = [], []
+    for t in range(n):
+        r = st.push(H1[t:t + 1], H2[t:t + 1], L1[t:t + 1], L2[t:t + 1])
+        if t < 6:
+            assert r is None
+            continue
+        assert r[0].shape[0] == (7 if t == 6 else 1) and tuple(r[0].shape[1:]) == (7, 9, 2)
+        got1.append(r[0].clone()); got2.append(r[1].clone())
+    g1, g2 = torch.cat(got1, 0), torch.cat(got2, 0)
+    assert g1.shape[0] == n
+    assert float((g1 - m1[0]).abs().max()) < 2e-3 and float((g2 - m2[0]).abs().max()) < 2e-3
+    assert st.overflow_report()['frames_seen'] == 0                # no canvas, nothing watched
+    ms = MultiOnlineStitcher(hip_nets, 360, 480, streams=2, use_graph=use_graph, meshes_only=True)
+    got = []
+    for t in range(n):
+        r = ms.push(torch.cat((H1[t:t + 1], H2[t:t + 1])), torch.cat((H2[t:t + 1], H1[t:t + 1])),
+                    torch.cat((L1[t:t + 1], L2[t:t + 1])), torch.cat((L2[t:t + 1], L1[t:t + 1])))
+        if t < 6:
+            assert r is None
+            continue
+        assert tuple(r[0].shape) == (2, 7 if t == 6 else 1, 7, 9, 2)
+        got.append(r[0][0].clone())                                # stream 0 = the pair above, view 1
+    assert float((torch.cat(got, 0) - m1[0]).abs().max()) < 2e-3
+    assert [rep['frames_seen'] for rep in ms.overflow_report()] == [0, 0]

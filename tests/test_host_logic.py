@@ -51,6 +51,36 @@ def test_cabi_exports_exactly_the_declared_symbols(built_lib):
     assert need > 0 and need % (32 * 5 * 7 * 256) == 0
 
 
+def test_no_matrix_kernel_spills_or_uses_scratch(built_lib):
+    """Every gfx950 code object of the built library, read back from its metadata notes (tools/kernel_resources.py): a kernel that
+    issues MFMA instructions must have .vgpr_spill_count = .sgpr_spill_count = 0 and no private segment.  Twice a spill shipped
+    unnoticed (round 4: 47 registers of conv_wino43_kernel, 114 KB of scratch stores per workgroup; round 5: 7 of
+    stem_pool_kernel_half with a scratch_load inside its MFMA stream)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    from stabstitch2_amd import _hip
+    if not os.path.exists(os.path.join(kernel_resources.LLVM, 'llvm-readelf')):
+        pytest.skip('no llvm-readelf in this image')
+    ks = kernel_resources.kernels(_hip.LIB_PATH)
+    mfma = {k: v for k, v in ks.items() if v['mfma_instructions'] > 0}
+    assert len(ks) >= 60 and len(mfma) >= 30, (len(ks), len(mfma))
+    for want in ('conv_igemm_kernel', 'conv_wino_kernel', 'conv_wino43_kernel', 'stem_pool_kernel_half'):
+        assert any(want in k for k in mfma), want
+    bad = {k: (v.get('.vgpr_spill_count', 0), v.get('.sgpr_spill_count', 0), v.get('.private_segment_fixed_size', 0))
+           for k, v in mfma.items()
+           if v.get('.vgpr_spill_count', 0) or v.get('.sgpr_spill_count', 0) or v.get('.private_segment_fixed_size', 0)}
+    assert not bad, 'MFMA kernels with spills / scratch (vgpr spills, sgpr spills, scratch bytes): %s' % bad
+    # the register budgets the occupancy arguments of DESIGN.md rest on
+    half = next(v for k, v in ks.items() if 'stem_pool_kernel_half' in k)
+    assert half['.vgpr_count'] + half.get('.agpr_count', 0) <= 128          # four workgroups of 256 threads per CU
+    for k, v in ks.items():
+        if 'conv_wino43_kernel' in k:
+            assert v['.vgpr_count'] <= 256 and v.get('.vgpr_spill_count', 0) == 0, k
+
+
 def test_product_never_imports_oracle_and_fails_without_gpu():
     pkg = os.path.join(ROOT, 'stabstitch2_amd')
     for dirpath, _, files in os.walk(pkg):
@@ -310,10 +340,15 @@ def test_wino43_dispatch_rule(monkeypatch):
 
 
 def test_wino43_capability_fallback(monkeypatch):
-    """A device that cannot give the F(4x4,3x3) kernel its 144 KB of LDS answers SS_ERR_UNSUPPORTED at the first launch (nothing has
-    been launched): ops.conv then switches the rule off for the process and takes the next kernel; with SS_WINO43=1 (forced) the error
-    is raised; any other error is raised."""
+    """A device that cannot give the F(4x4,3x3) kernel its 144 KB of LDS answers SS_ERR_DEVICE at the first launch (nothing has been
+    launched): ops.conv remembers THAT device (others keep the kernel, the process-wide switch is untouched) and takes the next
+    kernel; a launch the kernel cannot address (SS_ERR_UNSUPPORTED) falls through for that launch only; with SS_WINO43=1 (forced)
+    either error is raised; any other error is raised."""
     from stabstitch2_amd import ops, _hip
+
+    class X:                       # stands in for a tensor: only .device.index is looked at before the launch
+        def __init__(self, index):
+            self.device = type('D', (), {'index': index})()
 
     def refuse(code):
         def f(*a, **k):
@@ -322,13 +357,23 @@ def test_wino43_capability_fallback(monkeypatch):
             raise e
         return f
     monkeypatch.setattr(ops, 'WINO43', 'auto')
+    monkeypatch.setattr(ops, '_WINO43_REFUSED', set())
     monkeypatch.setattr(ops, 'conv_winograd43', refuse(-3))
-    assert ops._try_wino43(None, None, None, None, False, None) is None and ops.WINO43 == '0'
+    assert ops._try_wino43(X(0), None, None, None, False, None) is None
+    assert ops.WINO43 == 'auto' and not ops._WINO43_REFUSED          # one odd launch switches nothing off
+    monkeypatch.setattr(ops, 'conv_winograd43', refuse(-4))
+    assert ops._try_wino43(X(1), None, None, None, False, None) is None
+    assert ops.WINO43 == 'auto' and ops._WINO43_REFUSED == {1}
+    calls = []
+    monkeypatch.setattr(ops, 'conv_winograd43', lambda *a, **k: calls.append(1) or 'ran')
+    assert ops._try_wino43(X(1), None, None, None, False, None) is None and not calls       # device 1: not tried again
+    assert ops._try_wino43(X(0), None, None, None, False, None) == 'ran'                    # device 0 keeps the kernel
     monkeypatch.setattr(ops, 'WINO43', '1')
+    monkeypatch.setattr(ops, 'conv_winograd43', refuse(-4))
     with pytest.raises(_hip.HipError):
-        ops._try_wino43(None, None, None, None, False, None)
+        ops._try_wino43(X(0), None, None, None, False, None)
     monkeypatch.setattr(ops, 'WINO43', 'auto')
     monkeypatch.setattr(ops, 'conv_winograd43', refuse(-2))
     with pytest.raises(_hip.HipError):
-        ops._try_wino43(None, None, None, None, False, None)
+        ops._try_wino43(X(0), None, None, None, False, None)
     assert ops.WINO43 == 'auto'
