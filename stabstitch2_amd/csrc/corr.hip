@@ -408,8 +408,14 @@ extern "C" int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float*
     float* n2 = n1 + (long long)n * P * c;
     float* Dm = n2 + (long long)n * P * c;
     long long npix = (long long)n * P;
-    hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(npix, 4)), dim3(256), 0, st, f1, n1, npix, c);
-    hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(npix, 4)), dim3(256), 0, st, f2, n2, npix, c);
+    if (f2 == f1 + npix * c) {
+        // the two views' maps are the halves of one tensor (SpatialNet's trunk output, view 1 first) and n1 / n2 are adjacent in
+        // the workspace: one launch normalises both (a batch-1 push pays per launch)
+        hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(2 * npix, 4)), dim3(256), 0, st, f1, n1, 2 * npix, c);
+    } else {
+        hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(npix, 4)), dim3(256), 0, st, f1, n1, npix, c);
+        hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(npix, 4)), dim3(256), 0, st, f2, n2, npix, c);
+    }
     int rc = ss_launch_status();
     if (rc) return rc;
     // D[p][k] = sum_c n1[p][c] n2[k][c]: "image" = n1 as a 1 x P strip, "filters" = n2 rows, one group per batch item

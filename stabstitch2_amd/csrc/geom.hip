@@ -558,12 +558,64 @@ __global__ __launch_bounds__(256) void tsm_finish_kernel(const float* __restrict
     tsmotion[o + 1] = __fsub_rn(recover1(oy, img_h), smesh[o + 1]);
 }
 
+// tsm_prepare_kernel + tsm_finish_kernel as ONE launch where the rigid-mesh inverse is at hand (round 6: the streaming push pays
+// >= 4.5 us per launch whatever it does).  Frame k needs nothing another block computes: its target is frame k - lag's spatial
+// mesh, its points are its own temporal mesh -- the same expressions, evaluated here instead of being read back from the workspace:
+// bit-identical results, no workspace traffic.
+__global__ __launch_bounds__(256) void tsm_fused_kernel(const float* __restrict__ smotion, const float* __restrict__ tmotion,
+                                                        const double* __restrict__ winv, float* __restrict__ smesh,
+                                                        float* __restrict__ tsmotion, int n, float img_h, float img_w, int lag) {
+    __shared__ float sx[SS_NV], sy[SS_NV], Tx[SS_NT], Ty[SS_NT];
+    __shared__ float tg[SS_NV * 2];
+    const int k = blockIdx.x, v = threadIdx.x;
+    float rx = 0.f, ry = 0.f, px = 0.f, py = 0.f, smx = 0.f, smy = 0.f;
+    const long long o = ((long long)k * SS_NV + v) * 2;
+    if (v < SS_NV) {
+        rigid_vertex(v, img_h, img_w, rx, ry);
+        sx[v] = norm1(rx, img_w);
+        sy[v] = norm1(ry, img_h);
+        smx = __fadd_rn(rx, smotion[o]);
+        smy = __fadd_rn(ry, smotion[o + 1]);
+        smesh[o] = smx;
+        smesh[o + 1] = smy;
+        if (k >= lag) {        // target of frame k = normalised spatial mesh of frame k - lag
+            const long long op = ((long long)(k - lag) * SS_NV + v) * 2;
+            tg[v * 2] = norm1(__fadd_rn(rx, smotion[op]), img_w);
+            tg[v * 2 + 1] = norm1(__fadd_rn(ry, smotion[op + 1]), img_h);
+        }
+        px = norm1(__fadd_rn(rx, tmotion[o]), img_w);
+        py = norm1(__fadd_rn(ry, tmotion[o + 1]), img_h);
+    }
+    if (k < lag) {
+        if (v < SS_NV) { tsmotion[o] = 0.f; tsmotion[o + 1] = 0.f; }
+        return;
+    }
+    __syncthreads();
+    if (v < 2 * SS_NT) {
+        const int c = v / SS_NT, r = v - c * SS_NT;
+        double acc = 0.0;
+        for (int j = 0; j < SS_NV; ++j) acc = fma(winv[r * SS_NT + j], (double)tg[j * 2 + c], acc);
+        if (c == 0) Tx[r] = (float)acc; else Ty[r] = (float)acc;
+    }
+    __syncthreads();
+    if (v >= SS_NV) return;
+    float ox, oy;
+    tps_eval(sx, sy, Tx, Ty, px, py, ox, oy);
+    tsmotion[o] = __fsub_rn(recover1(ox, img_w), smx);
+    tsmotion[o + 1] = __fsub_rn(recover1(oy, img_h), smy);
+}
+
 extern "C" long long ss_tsmotion_workspace_floats(int n) { return 126 + (long long)n * (126 + 126 + 132); }
 
 extern "C" int ss_tsmotion_lag(const float* smotion, const float* tmotion, float* smesh, float* tsmotion, int n, int lag,
                                float img_h, float img_w, const double* rigid_winv, float* ws, void* stream) {
     if (!smotion || !tmotion || !smesh || !tsmotion || !ws || n <= 0 || lag < 1) return SS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (rigid_winv) {
+        hipLaunchKernelGGL(tsm_fused_kernel, dim3(n), dim3(256), 0, st, smotion, tmotion, rigid_winv, smesh, tsmotion, n, img_h,
+                           img_w, lag);
+        return ss_launch_status();
+    }
     hipLaunchKernelGGL(tsm_prepare_kernel, dim3(ss_cdiv(n * SS_NV, 128)), dim3(128), 0, st, smotion, tmotion, smesh, ws,
                        n, img_h, img_w, lag);
     float* ntgt = ws + 126;

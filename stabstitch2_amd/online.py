@@ -219,9 +219,9 @@ class OnlineStitcher:
         pair_s[:, 0] = self.prev_smotion.reshape(2, e)
         ring = torch.stack([torch.cat(r, 0).reshape(WINDOW, e) for r in (self.ring_smesh[0], self.ring_smesh[1],
                                                                           self.ring_tsm[0], self.ring_tsm[1])], 0).contiguous()
+        lr = torch.empty((2, 1, 3, pipeline.LR_H, pipeline.LR_W), device=d)       # both views back to back: one layout launch per push
         st = {'hr1': torch.empty((1, 3, self.h, self.w), device=d), 'hr2': torch.empty((1, 3, self.h, self.w), device=d),
-              'lr1': torch.empty((1, 3, pipeline.LR_H, pipeline.LR_W), device=d),
-              'lr2': torch.empty((1, 3, pipeline.LR_H, pipeline.LR_W), device=d),
+              'lr1': lr[0], 'lr2': lr[1],
               'prev_feat': self.prev_feat.clone(), 'pair_s': pair_s, 'pair_t': torch.zeros((2, 2, e), device=d),
               'ring': ring, 'ts_out': torch.empty((2, 4, e), device=d),
               'out': None if self.meshes_only else torch.empty((3, self.hc, self.wc), device=d)}
@@ -426,9 +426,9 @@ class MultiOnlineStitcher:
           pair_s / pair_t [2 views][prev, new][S][126], ring [4 kinds][S][7][126], prev_feat [2 views * S,45,60,128] view-major."""
         d, S, e = self.dev, self.S, 126
         one = [s.static for s in self.single]
+        lr = torch.empty((2, S, 3, pipeline.LR_H, pipeline.LR_W), device=d)       # both views back to back: one layout launch per push
         st = {'hr1': torch.empty((S, 3, self.h, self.w), device=d), 'hr2': torch.empty((S, 3, self.h, self.w), device=d),
-              'lr1': torch.empty((S, 3, pipeline.LR_H, pipeline.LR_W), device=d),
-              'lr2': torch.empty((S, 3, pipeline.LR_H, pipeline.LR_W), device=d),
+              'lr1': lr[0], 'lr2': lr[1],
               'prev_feat': torch.cat([torch.stack([o['prev_feat'][v] for o in one], 0) for v in range(2)], 0).contiguous(),
               'pair_s': torch.stack([o['pair_s'] for o in one], 2).contiguous(),           # [2,2,S,126]
               'pair_t': torch.zeros((2, 2, S, e), device=d),

@@ -62,6 +62,12 @@ def nhwc_to_nchw(x, c=None):
     return out
 
 
+def adjacent(a, b):
+    """Do two contiguous fp32 tensors lie back to back in memory (b right behind a)?  Then a launch over both reads them as one."""
+    return (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype == torch.float32 and a.device == b.device and
+            b.data_ptr() == a.data_ptr() + a.numel() * 4)
+
+
 def stem_input(xs):
     """NCHW frames (one tensor [n,3,h,w] or a list of them, laid back to back) -> [N,h,w+8,3]: the stem convolution's
     input layout (3 zero pixels left, 5 right; ss_nchw_to_nhwc3_padded)."""
@@ -69,11 +75,19 @@ def stem_input(xs):
     total = sum(x.shape[0] for x in xs)
     h, w = xs[0].shape[2], xs[0].shape[3]
     buf = torch.empty((total, h, w + 8, 3), device=xs[0].device, dtype=torch.float32)
-    o = 0
-    for x in xs:
+    o, i = 0, 0
+    xs = [_f(x) for x in xs]
+    while i < len(xs):
+        x = xs[i]
         assert x.shape[1] == 3 and tuple(x.shape[2:]) == (h, w), x.shape
-        H.call('ss_nchw_to_nhwc3_padded', H.dptr(_f(x)), H.dptr(buf[o:o + x.shape[0]]), x.shape[0], h, w, H.stream())
-        o += x.shape[0]
+        n = x.shape[0]
+        while i + 1 < len(xs) and adjacent(xs[i], xs[i + 1]):        # frames that lie back to back in memory: one launch
+            i += 1
+            assert xs[i].shape[1] == 3 and tuple(xs[i].shape[2:]) == (h, w), xs[i].shape
+            n += xs[i].shape[0]
+        H.call('ss_nchw_to_nhwc3_padded', H.dptr(x), H.dptr(buf[o:o + n]), n, h, w, H.stream())
+        o += n
+        i += 1
     return buf
 
 
@@ -547,8 +561,8 @@ def tensor_dlt(src, dst):
 
 def spatial_decompose(offset8, img_h, img_w):
     n = offset8.shape[0]
-    a = torch.empty((n, 3, 3), device=offset8.device, dtype=torch.float32)
-    b = torch.empty((n, 3, 3), device=offset8.device, dtype=torch.float32)
+    ab = torch.empty((2, n, 3, 3), device=offset8.device, dtype=torch.float32)      # (back to back: homo_warp_pair reads them as one)
+    a, b = ab[0], ab[1]
     H.call('ss_spatial_decompose', H.dptr(offset8), H.dptr(a), H.dptr(b), n, float(img_h), float(img_w), H.stream())
     return a, b
 
@@ -571,6 +585,18 @@ def homo_warp_nhwc(x, theta, out_h, out_w):
     out = torch.empty((n, out_h, out_w, c), device=x.device, dtype=torch.float32)
     H.call('ss_homo_warp_nhwc', H.dptr(x), H.dptr(theta), H.dptr(out), n, h, w, c, out_h, out_w, H.stream())
     return out
+
+
+def homo_warp_pair(x1, x2, th1, th2, out_h, out_w):
+    """(homo_warp_nhwc(x1, th1), homo_warp_nhwc(x2, th2)) -- as ONE launch when both the maps and the transforms lie back to back in
+    memory (the two views' halves of a trunk output, spatial_decompose's pair), else two."""
+    if adjacent(x1, x2) and adjacent(th1, th2) and x1.shape[1:] == x2.shape[1:]:
+        n1, n2 = x1.shape[0], x2.shape[0]
+        out = torch.empty((n1 + n2, out_h, out_w, x1.shape[3]), device=x1.device, dtype=torch.float32)
+        H.call('ss_homo_warp_nhwc', H.dptr(x1), H.dptr(th1), H.dptr(out), n1 + n2, x1.shape[1], x1.shape[2], x1.shape[3], out_h, out_w,
+               H.stream())
+        return out[:n1], out[n1:]
+    return homo_warp_nhwc(x1, th1, out_h, out_w), homo_warp_nhwc(x2, th2, out_h, out_w)
 
 
 def homo_warp_nchw(x, theta, out_h, out_w):

@@ -105,8 +105,7 @@ class SpatialNet(L.PreparedMixin, nn.Module):
         # bidirectional decomposition at 1/8 scale, warp both feature maps onto the middle plane
         th_ref, th_tgt = ops.spatial_decompose(offset_1, img_h, img_w)
         fh, fw = int(img_h / 8), int(img_w / 8)
-        w1 = ops.homo_warp_nhwc(f64_1, th_ref, fh, fw)
-        w2 = ops.homo_warp_nhwc(f64_2, th_tgt, fh, fw)
+        w1, w2 = ops.homo_warp_pair(f64_1, f64_2, th_ref, th_tgt, fh, fw)
         # stage 2: local cost volumes in both directions -> residual mesh motions
         return offset_1, ops.cost_volume_bidir(w1, w2, 5)          # [2,b,fh,fw,124]: both directions, one launch
 
