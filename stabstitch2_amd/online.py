@@ -60,8 +60,10 @@ def _spatial_temporal_heads(spatial, temporal, f64, prev_feat, feat, b, tm_out):
 
 class OnlineStitcher:
     def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True, grow='never', meshes_only=False):
+                 use_graph=True, grow='never', meshes_only=False, deterministic=False):
         """canvas: optional (wmin, wmax, hmin, hmax) in HR pixels (e.g. the offline bbox).
+        deterministic: every push under the conv engine's geometry-only kernel policy (ops.deterministic): with the offline canvas the
+        stream's frames equal the resident clip's (pipeline.run_two_view(..., deterministic=True)) bit for bit; ~1.6x slower pushes.
         meshes_only: no canvas, no render -- `push` returns the newly smoothed meshes (m1, m2) [k,7,9,2] (k = 7 on the 7th push,
         then 1) or None; the building block of ThreeViewOnlineStitcher, which captures the graph itself (use_graph is ignored).
         grow: 'never' -- the canvas fixed after the first window stays (frames whose mesh leaves it are cropped and COUNTED:
@@ -70,6 +72,7 @@ class OnlineStitcher:
         if grow not in ('never', 'recapture'):
             raise ValueError("grow must be 'never' or 'recapture'")
         self.grow = grow
+        self.deterministic = bool(deterministic)
         self.meshes_only = bool(meshes_only)
         self.last_meshes = None
         self.canvas_epoch = 0
@@ -309,6 +312,10 @@ class OnlineStitcher:
         """One frame pair: hr* [1,3,H,W] (0..255), lr* [1,3,360,480] ([-1,1]), device tensors.
         -> list of newly stitched frames (empty for the first 6 pushes, 7 frames on the 7th, then one per push).
         meshes_only: -> None for the first 6 pushes, then (m1, m2) [k,7,9,2] (k = 7 on the 7th push, then 1)."""
+        with ops.deterministic(self.deterministic):
+            return self._push(hr1, hr2, lr1, lr2)
+
+    def _push(self, hr1, hr2, lr1, lr2):
         if self.static is not None:
             return self._push_static(hr1, hr2, lr1, lr2)
         t = self.frames_in
@@ -381,7 +388,7 @@ class MultiOnlineStitcher:
     is independent of its neighbours bit for bit (tests/test_gpu_round4.py)."""
 
     def __init__(self, nets, height, width, streams, canvases=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True, grow='never', meshes_only=False):
+                 use_graph=True, grow='never', meshes_only=False, deterministic=False):
         """grow: as OnlineStitcher -- 'never' counts the frames whose mesh left their stream's canvas (`clipped_frames`, per
         stream), 'recapture' re-fixes the canvases of the streams that come near an edge and captures the graph again.
         meshes_only: no canvases, no render -- `push` returns the S streams' newly smoothed meshes (m1, m2) [S,k,7,9,2] (k = 7 on the
@@ -390,6 +397,7 @@ class MultiOnlineStitcher:
         if grow not in ('never', 'recapture'):
             raise ValueError("grow must be 'never' or 'recapture'")
         self.grow = grow
+        self.deterministic = bool(deterministic)      # geometry-only kernel policy: S batched streams == S single streams, bit for bit
         self.meshes_only = bool(meshes_only)
         self.last_meshes = None
         self._host_watch = self._host_event = None
@@ -403,7 +411,8 @@ class MultiOnlineStitcher:
             raise ValueError('one canvas per stream')
         self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
         self.single = [OnlineStitcher(nets, height, width, None if canvases is None else canvases[s], margin, warp_mode,
-                                      fusion_mode, use_graph=False, meshes_only=meshes_only) for s in range(self.S)]   # (growth is handled here, batched)
+                                      fusion_mode, use_graph=False, meshes_only=meshes_only, deterministic=deterministic)
+                       for s in range(self.S)]                   # (growth is handled here, batched)
         self.use_graph = use_graph
         self.static = None
         self.graph = None
@@ -595,6 +604,11 @@ class MultiOnlineStitcher:
         S = self.S
         if hr1.shape[0] != S or hr2.shape[0] != S or lr1.shape[0] != S or lr2.shape[0] != S:
             raise ValueError('expected %d streams per push' % S)
+        with ops.deterministic(self.deterministic):
+            return self._push(hr1, hr2, lr1, lr2)
+
+    def _push(self, hr1, hr2, lr1, lr2):
+        S = self.S
         if self.static is not None:
             return self._push_static(hr1, hr2, lr1, lr2)
         outs = [one.push(hr1[s:s + 1], hr2[s:s + 1], lr1[s:s + 1], lr2[s:s + 1]) for s, one in enumerate(self.single)]

@@ -151,6 +151,38 @@ def stem_pool(buf, wgt, bias=None):
 
 
 # ------------------------------------------------------------------ conv / pool / fc
+# Deterministic kernel policy.  By default the conv engine picks a layer's kernel by LAUNCH SIZE as well as by
+# geometry (F(4x4,3x3) needs >= 512 workgroups, F(2x2,3x3) >= 96, small launches are cut along K, FC layers with >= 16 rows run on
+# the conv engine): a frame's last digits depend on how many frames share its launches (~1e-5 px between a 32-frame clip, two
+# 16-frame passes and a stream).  Under the policy every choice follows the layer's GEOMETRY alone -- the Winograd rules as if the
+# launch were large, no split-K (and no pool-in-reduction), FC always on the one-wave-per-neuron kernel -- so a frame's result is
+# bit-identical whatever the batch: resident clip == chunked passes == streamed (tests/test_gpu_round6.py).  Price: small launches
+# lose split-K's parallelism (batch-1 streaming ~1.6x slower, clips unchanged to ~1 %).
+#     with ops.deterministic(): ...          or        pipeline.run_two_view(..., deterministic=True), OnlineStitcher(..., deterministic=True)
+DETERMINISTIC = os.environ.get('SS_DETERMINISTIC', '0') == '1'
+_PIN_IMAGES = 1 << 20
+
+
+class deterministic:
+    """Context manager: the geometry-only kernel policy inside the block (flag=False: leave the current policy as it is)."""
+
+    def __init__(self, flag=True):
+        self.flag = bool(flag)
+        self.old = None
+
+    def __enter__(self):
+        global DETERMINISTIC
+        self.old = DETERMINISTIC
+        if self.flag:
+            DETERMINISTIC = True
+        return self
+
+    def __exit__(self, *exc):
+        global DETERMINISTIC
+        DETERMINISTIC = self.old
+        return False
+
+
 def conv_workspace(device, floats):
     """Split-K scratch for ONE launch, sized by ss_conv_workspace_need and taken from torch's caching allocator on the
     launch stream (stream-ordered: the block may be reused as soon as the reduce kernel behind it has been enqueued,
@@ -161,6 +193,8 @@ def conv_workspace(device, floats):
 
 
 def _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups):
+    if DETERMINISTIC:          # no workspace = no split-K (ss_conv_nhwc: "a NULL workspace disables splitting")
+        return 0
     return int(H.lib().ss_conv_workspace_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups))
 
 
@@ -184,7 +218,7 @@ def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
         return False
     forced = WINO43 == '1'
     return bool(H.lib().ss_conv_uses_wino43(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho), int(wo),
-                                            int(images), int(groups), 1 if forced else WINO43_MIN_WGS,
+                                            int(images), int(groups), 1 if (forced or DETERMINISTIC) else WINO43_MIN_WGS,
                                             1 if forced else WINO43_MIN_CIN, 1 if forced else 0))
 
 
@@ -211,7 +245,7 @@ def _try_wino43(x, wgt, bias, res, relu, out):
 def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
     return bool(WINOGRAD and kt == 1 and tuple(pad) == (0, 1, 1) and
                 H.lib().ss_conv_uses_winograd(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho),
-                                              int(wo), int(images)))
+                                              int(wo), _PIN_IMAGES if DETERMINISTIC else int(images)))
 
 
 # which kernel the most recent ops.conv / ops.conv_grouped / ops.conv_winograd call launched ('wino' | 'igemm'): read by

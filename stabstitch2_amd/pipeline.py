@@ -545,11 +545,14 @@ def get_stable_sqe(img1_list, img2_list, smooth_mesh1, smooth_mesh2, warp_mode, 
 
 
 @torch.no_grad()
-def run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', to_host=False, out=None):
+def run_two_view(hr1, hr2, lr1, lr2, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', to_host=False, out=None, deterministic=False):
     """-> (frames, Hc, Wc, smooth_mesh1, smooth_mesh2); frames = device tensor [N,3,Hc,Wc]
     (or list of HWC ndarrays with to_host=True).  out: the frames tensor of a previous call to render into; it is reused
-    when the canvas still has that size (same-size clips of one stream), else a new one is allocated."""
-    acc = estimate_meshes(nets, lr1, lr2)
+    when the canvas still has that size (same-size clips of one stream), else a new one is allocated.
+    deterministic: the conv engine's geometry-only kernel policy (ops.deterministic): a frame's bits do not depend on how many
+    frames share its launches -- resident clip == chunked passes == stream."""
+    with ops.deterministic(deterministic):
+        acc = estimate_meshes(nets, lr1, lr2)
     frames, hc, wc = render_frames([hr1, hr2], [acc['smooth_mesh1'], acc['smooth_mesh2']], warp_mode, fusion_mode, out=out)
     if to_host:
         host = frames.permute(0, 2, 3, 1).cpu().numpy()
@@ -581,10 +584,11 @@ def three_view_render(img1, img2, img3, mesh1, middle, mesh3, warp_mode='NORMAL'
 
 
 @torch.no_grad()
-def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None):
+def run_three_view(hr1, hr2, hr3, lr1, lr2, lr3, nets, warp_mode='NORMAL', fusion_mode='AVERAGE', out=None, deterministic=False):
     # the middle view's TemporalNet motions and SpatialNet trunk features are computed once and reused by pair (2,3)
-    a12 = estimate_meshes(nets, lr1, lr2, keep_spatial_cache2=True)
-    a23 = estimate_meshes(nets, lr2, lr3, tmotion1=a12['tmotion2'], spatial_cache1=a12.get('spatial_cache2'))
+    with ops.deterministic(deterministic):
+        a12 = estimate_meshes(nets, lr1, lr2, keep_spatial_cache2=True)
+        a23 = estimate_meshes(nets, lr2, lr3, tmotion1=a12['tmotion2'], spatial_cache1=a12.get('spatial_cache2'))
     img_h, img_w = hr1[0].shape[-2:]
     m1, mid, m3 = three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'],
                                      a23['smooth_mesh2'], img_h, img_w)

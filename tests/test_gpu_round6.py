@@ -101,3 +101,45 @@ def test_meshes_only_streams_past_the_first_window(dev, hip_nets, clip16, use_gr
         got.append(r[0][0].clone())                                # stream 0 = the pair above, view 1
     assert float((torch.cat(got, 0) - m1[0]).abs().max()) < 2e-3
     assert [rep['frames_seen'] for rep in ms.overflow_report()] == [0, 0]
+
+
+def test_deterministic_policy_makes_a_frame_independent_of_its_batch(dev, hip_nets, monkeypatch):
+    """the kernel-choice pin as an API (`deterministic=True` on pipeline.run_two_view / OnlineStitcher /
+    MultiOnlineStitcher, `with ops.deterministic():` below them).  Under it every layer's kernel follows its geometry alone (no
+    launch-size thresholds, no split-K, FC on one kernel), so the SAME 32 frames give the SAME bits as one resident clip, as
+    passes of 16 pairs through the networks, as a stream of single pairs on the clip's canvas, and as one of two batched streams.
+    (Under the default policy these differ by ~1e-5 px / ~1e-3 grey levels: asserted too, so the test cannot pass vacuously.)"""
+    from stabstitch2_amd import pipeline, ops
+    from stabstitch2_amd.online import OnlineStitcher, MultiOnlineStitcher
+    n = 32
+    hr, lr = synth.make_clip_device(n, 360, 480, seed=3, device=dev)
+    fa, hc, wc, m1a, m2a = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets, deterministic=True)
+    monkeypatch.setattr(pipeline, 'SPATIAL_CHUNK', 16)
+    fb, hcb, wcb, m1b, m2b = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets, deterministic=True)
+    monkeypatch.setattr(pipeline, 'SPATIAL_CHUNK', 32)
+    assert (hc, wc) == (hcb, wcb) and torch.equal(m1a, m1b) and torch.equal(m2a, m2b) and torch.equal(fa, fb)
+    bbox = ops.mesh_bbox([m1a, m2a], 360, 480).cpu().tolist()
+    st = OnlineStitcher(hip_nets, 360, 480, canvas=bbox, deterministic=True)
+    frames = []
+    for t in range(n):
+        frames += st.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
+    assert (st.hc, st.wc) == (hc, wc) and len(frames) == n
+    fs = torch.stack(frames, 0)
+    assert torch.equal(fs, fa), float((fs - fa).abs().max())
+    # two batched streams (this pair and its mirror): stream 0 equals the single stream bit for bit
+    ms = MultiOnlineStitcher(hip_nets, 360, 480, streams=2, canvases=[bbox, bbox], deterministic=True)
+    got = []
+    for t in range(12):
+        r = ms.push(torch.cat((hr[0][t:t + 1], hr[1][t:t + 1])), torch.cat((hr[1][t:t + 1], hr[0][t:t + 1])),
+                    torch.cat((lr[0][t:t + 1], lr[1][t:t + 1])), torch.cat((lr[1][t:t + 1], lr[0][t:t + 1])))
+        got += r[0]
+    assert torch.equal(torch.stack(got, 0), fa[:12])
+    # the default policy: close, not equal
+    fd = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets)[0]
+    sd = OnlineStitcher(hip_nets, 360, 480, canvas=bbox)
+    fsd = []
+    for t in range(n):
+        fsd += sd.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
+    fsd = torch.stack(fsd, 0)
+    assert not torch.equal(fsd, fd) and float((fsd - fd).abs().median()) < 1e-3
+    assert float((fa - fd).abs().median()) < 1e-3                  # and the two policies agree to the usual tolerance

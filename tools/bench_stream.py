@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--eager', action='store_true')
     ap.add_argument('--fusion', default='AVERAGE')
+    ap.add_argument('--deterministic', action='store_true')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.set_grad_enabled(False)
@@ -35,7 +36,7 @@ def main():
         st = ThreeViewOnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion)
         push = lambda i: st.push(hr[0][i:i + 1], hr[1][i:i + 1], hr[2][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1], lr[2][i:i + 1])
     else:
-        st = OnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion)
+        st = OnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion, deterministic=args.deterministic)
         push = lambda i: st.push(hr[0][i:i + 1], hr[1][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1])
     for t in range(12):
         push(t)
@@ -45,7 +46,7 @@ def main():
         push(t % n)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res = {'views': args.views, 'pushes': args.pushes, 'ms_per_push': round(dt / args.pushes * 1e3, 4),
+    res = {'deterministic': args.deterministic, 'views': args.views, 'pushes': args.pushes, 'ms_per_push': round(dt / args.pushes * 1e3, 4),
            'fps_steady': round(args.pushes / dt, 1), 'canvas': [st.hc, st.wc]}
     g = getattr(st, 'graph', None)
     if g is not None:
