@@ -338,6 +338,12 @@ SS_API int ss_h2mesh(const float* H, const float* mesh, float* out, int n, int n
 SS_API int ss_three_view_align(const float* w12_m1, const float* w12_m2, const float* w23_m1, const float* w23_m2,
                         float* a1, float* a2, float* b1, float* b2, float* mid, int frames, float img_h, float img_w,
                         void* stream);
+/* the composition's five meshes (HR pixels, as ss_three_view_align writes them) normalised on the first canvas `bbox` in ONE launch
+ * (= five ss_mesh_normalize calls with img_h = img_w = 0, bit for bit), laid out for one batched solve + one point evaluation of
+ * both re-projections (threeview:381-420): out [6][n_points][2] = {a1, b2 | a2, b1 | mid, mid}: points = out[0:2], sources =
+ * out[2:4], targets = out[4:6] */
+SS_API int ss_three_view_normalize(const float* a1, const float* a2, const float* b1, const float* b2, const float* mid,
+                            const float* bbox, float* out, long long n_points, void* stream);
 SS_API int ss_three_view_finish(const float* n1, const float* n3, const float* mid, const float* bbox, float* mesh1,
                          float* middle, float* mesh3, long long n_points, void* stream);
 /* Streaming mode (stabstitch2_amd/online.py): the reference sizes the canvas from ALL frames of the clip (test_online_tra.py:

@@ -682,6 +682,36 @@ __global__ void mesh_normalize_kernel(const float* __restrict__ mesh, const floa
     out[i * 2 + 1] = norm1(__fsub_rn(y, hmin), oh);
 }
 
+// Three-view composition (threeview:381-420): the five aligned meshes normalised on the first canvas in ONE launch, laid out for
+// ONE batched TPS solve + ONE point evaluation of both re-projections: out [6][npts][2] = {a1, b2 (the points), a2, b1 (the
+// sources), mid, mid (the targets)}.  Same arithmetic per point as mesh_normalize_kernel (meshes are HR pixels already).
+struct FiveMeshes {
+    const float* m[5];          // a1, a2, b1, b2, mid
+};
+__global__ void three_view_normalize_kernel(FiveMeshes ms, const float* __restrict__ bbox, float* __restrict__ out, int npts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const float wmin = bbox[0], wmax = bbox[1], hmin = bbox[2], hmax = bbox[3];
+    const float ow = __fsub_rn(wmax, wmin), oh = __fsub_rn(hmax, hmin);
+    const int slot[6] = {0, 3, 1, 2, 4, 4};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int j = slot[k];
+        const float* m = j == 0 ? ms.m[0] : j == 1 ? ms.m[1] : j == 2 ? ms.m[2] : j == 3 ? ms.m[3] : ms.m[4];
+        out[((long long)k * npts + i) * 2] = norm1(__fsub_rn(m[i * 2], wmin), ow);
+        out[((long long)k * npts + i) * 2 + 1] = norm1(__fsub_rn(m[i * 2 + 1], hmin), oh);
+    }
+}
+extern "C" int ss_three_view_normalize(const float* a1, const float* a2, const float* b1, const float* b2, const float* mid,
+                                       const float* bbox, float* out, long long n_points, void* stream) {
+    if (!a1 || !a2 || !b1 || !b2 || !mid || !bbox || !out || n_points <= 0 || n_points >= (1ll << 28)) return SS_ERR_ARG;
+    FiveMeshes ms;
+    ms.m[0] = a1; ms.m[1] = a2; ms.m[2] = b1; ms.m[3] = b2; ms.m[4] = mid;
+    hipLaunchKernelGGL(three_view_normalize_kernel, dim3(ss_cdiv(n_points, 256)), dim3(256), 0, (hipStream_t)stream, ms, bbox, out,
+                       (int)n_points);
+    return ss_launch_status();
+}
+
 // the same for view `view` of `views`, written where the render wants it: frame f's 63 points at out[(f * views + view) * 126]
 // (source [frames][views][63][2] assembled by `views` launches, no torch.stack)
 // bbox_fs: floats between the canvas boxes of consecutive frames (0: one box for all; 4: a box per frame -- S live streams with a

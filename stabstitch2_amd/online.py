@@ -39,17 +39,22 @@ def _warmup_stream(dev):
     return s
 
 
-def _spatial_temporal_heads(spatial, temporal, f64, prev_feat, feat, b, tm_out):
+def _spatial_temporal_heads(spatial, temporal, f64, prev_feat, feat, b, tm_out, chain=False):
     """SpatialNet behind its stage-1 trunk (f64 [2b,45,60,128], view 1 first) and TemporalNet's regressor on the cached /
     current features (prev_feat, feat [2b,45,60,128], view-major) -> (offset_1, offset_2_ref, offset_2_tgt); the temporal
     motions of view 1 / view 2 are written to tm_out = (t1 [b,126], t2 [b,126]).  With layers.QUAD the four regressor heads
-    share their launches (layers.run_regressor_quad), else they run as SpatialNet's pair and TemporalNet's own."""
+    share their launches (layers.run_regressor_quad), else they run as SpatialNet's pair and TemporalNet's own.
+    chain: f64 holds b + 1 images of a CHAIN of views (v1 .. v_{b+1}); pair i = (v_i, v_{i+1}) -- the first views are images
+    0 .. b-1, the second views images 1 .. b, overlapping slices of one trunk pass (three views: the middle one passes the
+    trunks once, threeview:154-343 runs it through both pair passes)."""
+    o2 = 1 if chain else b
     if not L.QUAD:
+        assert not chain
         off = spatial.forward_features(f64, b, pipeline.LR_H, pipeline.LR_W)
         temporal.motions_from_features(prev_feat, feat, out_slices=[(0, b, tm_out[0]), (b, 2 * b, tm_out[1])])
         return off
     f32 = L.run_stage2(f64, spatial._prepared()['s2'])
-    off1, cv_s = spatial.forward_pair_cv(f64[:b], f64[b:], f32[:b], f32[b:], pipeline.LR_H, pipeline.LR_W)
+    off1, cv_s = spatial.forward_pair_cv(f64[:b], f64[o2:o2 + b], f32[:b], f32[o2:o2 + b], pipeline.LR_H, pipeline.LR_W)
     cv_t = ops.cost_volume(prev_feat, feat, 3)
     off_ref = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
     off_tgt = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
@@ -273,7 +278,8 @@ class OnlineStitcher:
             # weights (the graph by address); rebuild and recapture instead of silently stitching with stale filters
             self.trunk_pair = None
             self.graph = None
-        st['hr1'].copy_(hr1.reshape(st['hr1'].shape)); st['hr2'].copy_(hr2.reshape(st['hr2'].shape))
+        if not self.meshes_only:             # (meshes_only: the frames are not looked at, None will do)
+            st['hr1'].copy_(hr1.reshape(st['hr1'].shape)); st['hr2'].copy_(hr2.reshape(st['hr2'].shape))
         st['lr1'].copy_(lr1.reshape(st['lr1'].shape)); st['lr2'].copy_(lr2.reshape(st['lr2'].shape))
         if not self.use_graph:
             self._step_static()
@@ -388,7 +394,7 @@ class MultiOnlineStitcher:
     is independent of its neighbours bit for bit (tests/test_gpu_round4.py)."""
 
     def __init__(self, nets, height, width, streams, canvases=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True, grow='never', meshes_only=False, deterministic=False):
+                 use_graph=True, grow='never', meshes_only=False, deterministic=False, chain=False):
         """grow: as OnlineStitcher -- 'never' counts the frames whose mesh left their stream's canvas (`clipped_frames`, per
         stream), 'recapture' re-fixes the canvases of the streams that come near an edge and captures the graph again.
         meshes_only: no canvases, no render -- `push` returns the S streams' newly smoothed meshes (m1, m2) [S,k,7,9,2] (k = 7 on the
@@ -398,6 +404,12 @@ class MultiOnlineStitcher:
             raise ValueError("grow must be 'never' or 'recapture'")
         self.grow = grow
         self.deterministic = bool(deterministic)      # geometry-only kernel policy: S batched streams == S single streams, bit for bit
+        # chain: the S pairs are the neighbours of a chain of S + 1 views (pair s = views s, s + 1: ThreeViewOnlineStitcher's two
+        # chains).  The steady-state step then takes the S + 1 LR frames once (static['lrc'] [S+1,3,360,480]) and every inner view
+        # passes the trunks ONCE; the window-fill pushes go pair by pair as usual.  meshes_only streams only.
+        self.chain = bool(chain)
+        if self.chain and not meshes_only:
+            raise ValueError('chain=True needs meshes_only=True')
         self.meshes_only = bool(meshes_only)
         self.last_meshes = None
         self._host_watch = self._host_event = None
@@ -436,8 +448,10 @@ class MultiOnlineStitcher:
         d, S, e = self.dev, self.S, 126
         one = [s.static for s in self.single]
         lr = torch.empty((2, S, 3, pipeline.LR_H, pipeline.LR_W), device=d)       # both views back to back: one layout launch per push
-        st = {'hr1': torch.empty((S, 3, self.h, self.w), device=d), 'hr2': torch.empty((S, 3, self.h, self.w), device=d),
+        hr = None if self.meshes_only else torch.empty((2, S, 3, self.h, self.w), device=d)
+        st = {'hr1': None if hr is None else hr[0], 'hr2': None if hr is None else hr[1],
               'lr1': lr[0], 'lr2': lr[1],
+              'lrc': torch.empty((S + 1, 3, pipeline.LR_H, pipeline.LR_W), device=d) if self.chain else None,
               'prev_feat': torch.cat([torch.stack([o['prev_feat'][v] for o in one], 0) for v in range(2)], 0).contiguous(),
               'pair_s': torch.stack([o['pair_s'] for o in one], 2).contiguous(),           # [2,2,S,126]
               'pair_t': torch.zeros((2, 2, S, e), device=d),
@@ -522,11 +536,16 @@ class MultiOnlineStitcher:
         if self.trunk_pair is None:
             self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
             self.trunk_versions = self._versions()
-        f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)            # [2(net), 2S (view-major), 45,60,128]
         ps, pt = st['pair_s'], st['pair_t']
-        feat = f2[1]
-        off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f2[0], st['prev_feat'], feat, S,
-                                                         (pt[0, 1], pt[1, 1]))
+        if self.chain:
+            fc = L.run_stage1_pair([st['lrc']], self.trunk_pair)                   # [2(net), S + 1 views, 45,60,128]: each view once
+            feat = torch.cat((fc[1][:S], fc[1][1:]), 0)                            # TemporalNet's features, view-major per pair
+            f64 = fc[0]
+        else:
+            f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)        # [2(net), 2S (view-major), 45,60,128]
+            feat, f64 = f2[1], f2[0]
+        off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f64, st['prev_feat'], feat, S,
+                                                         (pt[0, 1], pt[1, 1]), chain=self.chain)
         ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W,
                            out=(ps[0, 1].view(S, 7, 9, 2), ps[1, 1].view(S, 7, 9, 2)))
         st['prev_feat'].copy_(feat)
@@ -569,7 +588,12 @@ class MultiOnlineStitcher:
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
             self.trunk_pair = None           # a net was reloaded / moved: restack the twin trunk and recapture
             self.graph = None
-        st['hr1'].copy_(hr1); st['hr2'].copy_(hr2); st['lr1'].copy_(lr1); st['lr2'].copy_(lr2)
+        if self.chain:                   # (pair s = views s, s + 1: lr1 holds views 0 .. S-1, lr2's last row is view S)
+            st['lrc'][:self.S].copy_(lr1); st['lrc'][self.S:].copy_(lr2[self.S - 1:])
+        else:
+            st['lr1'].copy_(lr1); st['lr2'].copy_(lr2)
+        if not self.meshes_only:
+            st['hr1'].copy_(hr1); st['hr2'].copy_(hr2)
         if not self.use_graph:
             self._step_static()
         elif self.graph is None:
@@ -602,8 +626,8 @@ class MultiOnlineStitcher:
         """One frame pair of every stream: hr* [S,3,H,W] (0..255), lr* [S,3,360,480] ([-1,1]), device tensors.
         -> S lists of newly stitched frames (empty for the first 6 pushes, 7 frames each on the 7th, then one per push)."""
         S = self.S
-        if hr1.shape[0] != S or hr2.shape[0] != S or lr1.shape[0] != S or lr2.shape[0] != S:
-            raise ValueError('expected %d streams per push' % S)
+        if lr1.shape[0] != S or lr2.shape[0] != S or (not self.meshes_only and (hr1.shape[0] != S or hr2.shape[0] != S)):
+            raise ValueError('expected %d streams per push' % S)          # (meshes_only: hr1 / hr2 are not looked at, None will do)
         with ops.deterministic(self.deterministic):
             return self._push(hr1, hr2, lr1, lr2)
 
@@ -611,7 +635,8 @@ class MultiOnlineStitcher:
         S = self.S
         if self.static is not None:
             return self._push_static(hr1, hr2, lr1, lr2)
-        outs = [one.push(hr1[s:s + 1], hr2[s:s + 1], lr1[s:s + 1], lr2[s:s + 1]) for s, one in enumerate(self.single)]
+        hs = (lambda h, s: None) if self.meshes_only else (lambda h, s: h[s:s + 1])
+        outs = [one.push(hs(hr1, s), hs(hr2, s), lr1[s:s + 1], lr2[s:s + 1]) for s, one in enumerate(self.single)]
         self.frames_in += 1
         if self.single[0].static is not None:      # every stream's first window is complete: switch to the batched step
             self._init_static()
@@ -626,30 +651,36 @@ class MultiOnlineStitcher:
 class ThreeViewOnlineStitcher:
     """Streaming form of the three-view script (test_online_tra_threeview.py:154-505, whose frame loops run the same sliding
     windows as the two-view script): one frame TRIPLE per push.  Two pair chains -- (view 1, view 2) and (view 2, view 3), run as ONE
-    batch of two streams (`MultiOnlineStitcher(streams=2, meshes_only=True)`: ring buffers, cached TemporalNet features, sliding
-    SmoothNet windows; every launch serves both pairs) -- deliver the newest smoothed meshes; the composition (mesh alignment, middle plane, TPS re-projection of the outer views: threeview:345-420) and the
-    three-image render (:421-505) run per frame on two FIXED boxes: the composition's "first canvas" (the box the reference takes
-    over all frames of the aligned meshes) and the output canvas.  Both are fixed when the first window is complete (its 7 frames'
-    boxes grown by `margin`) or given by the caller; with the offline boxes passed in the stream reproduces the offline frames
-    (tests/test_gpu_round5.py).  The steady state -- both chains, composition, render -- is ONE HIP graph.
+    batch of two streams (`MultiOnlineStitcher(streams=2, meshes_only=True, chain=True)`: ring buffers, cached TemporalNet features,
+    sliding SmoothNet windows; every launch serves both pairs, and the middle view passes the trunks ONCE per push: three image
+    passes, not four) -- deliver the newest smoothed meshes; the composition (mesh alignment, middle plane, TPS re-projection of the
+    outer views: threeview:345-420) and the three-image render (:421-505) run per frame on two FIXED boxes: the composition's "first
+    canvas" (the box the reference takes over all frames of the aligned meshes: a normalisation frame, nothing is cropped by it) and
+    the output canvas.  Both are fixed when the first window is complete (its 7 frames' boxes grown by `margin`) or given by the
+    caller; with the offline boxes passed in the stream reproduces the offline frames (tests/test_gpu_round5.py, against the CPU
+    oracle at 720p: tests/test_gpu_round6.py).  The steady state -- both chains, composition, render -- is ONE HIP graph.
 
         st = ThreeViewOnlineStitcher(nets, H, W)
         for frame in st.push(hr1, hr2, hr3, lr1, lr2, lr3): ...      # [], ..., 7 frames on the 7th push, then 1: [3,Hc,Wc] fp32
 
-    Overflow of the fixed output canvas is watched as in OnlineStitcher (`clipped_frames`, `overflow_report()`); the canvas does not
-    grow (grow='never')."""
+    Overflow of the fixed output canvas is watched as in OnlineStitcher (`clipped_frames`, `overflow_report()`); grow='recapture'
+    re-fixes the OUTPUT canvas (and captures the graph again) when a mesh comes within half the margin of its edge."""
 
     def __init__(self, nets, height, width, canvas=None, first_canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
-                 use_graph=True):
+                 use_graph=True, grow='never'):
+        if grow not in ('never', 'recapture'):
+            raise ValueError("grow must be 'never' or 'recapture'")
+        self.grow = grow
         self.nets = nets
         self.dev = next(nets[0].parameters()).device
         self.h, self.w = height, width
         self.margin = margin
         self.warp_mode, self.fusion_mode = warp_mode, fusion_mode
         self.use_graph = use_graph
-        # the two pair chains as a batch of two streams: (view 1, view 2) and (view 2, view 3) share every launch
+        # the two pair chains as a batch of two streams over the CHAIN of three views: every launch serves both pairs, view 2's
+        # trunk features are computed once
         self.chains = MultiOnlineStitcher(nets, height, width, streams=2, margin=margin, warp_mode=warp_mode, fusion_mode=fusion_mode,
-                                          use_graph=False, meshes_only=True)
+                                          use_graph=False, meshes_only=True, chain=True)
         box = lambda b: None if b is None else torch.tensor(b, dtype=torch.float32, device=self.dev)
         self.bbox, self.first_canvas = box(canvas), box(first_canvas)
         self.hc = self.wc = None
@@ -658,8 +689,23 @@ class ThreeViewOnlineStitcher:
         self.frames_in = 0
         self.static = None
         self.graph = None
-        self.watch_i = self.watch_f = None
         self.versions = None
+        # overflow state of the output canvas (the methods are OnlineStitcher's)
+        self.canvas_epoch = 0
+        self.watch_i = self.watch_f = None
+        self._watch_totals = [0, 0, -1]
+        self._host_watch = self._host_event = None
+        self._near_handled = 0
+
+    # ------------------------------------------------------------------ overflow / growth of the output canvas: as OnlineStitcher
+    _guard = OnlineStitcher._guard
+    _set_canvas = OnlineStitcher._set_canvas
+    _needed_bbox = OnlineStitcher._needed_bbox
+    _regrow = OnlineStitcher._regrow
+    _poll_growth = OnlineStitcher._poll_growth
+    _post_watch_copy = OnlineStitcher._post_watch_copy
+    overflow_report = OnlineStitcher.overflow_report
+    clipped_frames = OnlineStitcher.clipped_frames
 
     # ------------------------------------------------------------------ composition + render of k frames
     def _compose(self, m12, m23):
@@ -688,21 +734,6 @@ class ThreeViewOnlineStitcher:
         res = ops.linear_blend(f, w[2, 0:3], ops.mask_union(w[0, 3], w[1, 3]), w[2, 3])
         return res if out is None else out.copy_(res)
 
-    # ------------------------------------------------------------------ overflow (as OnlineStitcher)
-    def _guard(self):
-        return max(0.0, float(self.margin)) * 0.5 / (1.0 + 2.0 * max(0.0, float(self.margin))) * 2.0
-
-    def overflow_report(self):
-        rep = {'frames_seen': 0, 'clipped_frames': 0, 'first_clipped_frame': -1, 'near_frames': 0, 'canvas_epoch': 0}
-        if self.watch_i is not None:
-            wi = self.watch_i[0].cpu().tolist()
-            rep.update(frames_seen=wi[0], clipped_frames=wi[1], first_clipped_frame=wi[2], near_frames=wi[3])
-        return rep
-
-    @property
-    def clipped_frames(self):
-        return self.overflow_report()['clipped_frames']
-
     # ------------------------------------------------------------------ steady state
     def _versions(self):
         return tuple(n.weights_version for n in self.nets)
@@ -712,21 +743,23 @@ class ThreeViewOnlineStitcher:
         ch._step_static()
         m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
         meshes = self._compose((m1[0], m2[0]), (m1[1], m2[1]))
-        c = ch.static
-        self._render([c['hr1'][0:1], c['hr2'][0:1], c['hr2'][1:2]], meshes, out=st['out'])
+        hr = st['hr']
+        self._render([hr[0:1], hr[1:2], hr[2:3]], meshes, out=st['out'])
 
     def _state(self):
         return [self.chains.static[k] for k in MultiOnlineStitcher._STATE] + [self.watch_i, self.watch_f]
 
     def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3):
         c, st = self.chains.static, self.static
+        if self.grow == 'recapture':
+            self._poll_growth()
         if self.versions != self._versions():         # a net was reloaded / moved: stale twin trunk and graph
             self.chains.trunk_pair = None
             self.graph = None
             self.versions = self._versions()
-        for dst, src in ((c['hr1'][0:1], hr1), (c['hr1'][1:2], hr2), (c['hr2'][0:1], hr2), (c['hr2'][1:2], hr3),
-                         (c['lr1'][0:1], lr1), (c['lr1'][1:2], lr2), (c['lr2'][0:1], lr2), (c['lr2'][1:2], lr3)):
-            dst.copy_(src.reshape(dst.shape))
+        for k, (h, l) in enumerate(((hr1, lr1), (hr2, lr2), (hr3, lr3))):      # each view once: three frames, three LR frames
+            st['hr'][k:k + 1].copy_(h.reshape(st['hr'][k:k + 1].shape))
+            c['lrc'][k:k + 1].copy_(l.reshape(c['lrc'][k:k + 1].shape))
         if not self.use_graph:
             self._step_static()
         elif self.graph is None:
@@ -749,6 +782,8 @@ class ThreeViewOnlineStitcher:
         else:
             self.graph.replay()
         self.frames_in += 1
+        if self.grow == 'recapture':
+            self._post_watch_copy()
         return [st['out'].clone()]
 
     @torch.no_grad()
@@ -757,7 +792,9 @@ class ThreeViewOnlineStitcher:
         -> list of newly stitched frames (empty for the first 6 pushes, 7 frames on the 7th, then one per push)."""
         if self.static is not None:
             return self._push_static(hr1, hr2, hr3, lr1, lr2, lr3)
-        got = self.chains.push(torch.cat((hr1, hr2), 0), torch.cat((hr2, hr3), 0), torch.cat((lr1, lr2), 0), torch.cat((lr2, lr3), 0))
+        sh = lambda t, c: t.reshape((1,) + tuple(c))
+        got = self.chains.push(None, None, torch.cat((sh(lr1, lr1.shape[-3:]), sh(lr2, lr2.shape[-3:])), 0),
+                               torch.cat((sh(lr2, lr2.shape[-3:]), sh(lr3, lr3.shape[-3:])), 0))
         self.ring_hr.append((hr1, hr2, hr3))
         self.frames_in += 1
         if got is None:
@@ -766,16 +803,16 @@ class ThreeViewOnlineStitcher:
         # first window complete: fix the first canvas and the output canvas, render its 7 frames, switch to the static step
         if self.first_canvas is None:
             k = m12[0].shape[0]
-            sh = lambda m: m.reshape(1, k, 7, 9, 2)
-            a1, a2, b1, b2, _ = ops.three_view_align(sh(m12[0]), sh(m12[1]), sh(m23[0]), sh(m23[1]), self.h, self.w)
+            shp = lambda m: m.reshape(1, k, 7, 9, 2)
+            a1, a2, b1, b2, _ = ops.three_view_align(shp(m12[0]), shp(m12[1]), shp(m23[0]), shp(m23[1]), self.h, self.w)
             self.first_canvas = self._grown(ops.mesh_bbox([a1, a2, b1, b2], 0.0, 0.0))
         meshes = self._compose(m12, m23)                                           # three x [1,7,7,9,2]
         if self.bbox is None:
             self.bbox = self._grown(pipeline.canvas_bbox(meshes, self.h, self.w, prescaled=True))
-        self.hc, self.wc = pipeline.canvas_size(self.bbox)
-        self.watch_i, self.watch_f = ops.canvas_watch_state(1, self.dev)
+        self._set_canvas()
         frames = [self._render(list(hr), [m[:, i:i + 1] for m in meshes]) for i, hr in enumerate(self.ring_hr)]
         self.ring_hr = []
-        self.static = {'out': torch.empty((3, self.hc, self.wc), device=self.dev)}
+        self.static = {'out': torch.empty((3, self.hc, self.wc), device=self.dev),
+                       'hr': torch.empty((3, 3, self.h, self.w), device=self.dev)}
         self.versions = self._versions()
         return frames

@@ -1009,6 +1009,16 @@ def three_view_align(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w):
     return outs
 
 
+def three_view_normalize(a1, a2, b1, b2, mid, bbox):
+    """The five aligned meshes [1,N,7,9,2] (HR pixels) normalised on the first canvas in one launch -> [6, N, 63, 2] =
+    {a1, b2 | a2, b1 | mid, mid}: points [0:2], sources [2:4], targets [4:6] of the two re-projections' batched TPS solve."""
+    n = mid.numel() // 126
+    out = torch.empty((6, n, 63, 2), device=mid.device, dtype=torch.float32)
+    H.call('ss_three_view_normalize', H.dptr(_f(a1)), H.dptr(_f(a2)), H.dptr(_f(b1)), H.dptr(_f(b2)), H.dptr(_f(mid)), H.dptr(bbox),
+           H.dptr(out), n * 63, H.stream())
+    return out
+
+
 def three_view_finish(n1, n3, mid, bbox):
     """Re-projected outer meshes n1 / n3 [N,63,2] (normalised on the first canvas `bbox`) and the untranslated middle mesh
     -> (mesh1, middle, mesh3) [1,N,7,9,2] in first-canvas pixels."""

@@ -570,11 +570,14 @@ def three_view_compose(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w, first_canva
     first_canvas: device box [4] to use as the first canvas instead of the box of these frames (streaming mode: fixed once)."""
     a1, a2, b1, b2, mid = ops.three_view_align(w12_m1, w12_m2, w23_m1, w23_m2, img_h, img_w)
     bbox = first_canvas if first_canvas is not None else ops.mesh_bbox([a1, a2, b1, b2], 0.0, 0.0)   # (meshes are HR pixels already)
-    nrm = lambda m: ops.mesh_normalize(m, bbox, 0.0, 0.0)          # [N,63,2]
-    nmid, na2, nb1 = nrm(mid), nrm(a2), nrm(b1)
-    n1 = ops.tps_points(nrm(a1), na2, ops.tps_solve(na2, nmid))
-    n3 = ops.tps_points(nrm(b2), nb1, ops.tps_solve(nb1, nmid))
-    return tuple(ops.three_view_finish(n1, n3, mid, bbox))
+    # both re-projections (view 1 through pair (1,2)'s spline, view 3 through pair (2,3)'s) as ONE normalisation launch, ONE batched
+    # TPS solve of 2 N systems and ONE point evaluation (round 6: they were 5 + 2 + 2 launches; a solve is 47 us of one workgroup's
+    # latency whether the launch holds one system or many) -- the same arithmetic per system
+    nrm = ops.three_view_normalize(a1, a2, b1, b2, mid, bbox)       # [6,N,63,2] = {a1, b2 | a2, b1 | mid, mid}
+    n = nrm.shape[1]
+    src = nrm[2:4].reshape(2 * n, 63, 2)
+    pts = ops.tps_points(nrm[0:2].reshape(2 * n, 63, 2), src, ops.tps_solve(src, nrm[4:6].reshape(2 * n, 63, 2)))
+    return tuple(ops.three_view_finish(pts[:n], pts[n:], mid, bbox))
 
 
 @torch.no_grad()

@@ -143,3 +143,111 @@ def test_deterministic_policy_makes_a_frame_independent_of_its_batch(dev, hip_ne
     fsd = torch.stack(fsd, 0)
     assert not torch.equal(fsd, fd) and float((fsd - fd).abs().median()) < 1e-3
     assert float((fa - fd).abs().median()) < 1e-3                  # and the two policies agree to the usual tolerance
+
+
+def test_three_view_stream_vs_oracle_720p(dev, hip_nets):
+    """`ThreeViewOnlineStitcher` at 720p against the ORACLE's three-view path (oracle/pipeline.py: two full
+    2-view passes, composition, three-image render) on the same 10 triples, with the two boxes the oracle's offline run takes over
+    all frames (the composition's first canvas, the output canvas) handed to the stream: canvas size equal, frames within the
+    gates of test_run_three_view_vs_oracle (AVERAGE: views-1-2 region sharply, whole canvas through the median; LINEAR: whole
+    canvas).  The middle view passes the trunks once per push (chain mode): the launches of a push are counted."""
+    import cases
+    from oracle import pipeline as P
+    from test_gpu_parity import _oracle_nets
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.online import ThreeViewOnlineStitcher
+    n, h, w = 10, 720, 1280
+    hr, lr = synth.make_clip(n, h, w, seed=7, views=3)
+    nets = _oracle_nets()
+    a12 = P.estimate_meshes(nets, lr[0], lr[1])
+    a23 = P.estimate_meshes(nets, lr[1], lr[2])
+    # the oracle's boxes: first canvas = bbox of the aligned HR meshes, output canvas = bbox of the composed ones
+    s = lambda m: P._scale_to_hr(m, h, w)
+    w12_1, w12_2, w23_1, w23_2 = s(a12['smooth_mesh1']), s(a12['smooth_mesh2']), s(a23['smooth_mesh1']), s(a23['smooth_mesh2'])
+    off = (w12_2 - w23_1).reshape(1, n, -1, 2).mean(dim=2).unsqueeze(2).unsqueeze(2)
+    first = [float(v) for v in P._bbox([w12_1, w12_2, w23_1 + off, w23_2 + off])]
+    om1, omid, om3 = P.three_view_compose(a12['smooth_mesh1'], a12['smooth_mesh2'], a23['smooth_mesh1'], a23['smooth_mesh2'], h, w)
+    box = [float(v) for v in P._bbox([om1, omid, om3])]
+    hrd = [[f.to(dev) for f in v] for v in hr]
+    lrd = [[f.to(dev) for f in v] for v in lr]
+    k = 16
+    for fusion in ('AVERAGE', 'LINEAR'):
+        ofr, owc, ohc = P.three_view_render(hr[0], hr[1], hr[2], om1, omid, om3, 'NORMAL', fusion)
+        st = ThreeViewOnlineStitcher(hip_nets, h, w, canvas=box, first_canvas=first, fusion_mode=fusion)
+        frames = []
+        for t in range(n):
+            frames += st.push(hrd[0][t], hrd[1][t], hrd[2][t], lrd[0][t], lrd[1][t], lrd[2][t])
+        assert len(frames) == n and (st.hc, st.wc) == (int(ohc), int(owc))
+        assert st.overflow_report()['frames_seen'] == n and st.clipped_frames == 0
+        got = np.stack([cases.box_down(f.permute(1, 2, 0).cpu().numpy(), k) for f in frames])
+        ref = np.stack([cases.box_down(f.numpy().transpose(1, 2, 0), k) for f in ofr])
+        rng = np.stack([cases.box_iqr(f.numpy().transpose(1, 2, 0), k) for f in ofr])
+        if fusion == 'AVERAGE':
+            xlim = int(float(omid[..., 0].max() - box[0]) // k) - 1
+            ok = cases.smooth_boxes(rng, k)
+            ok[:, :, xlim:] = False
+            assert ok.mean() > 0.3, ok.mean()
+            dd = np.abs(got - ref)[ok]
+            print('\n[3-view stream vs oracle, AVERAGE] p99 %.3e max %.3e' % (np.quantile(dd, 0.99), dd.max()))
+            assert np.quantile(dd, 0.99) < 0.05 and dd.max() < 3.0, (float(np.quantile(dd, 0.99)), float(dd.max()))
+            clean = cases.smooth_boxes(rng, k)
+            assert np.median(np.abs(got - ref)[clean]) < 0.02
+        else:
+            close_boxes(got, ref, rng, 0.3, 'three-view LINEAR stream vs oracle', k=k, cover=0.5)
+
+
+def test_three_view_stream_shares_the_middle_view_and_grows_its_canvas(dev, hip_nets):
+    """(a) chain mode: a steady-state push sends THREE images through the twin trunks (one stem launch over 3 frames x 2 banks),
+    and its meshes equal the unshared batch of two pairs (four image passes) within the kernel-choice tolerance;
+    (b) grow='recapture': a triple stream whose outer views drift apart grows its output canvas before anything is cropped, where
+    grow='never' counts cropped frames."""
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.online import ThreeViewOnlineStitcher, MultiOnlineStitcher
+    n, h, w = 16, 180, 320
+    hr, lr = synth.make_clip(n, h, w, seed=4, views=3)
+    hrd = [[f.to(dev) for f in v] for v in hr]
+    lrd = [[f.to(dev) for f in v] for v in lr]
+    stems = []
+    real = ops.H.call
+
+    def spy(name, *a):
+        if name == 'ss_stem_pool':
+            stems.append(a[4])                   # images of the launch
+        return real(name, *a)
+    res = {}
+    for chain in (True, False):
+        ms = MultiOnlineStitcher(hip_nets, h, w, streams=2, use_graph=False, meshes_only=True, chain=chain)
+        got = []
+        for t in range(n):
+            if t == 10:
+                ops.H.call = spy
+            try:
+                r = ms.push(None, None, torch.cat((lrd[0][t], lrd[1][t])), torch.cat((lrd[1][t], lrd[2][t])))
+            finally:
+                ops.H.call = real
+            if r is not None:
+                got.append(torch.stack((r[0][:, -1], r[1][:, -1]), 0).clone())
+        res[chain] = torch.stack(got, 0)
+        assert stems == ([3] if chain else [4]), stems
+        del stems[:]
+    assert float((res[True] - res[False]).abs().max()) < 1e-3
+    # (b) drifting outer views
+    def run(grow):
+        st = ThreeViewOnlineStitcher(hip_nets, h, w, grow=grow, use_graph=True)
+        out = []
+        for t in range(40):
+            i = t % n
+            dx = 0 if t < 14 else int(min(t - 14, 16) * 1.5)          # views 1 and 3 slide outwards by up to 24 px (7.5 % of the width)
+            h1 = torch.roll(hrd[0][i], -dx, -1); h3 = torch.roll(hrd[2][i], dx, -1)
+            l1 = torch.roll(lrd[0][i], -int(dx * 480 / w), -1); l3 = torch.roll(lrd[2][i], int(dx * 480 / w), -1)
+            out += st.push(h1, hrd[1][i], h3, l1, lrd[1][i], l3)
+        torch.cuda.synchronize()
+        return st, out
+    never, _ = run('never')
+    rep = never.overflow_report()
+    grown, frames = run('recapture')
+    repg = grown.overflow_report()
+    assert rep['frames_seen'] == repg['frames_seen'] == 40
+    if rep['clipped_frames'] > 0:                # (the synthetic regressors follow the drift: when they do, growth must prevent the cropping)
+        assert repg['clipped_frames'] < rep['clipped_frames'] and grown.canvas_epoch >= 1 and grown.wc > never.wc
+    assert all(bool(torch.isfinite(f).all()) for f in frames)
