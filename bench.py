@@ -358,6 +358,9 @@ def parse_args(argv=None):
     ap.add_argument('--share-device', action='store_true',
                     help='multi-rank readiness check on a 1-GPU box: every rank drives cuda:0 (real kernels, per-rank clip seeds, '
                          'the gather and the N > 1 JSON line; use with --backend gloo -- RCCL refuses two ranks on one device)')
+    ap.add_argument('--also-360', action='store_true',
+                    help='N > 1: append the 360x480 64-frame configuration (configs[1]) measured on ALL ranks (north_star: both '
+                         'resolutions at 1 / 2 / 4 / 8 GPUs); N = 1 has it under other_configs already')
     ap.add_argument('--stub-step-ms', type=float, default=0.0,
                     help='launcher self-test without GPUs: every step is a sleep of this many ms (backend gloo)')
     return ap.parse_args(argv)
@@ -688,11 +691,23 @@ def main():
         dt = time.perf_counter() - t0
         rec = torch.tensor([float(args.frames * args.steps), dt, 0.0, 0.0, float(rank)], dtype=torch.float64)
         allrec = ssdist.gather_records(rec, dist, None, args.force_collective)
+        # (self-test of the device-identity check: SS_STUB_PCI = comma-separated fake PCI bus ids, one per rank)
+        fake = os.environ.get('SS_STUB_PCI', '').split(',')
+        idents = ssdist.gather_objects({'pci_bus_id': fake[rank] if rank < len(fake) and fake[rank] else 'stub:%02d' % rank,
+                                        'uuid': None, 'name': 'stub', 'hostname': socket.gethostname()}, dist)
+        clash = ssdist.shared_devices(idents)
+        if clash and not args.share_device:
+            if dist is not None:
+                dist.destroy_process_group()
+            raise SystemExit('bench.py: ranks %s drive ONE physical device (%s); refusing to print a multi-GPU line (pass '
+                             '--share-device for the single-GPU readiness check)' % (clash, idents[clash[0][0]]['pci_bus_id']))
         if rank == 0:
             emit(({'metric': 'launcher self-test (stubbed step)', 'value': round(ssdist.aggregate_fps(allrec), 3),
                               'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                               'ms_per_step': round(float(allrec[:, 1].max()) / args.steps * 1e3, 3), 'scaling': 'weak',
                               'ranks': dist.get_world_size() if dist is not None else 1, 'backend': 'gloo',
+                              'ranks_seen_by_backend': dist.get_world_size() if dist is not None else 1,
+                              'per_rank_pci_bus_id': [d['pci_bus_id'] for d in idents],
                               'per_rank_seconds': [round(float(x), 4) for x in allrec[:, 1]],
                               'clip_seeds': [int(x) for x in allrec[:, 4]]}))
         if dist is not None:
@@ -784,6 +799,34 @@ def main():
                         float(-1 if not host or host.get('cpu_last') is None else host['cpu_last'])], dtype=torch.float64)
     # the only collective: result gather (RCCL takes the record from device memory, gloo from the host)
     allrec = ssdist.gather_records(rec, dist, dev if args.backend == 'nccl' else None, args.force_collective)
+    # physical identity of every rank's GPU (PCI bus id, UUID): the local index above is an echo of the launcher's numbering
+    idents = ssdist.gather_objects(ssdist.device_identity(dev), dist)
+    clash = ssdist.shared_devices(idents)
+    seen = dist.get_world_size() if dist is not None else 1
+    if (clash and not args.share_device) or seen != args.gpus:
+        if dist is not None:
+            dist.destroy_process_group()
+        if seen != args.gpus:
+            raise SystemExit('bench.py: --gpus %d but the process group has %d ranks' % (args.gpus, seen))
+        raise SystemExit('bench.py: ranks %s drive ONE physical device (%s); refusing to print a multi-GPU line (pass '
+                         '--share-device for the single-GPU readiness check)' % (clash, idents[clash[0][0]]))
+    also360 = None
+    if args.also_360 and world > 1:
+        # configs[1] on every rank (its own clip seed), same bracket: barrier + synchronize on both sides, max over ranks
+        hr3, lr3 = synth.make_clip_device(64, 360, 480, seed=rank, device=dev)
+        for _ in range(2):
+            pipeline.run_two_view(hr3[0], hr3[1], lr3[0], lr3[1], nets)
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(10):
+            o3 = pipeline.run_two_view(hr3[0], hr3[1], lr3[0], lr3[1], nets)
+        sync()
+        rec3 = torch.tensor([640.0, time.perf_counter() - t3, float(o3[1]), float(o3[2]), float(rank)], dtype=torch.float64)
+        all3 = ssdist.gather_records(rec3, dist, dev if args.backend == 'nccl' else None, False)
+        also360 = {'workload': 'configs[1]: 360x480 2-view, 64-frame clip per step per GPU, 10 steps after 2 warm-up steps',
+                   'value': round(ssdist.aggregate_fps(all3), 1), 'unit': 'frames/s', 'n_gpus': world,
+                   'per_rank_seconds': [round(float(x), 4) for x in all3[:, 1]], 'ms_per_step': round(float(all3[:, 1].max()) * 100, 3)}
+        del hr3, lr3, o3
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -869,8 +912,17 @@ def main():
         result['per_rank_cpus_bound'] = [int(x) for x in allrec[:, 7]]
         result['per_rank_first_visible_device'] = [int(x) for x in allrec[:, 8]]
         result['per_rank_cpu_range'] = [[int(a), int(b)] for a, b in zip(allrec[:, 9], allrec[:, 10])]
+        result['ranks_seen_by_backend'] = seen
+        result['per_rank_pci_bus_id'] = [d.get('pci_bus_id') for d in idents]
+        result['per_rank_device_uuid'] = [d.get('uuid') for d in idents]
+        result['per_rank_hostname'] = [d.get('hostname') for d in idents]
+        result['distinct_physical_devices'] = len({(d.get('hostname'), d.get('pci_bus_id') or d.get('uuid') or 'rank%d' % r)
+                                                   for r, d in enumerate(idents)})
+        if also360 is not None:
+            result['also_360'] = also360
         if args.share_device:
             result['share_device'] = True
+            result['ranks_sharing_a_device'] = clash
     result['host'] = {'placement': host, 'HIP_VISIBLE_DEVICES': vis or None, 'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
                       'logical_cpus': os.cpu_count(), 'rccl_version': ssdist.collective_backend_version()}
     base = world == 1 and args.views == 2 and not args.online and args.io == 'f32' and not args.force_collective and not args.share_device

@@ -36,6 +36,9 @@ extern "C" {
 
 #define SS_WARP_NORMAL 0         /* the reference's clamped-index bilinear (utils/torch_tps_transform.py:30-106) */
 #define SS_WARP_FAST 1           /* F.grid_sample(bilinear, zeros, align_corners=True) (:158-162) */
+#define SS_WARP_EPS_FOLD 16      /* OR-ed into `mode` of the fused AVERAGE renders (ss_render_average*): the radial term as
+                                  * a log(a), a = dx^2 + (dy^2 + 1e-6), instead of the reference's d2 log(d2 + 1e-6)
+                                  * (utils/torch_tps_transform.py:108-137): ~1e-3 px at 720p, ~7 % of the kernel.  Opt-in. */
 
 SS_API int ss_version(void);
 SS_API const char* ss_error_string(int code);

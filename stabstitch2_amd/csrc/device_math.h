@@ -109,14 +109,22 @@ __device__ __forceinline__ void tps_eval_fast(const float* __restrict__ src, con
 // wave computes the 63 pairs once (lane k: control point k, tps_rows_table) and every lane reads them back as LDS
 // broadcasts; dx is shared by the two rows.  Per control point and lane: 6 VALU instructions + 2 v_log_f32 for two
 // points (the version that evaluated dx, dy and their squares per lane: 9 + 2).
+//
+// FOLD (opt-in, SS_WARP_EPS_FOLD): the reference's `+ 1e-6` is folded into the row table and the radial term
+// becomes a log2(a) with a = fma(dx, dx, dy2 + 1e-6) -- one packed instruction of five less per control point beside the two
+// quarter-rate logs -- instead of d2 log2(d2 + 1e-6): the term changes by 1e-6 log2(a) (<= 2e-5 of a term of order one), the
+// sampling coordinate by ~1e-3 px at 720p.  NOT the reference's arithmetic: never the default, never the headline.
+template <bool FOLD = false>
 __device__ __forceinline__ void tps_rows_table(const float* __restrict__ src, float y0, float y1, int lane,
                                                ss_f2* __restrict__ tab) {
     if (lane < SS_NV) {
         const float sy = src[2 * lane + 1];
         const float d0 = __fsub_rn(y0, sy), d1 = __fsub_rn(y1, sy);
-        tab[lane] = (ss_f2){__fmul_rn(d0, d0), __fmul_rn(d1, d1)};
+        tab[lane] = FOLD ? (ss_f2){__fadd_rn(__fmul_rn(d0, d0), 1e-6f), __fadd_rn(__fmul_rn(d1, d1), 1e-6f)}
+                         : (ss_f2){__fmul_rn(d0, d0), __fmul_rn(d1, d1)};
     }
 }
+template <bool FOLD = false>
 __device__ __forceinline__ void tps_eval_rows(const float* __restrict__ src, const float* __restrict__ T,
                                               const ss_f2* __restrict__ tab, float x, float y0, float y1, ss_f2& ox,
                                               ss_f2& oy) {
@@ -129,7 +137,7 @@ __device__ __forceinline__ void tps_eval_rows(const float* __restrict__ src, con
         const float dx = __fsub_rn(x, src[2 * k]);
         const ss_f2 dxx = {dx, dx};
         const ss_f2 d2 = __builtin_elementwise_fma(dxx, dxx, tab[k]);
-        const ss_f2 a = d2 + eps;
+        const ss_f2 a = FOLD ? d2 : d2 + eps;
         const ss_f2 lg = {__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)};
         const ss_f2 r = d2 * lg;
         const ss_f2 tx = {Tx[3 + k], Tx[3 + k]};

@@ -441,7 +441,7 @@ __device__ __forceinline__ unsigned char render_to_u8(float v) {          // `.a
 // then the next frame's: the light tail of one frame runs beside the heavy head of the next -- 32 launch boundaries and
 // 32 partially filled last rounds per clip less than one launch per frame).  Per-frame strides: `img_fs` / `out_fs` in
 // BYTES (frames of a view / canvases are equally spaced), `fp_fs` in floats; source [frame][VIEWS][63][2], T [frame][VIEWS][2][66].
-template <int VIEWS, bool U8>
+template <int VIEWS, bool U8, bool FOLD = false>
 __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, const float* __restrict__ source,
                                                              const float* __restrict__ T, const float* __restrict__ fp,
                                                              float* __restrict__ out, int h, int w, int hc, int wc,
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
     const float gya = linspace_at(-1.f, 1.f, hc, ya), gyb = linspace_at(-1.f, 1.f, hc, min(yb, hc - 1));
 #pragma unroll
     for (int k = 0; k < VIEWS; ++k)
-        if (mask & (1u << k)) tps_rows_table(source + k * SS_NV * 2, gya, gyb, lx, dytab[wv][k]);
+        if (mask & (1u << k)) tps_rows_table<FOLD>(source + k * SS_NV * 2, gya, gyb, lx, dytab[wv][k]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same wave reads it back: ordering only, no barrier
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float va[VIEWS][3], vb[VIEWS][3];
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
     for (int k = 0; k < VIEWS; ++k) {
         if (mask & (1u << k)) {
             ss_f2 px, py;
-            tps_eval_rows(source + k * SS_NV * 2, T + k * 2 * SS_NT, dytab[wv][k], gx, gya, gyb, px, py);
+            tps_eval_rows<FOLD>(source + k * SS_NV * 2, T + k * 2 * SS_NT, dytab[wv][k], gx, gya, gyb, px, py);
             if (U8) {
                 const unsigned char* img8 = reinterpret_cast<const unsigned char*>(rv.img[k]);
                 sample3_u8(img8, px.x, py.x, w, h, mode, va[k]);
@@ -546,11 +546,13 @@ static int render_average_launch(const void* const* imgs, const float* source, c
                                  long long footprint_floats, void* out, int frames, long long img_fs, long long out_fs,
                                  int views, int h, int w, int hc, int wc, int mode, void* stream, bool u8) {
     if (!imgs || !source || !T || !out || frames <= 0 || (views != 2 && views != 3) || h <= 1 || w <= 1 || hc <= 1 ||
-        wc <= 1 || ((mode & 0xFF) != SS_WARP_NORMAL && (mode & 0xFF) != SS_WARP_FAST))
+        wc <= 1 || ((mode & 0xEF) != SS_WARP_NORMAL && (mode & 0xEF) != SS_WARP_FAST))
         return SS_ERR_ARG;
 #ifndef SS_TUNING
     if (mode >> 8) return SS_ERR_ARG;
 #endif
+    const bool fold = (mode & SS_WARP_EPS_FOLD) != 0;
+    mode &= ~SS_WARP_EPS_FOLD;
     // a footprint row is only meaningful for the (views, canvas) it was built for: the kernel indexes its lattice and tile
     // order with this geometry, so a row of another size is an argument error, not an out-of-bounds read
     const long long fp_fs = ss_render_footprint_floats(views, hc, wc);
@@ -571,7 +573,15 @@ static int render_average_launch(const void* const* imgs, const float* source, c
         const float* t_ = T + (long long)f0 * views * 2 * SS_NT;
         const float* p_ = footprint ? footprint + (long long)f0 * fp_fs : nullptr;
         float* o = reinterpret_cast<float*>(static_cast<char*>(out) + (long long)f0 * out_fs);
-        if (views == 2) {
+        if (fold) {        // opt-in: the reference's + 1e-6 folded into the row table (not its arithmetic; see device_math.h)
+            if (views == 2) {
+                if (u8) hipLaunchKernelGGL((render_average_kernel<2, true, true>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+                else hipLaunchKernelGGL((render_average_kernel<2, false, true>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+            } else {
+                if (u8) hipLaunchKernelGGL((render_average_kernel<3, true, true>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+                else hipLaunchKernelGGL((render_average_kernel<3, false, true>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
+            }
+        } else if (views == 2) {
             if (u8) hipLaunchKernelGGL((render_average_kernel<2, true>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
             else hipLaunchKernelGGL((render_average_kernel<2, false>), g, dim3(256), 0, st, r, s_, t_, p_, o, h, w, hc, wc, mode, img_fs, out_fs, fp_fs);
         } else {

@@ -38,3 +38,46 @@ def collective_backend_version():
 def aggregate_fps(records):
     """records [world, >=2] with columns (frames, seconds, ...): whole-job fps = sum(frames) / max(seconds)."""
     return float(records[:, 0].sum()) / float(records[:, 1].max())
+
+
+def device_identity(device):
+    """Physical identity of the GPU behind `device`: {'pci_bus_id', 'uuid', 'name', 'hostname'} (strings; None where the
+    platform does not tell).  A rank's LOCAL device index says nothing about which GPU it drives (HIP_VISIBLE_DEVICES remaps):
+    the multi-GPU bench line carries these per rank and refuses to print when two ranks sit on one physical device."""
+    import socket
+    from . import hostbind
+    ident = {'pci_bus_id': None, 'uuid': None, 'name': None, 'hostname': socket.gethostname()}
+    try:
+        ident['pci_bus_id'] = hostbind.gpu_pci_bus_id(device)
+    except Exception:
+        pass
+    try:
+        props = torch.cuda.get_device_properties(device)
+        ident['name'] = props.name
+        u = getattr(props, 'uuid', None)
+        ident['uuid'] = None if u is None else str(u)
+    except Exception:
+        pass
+    return ident
+
+
+def gather_objects(obj, dist=None):
+    """One picklable object per rank -> list over ranks (identity without an initialised process group)."""
+    if dist is None or not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def shared_devices(identities):
+    """identities: list of device_identity dicts (one per rank) -> list of rank groups that sit on ONE physical device (empty
+    when every rank has its own).  Two ranks share a device when host and PCI bus id (or, without one, the UUID) coincide; a
+    rank whose platform reports neither is its own group (nothing can be said)."""
+    groups = {}
+    for r, d in enumerate(identities):
+        key = d.get('pci_bus_id') or d.get('uuid')
+        if key is None:
+            continue
+        groups.setdefault((d.get('hostname'), key), []).append(r)
+    return [g for g in groups.values() if len(g) > 1]

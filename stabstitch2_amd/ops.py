@@ -730,6 +730,13 @@ def window_push(ring, src, src_off, state=None, blocks=0, block=0, stride=0, del
 
 # ------------------------------------------------------------------ render
 MODES = {'NORMAL': 0, 'FAST': 1}
+# Opt-in (SS_RENDER_EPS_FOLD=1): the fused AVERAGE renders fold the reference's + 1e-6 into their row table
+# (SS_WARP_EPS_FOLD): not the reference's arithmetic (~1e-3 px), never the default.
+RENDER_EPS_FOLD = os.environ.get('SS_RENDER_EPS_FOLD', '0') == '1'
+
+
+def _avg_mode(mode):
+    return MODES[mode] | (16 if RENDER_EPS_FOLD else 0)
 
 
 def tps_warp(U, source, T, hc, wc, mode='NORMAL', with_mask=False):
@@ -768,7 +775,7 @@ def render_average(imgs, source, T, hc, wc, mode='NORMAL', out=None, footprint=N
         out = torch.empty((3, hc, wc), device=imgs[0].device, dtype=torch.float32)
     fp, fpn = _fp_args(footprint)
     H.call('ss_render_average', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, H.dptr(out), v, h, w, hc, wc,
-           MODES[mode], H.stream())
+           _avg_mode(mode), H.stream())
     return out
 
 
@@ -784,7 +791,7 @@ def render_average_u8(frames, source, T, hc, wc, mode='NORMAL', out=None, footpr
         out = torch.empty((hc, wc, 3), device=frames[0].device, dtype=torch.uint8)
     fp, fpn = _fp_args(footprint)
     H.call('ss_render_average_u8', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, _u8ptr(out), v, h, w, hc, wc,
-           MODES[mode], H.stream())
+           _avg_mode(mode), H.stream())
     return out
 
 
@@ -800,7 +807,7 @@ def render_average_clip(views, source, T, hc, wc, mode='NORMAL', out=None, footp
     assert tuple(out.shape) == (n, 3, hc, wc)
     fp, fpn = H.dptr(footprint, True), (0 if footprint is None else footprint.shape[-1])
     H.call('ss_render_average_clip', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, H.dptr(out), n, v, h, w, hc, wc,
-           MODES[mode], H.stream())
+           _avg_mode(mode), H.stream())
     return out
 
 
@@ -815,7 +822,7 @@ def render_average_clip_u8(views, source, T, hc, wc, mode='NORMAL', out=None, fo
     assert tuple(out.shape) == (n, hc, wc, 3)
     fp, fpn = H.dptr(footprint, True), (0 if footprint is None else footprint.shape[-1])
     H.call('ss_render_average_clip_u8', arr, H.dptr(_f(source)), H.dptr(T), fp, fpn, _u8ptr(out), n, v, h, w, hc, wc,
-           MODES[mode], H.stream())
+           _avg_mode(mode), H.stream())
     return out
 
 

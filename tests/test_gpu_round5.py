@@ -325,7 +325,7 @@ def test_bench_eight_ranks_share_one_gpu():
     env = dict(os.environ)
     env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--share-device',
-                        '--steps', '2', '--warmup', '1', '--frames', '8', '--no-cpu-baseline', '--no-other-configs'],
+                        '--steps', '2', '--warmup', '1', '--frames', '8', '--no-cpu-baseline', '--no-other-configs', '--also-360'],
                        capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -336,6 +336,13 @@ def test_bench_eight_ranks_share_one_gpu():
     assert len(d['per_rank_seconds']) == 8 and all(s > 0 for s in d['per_rank_seconds'])
     assert abs(d['value'] - 8 * 8 * 2 / max(d['per_rank_seconds'])) < 1e-2 * d['value']
     assert d['scaling'] == 'weak' and 'x 8 GPUs = configs[3]' in d['config']['workload']
+    # round 6: physical identity per rank (PCI bus id / UUID, not the launcher's index), what the backend saw, and the
+    # 360x480 configuration measured on all ranks
+    assert d['ranks_seen_by_backend'] == 8 and len(d['per_rank_pci_bus_id']) == 8 and len(set(d['per_rank_pci_bus_id'])) == 1
+    assert d['distinct_physical_devices'] == 1 and d['ranks_sharing_a_device'] == [list(range(8))]
+    assert len(d['per_rank_device_uuid']) == 8 and len(set(d['per_rank_hostname'])) == 1
+    a = d['also_360']
+    assert a['n_gpus'] == 8 and len(a['per_rank_seconds']) == 8 and abs(a['value'] - 8 * 640 / max(a['per_rank_seconds'])) < 1e-2 * a['value']
     assert d['host']['GPU_MAX_HW_QUEUES'] == '16'                       # every rank's runtime has its own 16 hardware queues
     ranges = d['per_rank_cpu_range']
     if all(a >= 0 for a, _ in ranges):                                   # (hosts without NUMA information bind nothing: -1)
@@ -344,6 +351,11 @@ def test_bench_eight_ranks_share_one_gpu():
         assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), ranges      # ... split into disjoint CPU slices
         assert all(c >= 1 for c in d['per_rank_cpus_bound'])
     print('\n[8 ranks on one GPU] %.1f frames/s aggregate, per-rank seconds %s, cpu slices %s' % (d['value'], d['per_rank_seconds'], ranges))
+    # the same launch WITHOUT --share-device: two ranks on one physical device are refused (no line, non-zero exit)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '0',
+                         '--frames', '8', '--no-cpu-baseline', '--no-other-configs'], capture_output=True, text=True, timeout=900,
+                        env=dict(env, HIP_VISIBLE_DEVICES='0,0'), cwd=ROOT)
+    assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith('{')], r2.stdout[-1000:]
 
 
 @pytest.mark.parametrize('shape', [(4, 23, 30, 256, 256, True, True), (2, 33, 31, 32, 64, True, False), (1, 16, 29, 16, 128, False, True),

@@ -251,3 +251,26 @@ def test_three_view_stream_shares_the_middle_view_and_grows_its_canvas(dev, hip_
     if rep['clipped_frames'] > 0:                # (the synthetic regressors follow the drift: when they do, growth must prevent the cropping)
         assert repg['clipped_frames'] < rep['clipped_frames'] and grown.canvas_epoch >= 1 and grown.wc > never.wc
     assert all(bool(torch.isfinite(f).all()) for f in frames)
+
+
+def test_render_eps_fold_is_opt_in_and_within_the_gates(dev, golden, hip_nets, clip16, monkeypatch):
+    """VERDICT r5 item 7, measured instead of declined: SS_RENDER_EPS_FOLD=1 (SS_WARP_EPS_FOLD on the fused AVERAGE renders: the
+    reference's + 1e-6 folded into the row table, a log(a) instead of d2 log(d2 + 1e-6)) is OFF by default; switched on, the fused
+    render still passes the reference's gates -- G7 (fused AVERAGE frame), G9 (16-frame pipeline: canvas, box medians, PSNR / SSIM)
+    and G13 (uint8 bytes vs the reference's writer) -- and its deviation from the default render is reported."""
+    import test_gpu_parity as TP
+    import test_gpu_round3 as T3
+    from stabstitch2_amd import ops, pipeline
+    assert ops.RENDER_EPS_FOLD is False and ops._avg_mode('NORMAL') == 0
+    hr, lr = synth.make_clip_device(8, 720, 1280, seed=0, device=dev)
+    f0, hc, wc, m1, m2 = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets)
+    monkeypatch.setattr(ops, 'RENDER_EPS_FOLD', True)
+    assert ops._avg_mode('NORMAL') == 16 and ops._avg_mode('FAST') == 17
+    f1 = pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], hip_nets)[0]
+    d = (f1 - f0).abs()
+    print('\n[eps fold vs default, 720p AVERAGE] median %.2e  p99.9 %.2e  max %.2e grey levels'
+          % (float(d.median()), float(torch.quantile(d.flatten()[::97], 0.999)), float(d.max())))
+    assert float(d.median()) < 2e-3 and float(torch.quantile(d.flatten()[::97], 0.999)) < 0.2
+    TP.test_tps_dense_warp_and_fusion(dev, golden)                  # G6 / G7: the fused AVERAGE frame under the switch
+    TP.test_pipeline_vs_reference(dev, golden, hip_nets, clip16)    # G9
+    T3.test_u8_pipeline_bytes_vs_reference(dev, golden, hip_nets)   # G13: the reference writer's bytes

@@ -228,6 +228,16 @@ def test_bench_self_launches_ranks_and_gathers():
     # whole-job value = all ranks' frames / slowest rank (rank 1 sleeps twice as long per step)
     assert out['per_rank_seconds'][1] >= out['per_rank_seconds'][0] * 0.9
     assert abs(out['value'] - 2 * 32 * 3 / max(out['per_rank_seconds'])) / out['value'] < 0.05
+    assert out['ranks_seen_by_backend'] == 2 and out['backend'] == 'gloo' and len(set(out['per_rank_pci_bus_id'])) == 2
+    # two ranks that report ONE physical device (same host, same PCI bus id): refused without --share-device, printed with it
+    env3 = dict(env, SS_STUB_PCI='0000:05:00.0,0000:05:00.0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--frames', '8',
+           '--backend', 'gloo', '--stub-step-ms', '5']
+    r3 = subprocess.run(cmd, capture_output=True, text=True, env=env3, timeout=300)
+    assert r3.returncode != 0 and 'ONE physical device' in (r3.stderr + r3.stdout)
+    assert not [ln for ln in r3.stdout.splitlines() if ln.startswith('{')]
+    r4 = subprocess.run(cmd + ['--share-device'], capture_output=True, text=True, env=env3, timeout=300)
+    assert r4.returncode == 0 and len([ln for ln in r4.stdout.splitlines() if ln.startswith('{')]) == 1, r4.stderr[-2000:]
     # N = 1 never spawns; a launcher-provided WORLD_SIZE that disagrees with --gpus is refused
     env2 = dict(env, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub-step-ms', '1'],
