@@ -53,6 +53,7 @@ SIGNATURES = {
     'ss_cost_volume': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_cost_volume_bidir': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_cost_volume_set_tile': (c_i, [c_i]),
+    'ss_wino43_set_persistent': (c_i, [c_i]),
     'ss_tensor_dlt': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
     'ss_spatial_decompose': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
     'ss_spatial_meshes': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),

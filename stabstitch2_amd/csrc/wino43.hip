@@ -567,6 +567,440 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
 #endif
 }
 
+// The same kernel with PERSISTENT workgroups (round 6): one workgroup per CU walks its share of the launch's tile
+// blocks and requests block n + 1's chunk-0 rows and first two filter groups in front of block n's epilogue.  A workgroup is alone
+// on its CU (144 KB of LDS), so nothing else can hide the prologue's loaded HBM round trip; the registers it needs (rr: 24, u: 24)
+// are free once the last MFMA of a block has issued.  Arithmetic per output identical to conv_wino43_kernel: bit-identical results.
+template <bool RES, bool ONE = false, int GEO = 0>
+__global__ __launch_bounds__(512, 1) void conv_wino43p_kernel(W43P p) {
+    constexpr int ABL = 0;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using Gm = XG<GEO>;
+    constexpr int X_ROWP = Gm::ROWP, X_PL = Gm::PL, X_V1F = 8 * Gm::PL, X_RW = Gm::RW, X_TXU = Gm::TXU;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = wave & 1;                              // 32-channel half of the workgroup's 64 output channels
+    const int pa = wave >> 2, pbb = (wave >> 1) & 1;        // position block: rows 3 pa .., columns 3 pbb ..
+
+    // ---- the workgroup is PERSISTENT: it walks tile blocks blockIdx.x, blockIdx.x + gridDim.x, ... of the launch (XCD-aware order,
+    // as wino.hip: every XCD gets one contiguous run of blocks; gridDim.x is a multiple of 8, so a workgroup's blocks stay on its
+    // XCD), and requests the NEXT block's raw rows and first filters before the current block's epilogue: the prologue's loaded HBM
+    // round trip (5k of a layer1 workgroup's 66k clocks, r05_wino43_ablations.txt) hides behind the dump / combine phases.
+    const unsigned nblocks = p.N * p.nbx * p.nby * p.ncb;
+    unsigned cbk = 0, img = 0;
+    int oy0 = 0, ox0 = 0;
+    auto decode = [&](unsigned it, unsigned& cbk_, unsigned& img_, int& oy_, int& ox_) __attribute__((always_inline)) {
+        unsigned lin = it;
+        if (nblocks >= 16) {
+            const unsigned q = nblocks / 8, r = nblocks % 8, xcd = lin % 8, idx = lin / 8;
+            lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        const unsigned mb = ss_div32(lin, p.divNcb);
+        cbk_ = lin - mb * p.ncb;                            // 64-channel output block
+        const unsigned t1 = ss_div32(mb, p.divBx);
+        const int bx = (int)(mb - t1 * p.nbx);
+        img_ = ss_div32(t1, p.divBy);
+        const int by = (int)(t1 - img_ * p.nby);
+        oy_ = by * Gm::BH;
+        ox_ = bx * Gm::BW;
+    };
+    const int grp = blockIdx.z;
+
+    const __amdgpu_buffer_rsrc_t rin = x_rsrc(p.in + (long long)grp * p.in_gs, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t ru = x_rsrc(p.U + (long long)grp * p.u_gs, p.u_bytes);
+
+    // ---- stage 1 item of this thread: (channel quad q, raw column xx, tile row ty); threads 496..511 carry no pixel: their
+    // loads are out of range (zeros) and their writes land in the two pad columns of V1
+    const int s1_q = tid & 3;
+    const int s1_pix = tid >> 2;
+    const bool s1_real = GEO == 1 || s1_pix < 2 * X_RW;
+    const int s1_ty = GEO == 1 ? (s1_pix >> 5) : (s1_real ? (s1_pix >= X_RW ? 1 : 0) : ((s1_pix >> 1) & 1));
+    const int s1_xx = GEO == 1 ? (s1_pix & 31) : (s1_real ? s1_pix - s1_ty * X_RW : X_RW + (s1_pix & 1));
+    const unsigned rowstep = (unsigned)p.W * (unsigned)p.C * 4u;
+    unsigned rbase = 0u;
+    // rows of the item that lie inside the image (bit r); v_bfe_i32 turns a bit into the all-ones "out of range" mask
+    int rmask = 0;
+    auto s1_block = [&](unsigned img_, int oy_, int ox_) __attribute__((always_inline)) {       // the item's addressing in block (img_, oy_, ox_)
+        // (the item's indices re-derived from the thread id behind an opaque copy, as epi_setup does: kept from the kernel's entry
+        // they were five more registers live across the K loop, where the allocator has none to spare)
+        int t_ = threadIdx.x;
+        asm volatile("" : "+v"(t_));
+        const int q_ = t_ & 3, pix_ = t_ >> 2;
+        const bool real_ = GEO == 1 || pix_ < 2 * X_RW;
+        const int ty_ = GEO == 1 ? (pix_ >> 5) : (real_ ? (pix_ >= X_RW ? 1 : 0) : ((pix_ >> 1) & 1));
+        const int xx_ = GEO == 1 ? (pix_ & 31) : (real_ ? pix_ - ty_ * X_RW : X_RW + (pix_ & 1));
+        const int s1_iy0 = oy_ - 1 + 4 * ty_, s1_ix = ox_ - 1 + xx_;
+        rbase = ((((unsigned)img_ * p.H + (unsigned)s1_iy0) * p.W + (unsigned)s1_ix) * (unsigned)p.C + 4u * q_) * 4u;
+        rmask = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            rmask |= (real_ && (unsigned)(s1_iy0 + r) < (unsigned)p.H && (unsigned)s1_ix < (unsigned)p.W) ? 0 : (1 << r);
+    };
+    const int s1_lds = (2 * s1_q) * X_PL + Gm::tyoff(s1_ty) + ((s1_xx & 2) ? Gm::boff(s1_ty) : 0) + (s1_xx >> 2) * 4 + (s1_xx & 1) * 2;
+    auto zero_cols = [&]() __attribute__((always_inline)) {
+        if constexpr (GEO == 1) {
+            // window columns 32, 33 (image columns 31, 32: past every map this geometry takes) = entry A[8] of every V1 row of both
+            // buffers: zeros, written per block (the epilogue's stage overwrites them) -- 2 buffers x 8 pairs x 4 tile rows x 6 rows =
+            // 384 entries (made visible by the prologue's barrier)
+            if (tid < 384) {
+                const int bufi = tid / 192, r = tid - bufi * 192;          // r = (pair, tile row, row)
+                *reinterpret_cast<x_f32x4*>(smem + bufi * X_V1F + (r / 24) * X_PL + Gm::tyoff((r % 24) / 6) + ((r % 24) % 6) * X_ROWP + 4 * Gm::TXS) = (x_f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    // ---- this lane in the GEMMs (v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5]): tile lane & 31, channels
+    // 8 kh .. 8 kh + 7 of the chunk = pairs 4 kh .. 4 kh + 3
+    const int kh = lane >> 5;
+    const int m_tile = lane & 31;
+    const int m_ty = GEO == 1 ? (m_tile >> 3) : (m_tile >> 4), m_tx = GEO == 1 ? (m_tile & 7) : (m_tile & 15);
+    const int t_srcA = (4 * kh) * X_PL + Gm::tyoff(m_ty) + (3 * pa) * X_ROWP + 4 * m_tx;
+    const int t_srcB = t_srcA + Gm::boff(m_ty);
+    const x_f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f};
+
+    const unsigned u_lane = (unsigned)lane * 16u;
+    // packed filters: [cout/32][chunk][pos 36][half][lane][4]
+    unsigned u_wave = 0u;
+    auto u_block = [&](unsigned cbk_) __attribute__((always_inline)) {
+        u_wave = (cbk_ * 2u + (unsigned)blk) * (unsigned)p.nchunk * X_UCHUNK + (unsigned)((3 * pa) * 6 + 3 * pbb) * X_UPOS;
+    };
+
+    x_f32x16 acc[3][3];
+    auto acc_zero = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][s][r] = 0.f;
+    };
+
+    x_f32x4 rr[6];
+    if constexpr (ABL & 2) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) rr[r] = (x_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto raw_issue = [&](int c) __attribute__((always_inline)) {
+        if constexpr (ABL & 2) return;
+        const unsigned coff = (unsigned)c * 64u;
+        int rm = rmask;
+        asm volatile("" : "+v"(rm));         // (left alone, hipcc hoists the six masks out of the K loop and spills them)
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            rr[r] = __builtin_bit_cast(x_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rbase + (unsigned)r * rowstep + coff) | (unsigned)__builtin_amdgcn_sbfe(rm, r, 1), 0, 0));
+    };
+    // row transform B^T d of channel pair pr of the quad (rows 0..2 when half == 0, rows 3..5 when half == 1), packed over the pair
+    auto s1_piece = [&](float* buf, int pr, int half) __attribute__((always_inline)) {
+        if constexpr (ABL & 2) return;
+        auto D = [&](int r) __attribute__((always_inline)) { return pr ? X_HI(rr[r]) : X_LO(rr[r]); };
+        float* w = buf + s1_lds + pr * X_PL;
+        auto put = [&](int i, x_f32x2 v) __attribute__((always_inline)) { *reinterpret_cast<x_f32x2*>(w + i * X_ROWP) = v; };
+        if (half == 0) {
+            const x_f32x2 t1 = x_pk_nk(k4, D(2), D(4));
+            const x_f32x2 t2 = x_pk_nk(k4, D(1), D(3));
+            put(0, x_pk_k(k4, D(0), x_pk_nk(k5, D(2), D(4))));
+            put(1, x_pk_add(t1, t2));
+            put(2, x_pk_sub(t1, t2));
+        } else {
+            const x_f32x2 t3 = x_pk_sub(D(4), D(2));
+            const x_f32x2 t4 = x_pk_sub(D(3), D(1));
+            put(3, x_pk_k(k2, t4, t3));
+            put(4, x_pk_nk(k2, t4, t3));
+            put(5, x_pk_k(k4, D(1), x_pk_nk(k5, D(3), D(5))));
+        }
+    };
+    auto lds_barrier = [&]() __attribute__((always_inline)) {       // __syncthreads() minus its global-memory fence (it would drain every prefetch in flight)
+        if constexpr (ABL & 16) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+
+    // filters of one GROUP = (chunk, half h, position row g): three positions x 16 bytes (MFMA steps 4 h .. 4 h + 3)
+    x_f32x4 u[3][3];
+    if constexpr (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) u[i][j] = (x_f32x4){(float)lane, 1.f, 2.f, (float)(i + j)};
+    }
+    auto u_issue = [&](int set, int c, int G) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        const int h = G / 3, g = G % 3;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int so = (int)__builtin_amdgcn_readfirstlane(u_wave + (unsigned)c * X_UCHUNK + (unsigned)(g * 6 + s) * X_UPOS + (unsigned)h * 1024u);
+            u[set][s] = __builtin_bit_cast(x_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane, so, 0));
+        }
+    };
+
+    // ---- prologue: chunk 0 row-transformed in LDS, chunk 1's rows and the first two filter groups in flight.  Runs INSIDE each of
+    // the two column-block copies of the K loop: hipcc structurizes the (wave-uniform) branch between them as "copy 0, then maybe
+    // copy 1", so whatever the prologue leaves in registers for copy 1 is live across all of copy 0 -- it spilled 47 registers (12
+    // prefetched vectors) to scratch around copy 0 for that: 114 KB of scratch stores per workgroup, as much as the output tile
+    // `pre`: this block's chunk-0 rows and first two filter groups were requested in front of the previous block's epilogue
+    auto prologue = [&](bool pre) __attribute__((always_inline)) {
+        acc_zero();
+        if (!pre) raw_issue(0);
+        u_issue(0, 0, 0);           // (filters come from L2 -- every workgroup reads the same ones: not worth 24 registers across the epilogue)
+        u_issue(1, 0, 1);
+        zero_cols();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s1_piece(smem, k >> 1, k & 1);
+        lds_barrier();
+        if constexpr (!ONE) raw_issue(1);
+    };
+
+    // ---- epilogue addressing and the residual: set up inside the LAST chunk (live ranges do not cross the K loop), the residual
+    // of the first phase requested there too -- behind the chunk's last filter loads, so no wait of the stream covers it
+    float* __restrict__ out = p.out + (long long)grp * p.out_gs;
+    const __amdgpu_buffer_rsrc_t rout = x_rsrc(out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = x_rsrc(RES ? p.res + (long long)grp * p.out_gs : out, p.out_bytes);
+    int e_n, tx, kh_e, lane_e;
+    unsigned pixb, rowb, base;
+    unsigned roff[4], cinv[4];
+    x_f32x2 rv[4][4];
+    auto epi_setup = [&]() __attribute__((always_inline)) {
+        // (thread indices re-derived behind an opaque copy: hipcc otherwise computes these addresses in front of the K loop and
+        // spills them across it)
+        int tid_e = threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        e_n = tid_e & 31;
+        tx = tid_e >> 5;
+        lane_e = tid_e & 63;
+        kh_e = lane_e >> 5;
+        // pixel offsets: row part per a -- 0xFFFF0000 (past every buffer the launcher admits) for rows outside the image -- plus
+        // y * pixel pitch, or-ed with the column's out-of-range mask (columns past the image, the idle tile slot)
+        // tile `tx` of a phase's 16: GEO 0 -- column tx of tile row `phase`; GEO 1 -- column tx & 7 of tile row 2 phase + (tx >> 3)
+        const int txc = GEO == 1 ? (tx & 7) : tx;
+        const int oxb = ox0 + 4 * txc;
+        pixb = (unsigned)p.out_cs * 4u;
+        rowb = pixb * (unsigned)p.W;
+        base = ((((unsigned)img * p.H + oy0) * p.W + oxb) * (unsigned)p.out_cs + cbk * 64 + 2 * e_n) * 4u;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) cinv[y] = (txc < X_TXU && oxb + y < p.W) ? 0u : 0xFFFFFFFFu;
+    };
+    auto row_offsets = [&](int ty) __attribute__((always_inline)) {
+        const int trow = GEO == 1 ? 2 * ty + (tx >> 3) : ty;        // tile row of this thread's tile in phase ty
+#pragma unroll
+        for (int a = 0; a < 4; ++a) roff[a] = oy0 + 4 * trow + a < p.H ? base + (unsigned)(4 * trow + a) * rowb : 0xFFFF0000u;
+    };
+    // residual of output column y of the current phase's rows (roff)
+    auto res_col = [&](int y) __attribute__((always_inline)) {
+        if constexpr (RES) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                rv[y][a] = __builtin_bit_cast(x_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, (roff[a] + (unsigned)y * pixb) | cinv[y], 0, 0));
+        }
+    };
+
+    auto kloop = [&](auto bc, bool pre) __attribute__((always_inline)) {
+        constexpr int B = decltype(bc)::value;          // column block of this wave (compile time: the column transform differs)
+        prologue(pre);
+        x_f32x4 rd[3];                                   // the window row of one pair step: A[tx], B[tx], A[tx + 1]
+        x_f32x2 av[2][3];
+        if constexpr (ABL & (4 | 8)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rd[i] = (x_f32x4){(float)lane, 1.f, 2.f, 3.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i][0] = av[i][1] = av[i][2] = (x_f32x2){(float)(lane + i), 1.f};
+        }
+        // pair step M of a chunk = (half h = M / 6, position row g = (M / 2) % 3, channel pair e2 = M % 2 of the half's four channels):
+        // two MFMA steps (channels 2 e2, 2 e2 + 1) x three positions
+        auto rd_issue = [&](const float* buf, int M) __attribute__((always_inline)) {
+            if constexpr (ABL & 8) return;
+            const int h = M / 6, g = (M / 2) % 3, e2 = M % 2;
+            const int off = (2 * h + e2) * X_PL + g * X_ROWP;
+            rd[0] = *reinterpret_cast<const x_f32x4*>(buf + t_srcA + off);
+            rd[1] = *reinterpret_cast<const x_f32x4*>(buf + t_srcB + off);
+            rd[2] = *reinterpret_cast<const x_f32x4*>(buf + t_srcA + off + 4);
+            // (all 16 bytes are "used": left alone hipcc shortens the half-used entry of a column block to a ds_read_b64, whose
+            // 32-lane groups put the tiles of both tile rows on the same banks)
+            asm volatile("" : "+v"(rd[0]), "+v"(rd[2]));
+        };
+        // column transform of the window row in rd -> the three A operands of this wave's column block, both channels of the pair
+        auto xf = [&](int slot) __attribute__((always_inline)) {
+            if constexpr (ABL & 4) return;
+            const x_f32x2 x0 = X_LO(rd[0]), x1 = X_HI(rd[0]), x2 = X_LO(rd[1]), x3 = X_HI(rd[1]), x4 = X_LO(rd[2]), x5 = X_HI(rd[2]);
+            if constexpr (B == 0) {
+                const x_f32x2 s1 = x_pk_nk(k4, x2, x4);
+                const x_f32x2 s2 = x_pk_nk(k4, x1, x3);
+                av[slot][0] = x_pk_k(k4, x0, x_pk_nk(k5, x2, x4));
+                av[slot][1] = x_pk_add(s1, s2);
+                av[slot][2] = x_pk_sub(s1, s2);
+            } else {
+                const x_f32x2 s3 = x_pk_sub(x4, x2), s4 = x_pk_sub(x3, x1);
+                av[slot][0] = x_pk_k(k2, s4, s3);
+                av[slot][1] = x_pk_nk(k2, s4, s3);
+                av[slot][2] = x_pk_k(k4, x1, x_pk_nk(k5, x3, x5));
+            }
+        };
+        rd_issue(smem, 0);
+        xf(0);
+        rd_issue(smem, 1);
+        // one chunk = 12 pair steps.  MORE (compile time): a chunk follows -- its row transform, its first two steps' operands and its
+        // filters are produced inside this one.  The last chunk is a second copy without them: branches inside the stream cost
+        // more than the code (tried: +19 % K-loop time), and nothing stays in flight in front of the epilogue's barrier.
+        auto chunk = [&](int c, auto more_c) __attribute__((always_inline)) {
+            constexpr bool MORE = decltype(more_c)::value;
+            float* bc_ = smem + (c & 1) * X_V1F;                // V1 of chunk c
+            float* bn = smem + ((c + 1) & 1) * X_V1F;           // chunk c + 1 (written during this chunk)
+            const int c2 = c + 2 < p.nchunk ? c + 2 : c + 1;    // (the last but one chunk re-requests its successor's rows: unused)
+#pragma unroll
+            for (int M = 0; M < 12; ++M) {
+                const int G = M / 2, g = G % 3, e2 = M % 2;
+                __builtin_amdgcn_sched_barrier(0);
+                // operands of the next pair step from the row in rd (requested a step ago), then the request of the row after it
+                if (M + 1 < 12 || MORE) xf((M + 1) & 1);
+                if (M + 2 < 12) rd_issue(bc_, M + 2);
+                else if (MORE) rd_issue(bn, M + 2 - 12);
+                if (e2 == 0) {                                   // first step of a group: the filters of group G + 2
+                    if (G + 2 < 6) u_issue((G + 2) % 3, c, G + 2);
+                    else if (MORE) u_issue((G + 2) % 3, c + 1, G + 2 - 6);
+                }
+#if X_SCHED == 1
+                __builtin_amdgcn_sched_barrier(0);               // the requests go out in front of the step's six MFMAs
+#endif
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        acc[g][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[M & 1][s][e], u[G % 3][s][2 * e2 + e], acc[g][s], 0, 0, 0);
+                if constexpr (!MORE) {
+                    if (M == 6) { epi_setup(); row_offsets(0); }
+                    if (M == 7) res_col(0);
+                    if (M == 8) res_col(1);
+                    if (M == 9) res_col(2);
+                    if (M == 10) res_col(3);
+                }
+                if constexpr (MORE) {
+                    // stage 1 of chunk c + 1 between the MFMAs of steps 4..7 (its rows were requested a chunk ago)
+                    if (M == 4) s1_piece(bn, 0, 0);
+                    if (M == 5) s1_piece(bn, 0, 1);
+                    if (M == 6) s1_piece(bn, 1, 0);
+                    if (M == 7) s1_piece(bn, 1, 1);
+                    // behind step 8's filter loads: buffer loads return in order, the next filter wait (4 steps on) covers these too
+                    if (M == 8) raw_issue(c2);
+                    // every V1 read of chunk c has been issued (step 11's, two steps ahead); behind the barrier chunk c + 1 is read
+                    if (M == 9) { __builtin_amdgcn_sched_barrier(0); lds_barrier(); }
+                }
+            }
+        };
+        if constexpr (!ONE) {
+            int c = 0;
+            do { chunk(c, std::true_type{}); } while (++c + 1 < p.nchunk);
+        }
+        chunk(p.nchunk - 1, std::false_type{});
+    };
+    // the whole block loop exists once per column-block copy (what crosses the branch between the copies would be live across
+    // copy 0, see the prologue's note): nothing but addresses does
+    auto epilogue = [&](bool has_next, unsigned it_next) __attribute__((always_inline)) {
+
+        // ---------------------------------------------------------------- epilogue: Y = A^T M A, bias, residual, ReLU
+        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        // Two phases, one per tile row ty: ALL eight waves stage their accumulators of that row's 16 tiles ([position][tile][64 couts],
+        // 144 KB), then every thread owns the tile (ty, tx) for the output channels 2 e_n and 2 e_n + 1 -- the two halves of packed
+        // registers (nothing multiplies here: v_pk_add_f32 / v_pk_fma_f32 do both channels' work per issue slot) and of 8-byte LDS
+        // reads, residual loads and stores (a wave moves 256-byte runs of a pixel's channels).
+        const float* s0 = smem + tx * 64 + 2 * e_n;
+        float bias0 = 0.f, bias1 = 0.f;
+        if (p.bias) {
+            bias0 = p.bias[(long long)grp * p.Co + cbk * 64 + 2 * e_n];
+            bias1 = p.bias[(long long)grp * p.Co + cbk * 64 + 2 * e_n + 1];
+        }
+        const x_f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f}, bias2 = {bias0, bias1};
+    #pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+            lds_barrier();                                      // V1 (phase 0) / the previous phase's stage is free; (not
+                                                                // __syncthreads(): its vmcnt(0) would wait for the residual here)
+            {
+                float* d = smem + ((3 * pa) * 6 + 3 * pbb) * 1024 + blk * 32 + (lane_e & 31);
+    #pragma unroll
+                for (int g = 0; g < 3; ++g)
+    #pragma unroll
+                    for (int s = 0; s < 3; ++s)
+    #pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int t16 = (r8 & 3) + 8 * (r8 >> 2) + 4 * kh_e;   // accumulator 8 ty + r8 = tile 16 ty + t16
+                            d[(g * 6 + s) * 1024 + t16 * 64] = acc[g][s][8 * ty + r8];
+                        }
+            }
+            lds_barrier();
+            // this phase's store offsets; roff then moves on to the next phase: its residual columns are requested as soon as this
+            // phase has consumed theirs
+            unsigned roff_s[4];
+    #pragma unroll
+            for (int a = 0; a < 4; ++a) roff_s[a] = roff[a];
+            if (ty == 0) row_offsets(1);
+            // rows of M -> T[i][y] = sum_j M[i][j] A[j][y]
+            x_f32x2 t[6][4];
+    #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                x_f32x2 m[6];
+    #pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const x_f32x2*>(s0 + (i * 6 + j) * 1024);
+                const x_f32x2 p12 = m[1] + m[2], q12 = m[1] - m[2], p34 = m[3] + m[4], q34 = m[3] - m[4];
+                t[i][0] = (m[0] + p12) + p34;
+                t[i][1] = __builtin_elementwise_fma(c2, q34, q12);
+                t[i][2] = __builtin_elementwise_fma(c4, p34, p12);
+                t[i][3] = __builtin_elementwise_fma(c8, q34, q12) + m[5];
+            }
+    #pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const x_f32x2 p12 = t[1][y] + t[2][y], q12 = t[1][y] - t[2][y], p34 = t[3][y] + t[4][y], q34 = t[3][y] - t[4][y];
+                x_f32x2 o[4];
+                o[0] = (t[0][y] + p12) + p34;
+                o[1] = __builtin_elementwise_fma(c2, q34, q12);
+                o[2] = __builtin_elementwise_fma(c4, p34, p12);
+                o[3] = __builtin_elementwise_fma(c8, q34, q12) + t[5][y];
+    #pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    x_f32x2 v = o[a] + bias2;
+                    if (RES) v = v + rv[y][a];
+                    const unsigned off = (roff_s[a] + (unsigned)y * pixb) | cinv[y];
+                    v[0] = fmaxf(v[0], relu_lo);
+                    v[1] = fmaxf(v[1], relu_lo);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(x_u32x2, v), rout, off, 0, 0);
+                }
+                if (ty == 0) res_col(y);
+            }
+            // the NEXT block's chunk-0 rows, requested behind phase 0 (and behind phase 1's residual columns: buffer loads return in
+            // order, the wait for a residual must not cover an HBM round trip of rows): rr is free (stage 1 ended a chunk ago) and so
+            // is the half of the accumulators phase 0 staged; the rows arrive while phase 1 is dumped, combined and stored
+            // (issued unconditionally -- behind the last block the row mask marks every row out of range and the descriptor returns
+            // zeros without touching memory: with the loads inside a branch hipcc's vmcnt bookkeeping turns conservative and phase 1's
+            // wait for its residual columns waits for these rows too)
+            if (ty == 0) {
+                unsigned cbk_n, img_n;
+                int oy_n, ox_n;
+                decode(has_next ? it_next : 0u, cbk_n, img_n, oy_n, ox_n);
+                s1_block(img_n, oy_n, ox_n);
+                rmask = has_next ? rmask : 0x3F;
+                raw_issue(0);
+            }
+        }
+
+        lds_barrier();              // the stage is read: the next block's row transform may overwrite it
+    };
+    auto run = [&](auto bc) __attribute__((always_inline)) {
+        bool pre = false;
+        for (unsigned it = blockIdx.x; it < nblocks; it += gridDim.x) {
+            decode(it, cbk, img, oy0, ox0);
+            if (!pre) s1_block(img, oy0, ox0);
+            u_block(cbk);
+            kloop(bc, pre);
+            const unsigned it_next = it + gridDim.x;
+            pre = it_next < nblocks;
+            epilogue(pre, it_next);
+        }
+    };
+    if (pbb == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+
 // Packed transformed filters in the MFMA B-operand register layout (one 16-byte load per lane = 4 MFMA steps):
 //   U[cout/32][chunk][pos 36][half][lane][e] = (G g G^T)[pos] of (cout = 32 cb + (lane & 31), cin = 16 chunk + 8 (lane >> 5) + 4 half + e)
 // fp64 accumulation, rounded once.   wgt: [cout][1][3][3][cin] (BN folded).
@@ -640,6 +1074,11 @@ extern "C" int ss_conv_uses_wino43(int kt, int kh, int kw, int stride, int cin, 
     return eff * 100.0 >= (double)min_fill_pct && (long long)images * nby * nbx * (cout / 64) * groups >= min_wgs && cin >= min_cin;
 }
 
+// Process-wide A/B knob (output-neutral, like ss_cost_volume_set_tile): 1 = persistent workgroups (conv_wino43p_kernel), 0 = one
+// workgroup per tile block (conv_wino43_kernel).
+static std::atomic<int> g_w43_persistent{1};
+extern "C" int ss_wino43_set_persistent(int on) { g_w43_persistent.store(on ? 1 : 0); return SS_OK; }
+
 #ifdef SS_TUNING
 int g_w43_ablate = 0;                    // ss_debug_set key 21
 extern int g_wino_knob[4];               // [1] (key 17): first-round stagger of this kernel, clocks per CU slot
@@ -696,7 +1135,15 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+                hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)conv_wino43p_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
             if (!ok) (void)hipGetLastError();
             attr_state[dev].store(ok ? 2 : 3, std::memory_order_release);
         }
@@ -705,6 +1152,31 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     }
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
+    if (g_w43_persistent.load(std::memory_order_relaxed)) {
+        // persistent workgroups: one per CU (a multiple of 8, so that a workgroup's blocks stay on its XCD), never more than blocks
+        static std::atomic<int> cus[64];
+        int ncu = cus[dev].load(std::memory_order_relaxed);
+        if (ncu == 0) {
+            hipDeviceProp_t prop;
+            ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            ncu -= ncu % 8;
+            if (ncu < 8) ncu = 8;
+            cus[dev].store(ncu, std::memory_order_relaxed);
+        }
+        const unsigned per_group = (unsigned)(wgs < ncu ? wgs : ncu);
+        dim3 gp(per_group, 1, groups);
+#define X_LAUNCHP(RES_, ONE_, GEO_) hipLaunchKernelGGL((conv_wino43p_kernel<RES_, ONE_, GEO_>), gp, dim3(512), lds, st, p)
+        const bool onep = p.nchunk == 1;
+        if (geo) {
+            if (onep) { if (res) X_LAUNCHP(true, true, 1); else X_LAUNCHP(false, true, 1); }
+            else { if (res) X_LAUNCHP(true, false, 1); else X_LAUNCHP(false, false, 1); }
+        } else {
+            if (onep) { if (res) X_LAUNCHP(true, true, 0); else X_LAUNCHP(false, true, 0); }
+            else { if (res) X_LAUNCHP(true, false, 0); else X_LAUNCHP(false, false, 0); }
+        }
+#undef X_LAUNCHP
+        return ss_launch_status();
+    }
 #ifdef SS_TUNING
     if (g_w43_ablate && !res && !geo) {         // tools/diag_wino43.py <layers> <ablation masks>
         switch (g_w43_ablate) {

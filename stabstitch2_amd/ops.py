@@ -225,6 +225,12 @@ def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
 _WINO43_REFUSED = set()      # device indices whose first F(4x4,3x3) launch answered SS_ERR_DEVICE (no 144 KB of LDS per workgroup)
 
 
+# F(4x4,3x3) with persistent workgroups (csrc/wino43.hip, conv_wino43p_kernel; bit-identical to the one-block-per-workgroup kernel).
+# SS_WINO43_PERSIST=0 = the latter, for A/B runs; the knob is the library's process-wide, output-neutral ss_wino43_set_persistent.
+WINO43_PERSIST = os.environ.get('SS_WINO43_PERSIST', '1') == '1'
+_w43_persist_set = [None]
+
+
 def _try_wino43(x, wgt, bias, res, relu, out):
     """ops.conv's use of the F(4x4,3x3) kernel.  The kernel needs 144 KB of LDS per workgroup; a device that cannot give it (not
     gfx950) makes the library answer SS_ERR_DEVICE at the first launch, nothing has been launched then: THAT device is remembered
@@ -232,6 +238,9 @@ def _try_wino43(x, wgt, bias, res, relu, out):
     sizes the kernel cannot address (SS_ERR_UNSUPPORTED) falls through for this launch only.  -> the result, or None."""
     if x.device.index in _WINO43_REFUSED:
         return None
+    if _w43_persist_set[0] != WINO43_PERSIST:
+        H.lib().ss_wino43_set_persistent(int(WINO43_PERSIST))
+        _w43_persist_set[0] = WINO43_PERSIST
     try:
         return conv_winograd43(x, wgt, bias, res, relu, out)
     except H.HipError as e:

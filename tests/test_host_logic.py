@@ -69,15 +69,17 @@ def test_no_matrix_kernel_spills_or_uses_scratch(built_lib):
     assert len(ks) >= 60 and len(mfma) >= 30, (len(ks), len(mfma))
     for want in ('conv_igemm_kernel', 'conv_wino_kernel', 'conv_wino43_kernel', 'stem_pool_kernel_half'):
         assert any(want in k for k in mfma), want
-    bad = {k: (v.get('.vgpr_spill_count', 0), v.get('.sgpr_spill_count', 0), v.get('.private_segment_fixed_size', 0))
-           for k, v in mfma.items()
-           if v.get('.vgpr_spill_count', 0) or v.get('.sgpr_spill_count', 0) or v.get('.private_segment_fixed_size', 0)}
-    assert not bad, 'MFMA kernels with spills / scratch (vgpr spills, sgpr spills, scratch bytes): %s' % bad
+    # (SGPR spills go to VGPR lanes -- v_writelane / v_readlane, no memory: the persistent F(4x4,3x3) kernel parks up to six
+    # block-loop scalars that way outside its K loop; what must never ship is a VGPR spilled to scratch memory)
+    bad = {k: (v.get('.vgpr_spill_count', 0), v.get('.private_segment_fixed_size', 0))
+           for k, v in mfma.items() if v.get('.vgpr_spill_count', 0) or v.get('.private_segment_fixed_size', 0)}
+    assert not bad, 'MFMA kernels with VGPR spills / scratch (vgpr spills, scratch bytes): %s' % bad
+    assert max(v.get('.sgpr_spill_count', 0) for v in mfma.values()) <= 8
     # the register budgets the occupancy arguments of DESIGN.md rest on
     half = next(v for k, v in ks.items() if 'stem_pool_kernel_half' in k)
     assert half['.vgpr_count'] + half.get('.agpr_count', 0) <= 128          # four workgroups of 256 threads per CU
     for k, v in ks.items():
-        if 'conv_wino43_kernel' in k:
+        if 'conv_wino43' in k:               # (both the persistent and the one-block-per-workgroup kernel)
             assert v['.vgpr_count'] <= 256 and v.get('.vgpr_spill_count', 0) == 0, k
 
 
