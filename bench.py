@@ -468,6 +468,30 @@ def other_configs(nets, dev, args):
     finally:
         pipeline.QUAD_OVERLAP = old_ov
     del o
+    # round 6 opt-ins (never the headline): the geometry-only kernel policy (a frame's bits independent of its batch), the one-block-
+    # per-workgroup F(4x4,3x3) kernel (A/B of the persistent one), the render with the reference's + 1e-6 folded into its row table
+    from stabstitch2_amd import ops as _ops
+    dt, o, sg = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets, deterministic=True), sync, W, K, True)
+    entry('720p 2-view, deterministic kernel policy (opt-in: deterministic=True)', n, dt, K, o[1], o[2], sg,
+          note='every kernel chosen by layer geometry alone: resident clip == chunked passes == stream, bit for bit')
+    del o
+    _ops.WINO43_PERSIST = False
+    try:
+        dt, o, sg = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets), sync, W, K, True)
+        entry('720p 2-view, F(4x4,3x3) with one workgroup per tile block (A/B: SS_WINO43_PERSIST=0)', n, dt, K, o[1], o[2], sg,
+              note='the round-5 kernel; the headline runs the persistent one (bit-identical)')
+    finally:
+        _ops.WINO43_PERSIST = True
+    del o
+    _ops.RENDER_EPS_FOLD = True
+    try:
+        dt, o, sg = measure(lambda: pipeline.run_two_view(hr[0], hr[1], lr[0], lr[1], nets), sync, W, K, True)
+        entry('720p 2-view, render with the + 1e-6 folded into the row table (opt-in SS_RENDER_EPS_FOLD=1)', n, dt, K, o[1], o[2], sg,
+              note='NOT the reference arithmetic (a log a instead of d2 log(d2 + 1e-6), ~1e-3 px): passes the G7 / G9 / G13 gates '
+                   '(tests/test_gpu_round6.py), never the default')
+    finally:
+        _ops.RENDER_EPS_FOLD = False
+    del o
     # opt-in arithmetic of the Winograd GEMMs: fp32 products formed exactly from three bf16 slices per operand (nine slice
     # products) on the bf16 matrix pipe, fp32 accumulation (ops.WINO_MATH, csrc/wino.hip SLICED).  NOT the headline.
     from stabstitch2_amd import ops
@@ -570,7 +594,21 @@ def other_configs(nets, dev, args):
     res['720p 2-view streaming (batch 1, one pair per push)']['canvas_overflow'] = st1.overflow_report()      # device-side watcher (read after the clock)
     res['720p 2-view streaming (batch 1, one pair per push)']['fps_steady'] = round(200 / dts, 1)
     res['720p 2-view streaming (batch 1, one pair per push)']['ms_per_push_steady'] = round(dts / 200 * 1e3, 4)
+    res['720p 2-view streaming (batch 1, one pair per push)']['graph_nodes'] = st1.graph_nodes      # (hipGraphGetNodes of the captured step)
     del st1
+    std = OnlineStitcher(nets, 720, 1280, deterministic=True)
+    for t in range(12):
+        std.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
+    sync()
+    t0 = time.perf_counter()
+    for t in range(100):
+        i = t % n
+        std.push(hr[0][i:i + 1], hr[1][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1])
+    sync()
+    entry('720p 2-view streaming, deterministic kernel policy (opt-in)', 100, time.perf_counter() - t0, 1, std.hc, std.wc,
+          note='OnlineStitcher(deterministic=True), steady state: frames bit-identical to the resident clip; no split-K at batch 1')
+    res['720p 2-view streaming, deterministic kernel policy (opt-in)']['graph_nodes'] = std.graph_nodes
+    del std
     # the three-view script as a stream: two pair chains + per-frame composition + three-image render, one HIP graph per push
     from stabstitch2_amd.online import ThreeViewOnlineStitcher
     st3 = ThreeViewOnlineStitcher(nets, 720, 1280)
@@ -583,7 +621,8 @@ def other_configs(nets, dev, args):
         st3.push(hr[0][i:i + 1], hr[1][i:i + 1], hr[2][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1], lr[2][i:i + 1])
     sync()
     entry('720p 3-view streaming (batch 1, one triple per push)', 100, time.perf_counter() - t0, 1, st3.hc, st3.wc,
-          note='ThreeViewOnlineStitcher, steady state (graph replays), 100 pushes')
+          note='ThreeViewOnlineStitcher, steady state (graph replays), 100 pushes; the middle view passes the trunks once')
+    res['720p 3-view streaming (batch 1, one triple per push)']['graph_nodes'] = st3.graph_nodes
     del st3
     # batch of S independent live streams advancing together (one graph launch per push of S pairs)
     from stabstitch2_amd.online import MultiOnlineStitcher
@@ -960,7 +999,10 @@ def main():
                 'three_view_fps': pick('configs[4]'), 'three_view_linear_fps': oc.get('720p 3-view fusion LINEAR', {}).get('fps'),
                 'configs1_360x480_fps': pick('configs[1]'), 'warp_fast_fps': oc.get('720p 2-view warp FAST', {}).get('fps'),
                 'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
-                'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push')}
+                'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push'),
+                'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
+                'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),
+                'wino43_one_block_per_workgroup_fps': pick('one workgroup per tile block'), 'render_eps_fold_fps': pick('folded into the row table')}
         for k, v in summ.items():
             result['config']['summary_' + k] = v
     if base and not args.no_cpu_baseline:

@@ -30,6 +30,29 @@ WINDOW = pipeline.WINDOW
 _warmup = {}
 
 
+def _new_graph():
+    """A CUDAGraph that keeps its hipGraph_t (torch >= 2.5: keep_graph=True) so that `_graph_nodes` can count its nodes."""
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError:
+        return torch.cuda.CUDAGraph()
+
+
+def _graph_nodes(g):
+    """Nodes of a captured graph (hipGraphGetNodes on the raw handle), None where the runtime / torch does not expose it.  The
+    streaming push is bound by its node count (a node costs >= 4.5 us whatever it does): bench.py prints it."""
+    try:
+        import ctypes
+        raw = g.raw_cuda_graph()
+        n = ctypes.c_size_t(0)
+        hip = ctypes.CDLL('libamdhip64.so')
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+            return None
+        return int(n.value)
+    except Exception:
+        return None
+
+
 def _warmup_stream(dev):
     """One capture warm-up stream per device, shared by every stitcher."""
     s = _warmup.get(dev)
@@ -102,6 +125,7 @@ class OnlineStitcher:
         self.use_graph = use_graph
         self.static = None               # steady-state buffers (inputs, rings, output) once the window is full
         self.graph = None
+        self.graph_nodes = None          # nodes of the captured steady-state graph (None: not captured / not exposed)
         self.trunk_pair = None
         self.trunk_versions = None
 
@@ -297,10 +321,11 @@ class OnlineStitcher:
                 st[k].copy_(v)
             if keep_w is not None:
                 self.watch_i.copy_(keep_w[0]); self.watch_f.copy_(keep_w[1])
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             with torch.cuda.graph(g):
                 self._step_static()
             self.graph = g
+            self.graph_nodes = _graph_nodes(g)
             for k, v in keep.items():          # capture does not execute: state is still the pre-push state
                 st[k].copy_(v)
             self.graph.replay()
@@ -428,6 +453,7 @@ class MultiOnlineStitcher:
         self.use_graph = use_graph
         self.static = None
         self.graph = None
+        self.graph_nodes = None
         self.trunk_pair = None
         self.trunk_versions = None
         self.frames_in = 0
@@ -605,10 +631,11 @@ class MultiOnlineStitcher:
             torch.cuda.current_stream(self.dev).wait_stream(side)
             for k, v in keep.items():
                 st[k].copy_(v)
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             with torch.cuda.graph(g):
                 self._step_static()
             self.graph = g
+            self.graph_nodes = _graph_nodes(g)
             for k, v in keep.items():
                 st[k].copy_(v)
             self.graph.replay()
@@ -689,6 +716,7 @@ class ThreeViewOnlineStitcher:
         self.frames_in = 0
         self.static = None
         self.graph = None
+        self.graph_nodes = None
         self.versions = None
         # overflow state of the output canvas (the methods are OnlineStitcher's)
         self.canvas_epoch = 0
@@ -772,10 +800,11 @@ class ThreeViewOnlineStitcher:
             torch.cuda.current_stream(self.dev).wait_stream(side)
             for t, v in zip(state, keep):
                 t.copy_(v)
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             with torch.cuda.graph(g):
                 self._step_static()
             self.graph = g
+            self.graph_nodes = _graph_nodes(g)
             for t, v in zip(state, keep):          # capture does not execute: state is still the pre-push state
                 t.copy_(v)
             self.graph.replay()
