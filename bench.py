@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_PROFILE = os.path.join('profiles', 'r05_pmc_hbm.json')
+PMC_PROFILE = os.path.join('profiles', 'r06_pmc_hbm.json')
 
 
 def build_nets(dev, profile='default'):
@@ -64,22 +64,22 @@ build_nets.weights = 'synthetic checkpoints'
 
 def _measured_limiters():
     """Kernels of the `secondary` list that are NOT HBM-bound although SURVEY.md 8d prices them against HBM: what the committed
-    PMC passes (profiles/r05_pmc_render.json, profiles/r05_pmc_lds.json) measured instead.  Static, like the HBM bytes."""
+    PMC passes (profiles/r06_pmc_render.json, profiles/r06_pmc_lds.json) measured instead.  Static, like the HBM bytes."""
     out = {}
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r05_pmc_render.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r06_pmc_render.json')) as f:
             r = json.load(f)
         out['render_average_kernel'] = {'unit': 'valu', 'valu_issue_active_frac': r['valu_active_frac'],
-                                        'source': 'profiles/r05_pmc_render.json (SQ_ACTIVE_INST_VALU)'}
+                                        'source': 'profiles/r06_pmc_render.json (SQ_ACTIVE_INST_VALU)'}
     except (OSError, KeyError, ValueError):
         pass
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r05_pmc_lds.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r06_pmc_lds.json')) as f:
             l = json.load(f)['cost_volume']
         out['cost_volume_kernel'] = {'unit': 'valu issue (packed fp32 FMA + operand moves)', 'lds_active_frac': l['lds_busy_frac'],
                                      'lds_bank_conflict_frac': l['lds_bank_conflict_frac'],
-                                     'source': 'profiles/r05_pmc_lds.json (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT)'}
-        with open(os.path.join(ROOT, 'profiles', 'r05_pmc_mfma.json')) as f:
+                                     'source': 'profiles/r06_pmc_lds.json (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT)'}
+        with open(os.path.join(ROOT, 'profiles', 'r06_pmc_mfma.json')) as f:
             m = json.load(f)['cost_volume']['counters']
         out['cost_volume_kernel']['valu_issue_frac'] = round(m['SQ_INSTS_VALU'] * 4 / 1024.0 / (m['GRBM_GUI_ACTIVE'] / 8.0), 3)
     except (OSError, KeyError, ValueError):
@@ -921,7 +921,7 @@ def main():
                      'algorithmic_bytes_per_launch': round(conv_bytes / max(conv_n, 1)),
                      'avg_launch_us': round(conv_ms * 1e3 / max(conv_n, 1), 2),
                      'kernel_ms_per_step': round(conv_ms, 3),
-                     # the two kernels of the engine separately (HIP events of the same step; profiles/r05_kernel_stats.txt holds
+                     # the two kernels of the engine separately (HIP events of the same step; profiles/r06_kernel_stats.txt holds
                      # the rocprofv3 kernel trace of this same command, profiled and un-profiled clocks stated there)
                      'per_kernel': {k: {'launches_per_step': v[0], 'avg_launch_us': round(v[1] * 1e3 / max(v[0], 1), 2),
                                         'ms_per_step': round(v[1], 3),

@@ -76,14 +76,29 @@ def _spatial_temporal_heads(spatial, temporal, f64, prev_feat, feat, b, tm_out, 
         off = spatial.forward_features(f64, b, pipeline.LR_H, pipeline.LR_W)
         temporal.motions_from_features(prev_feat, feat, out_slices=[(0, b, tm_out[0]), (b, 2 * b, tm_out[1])])
         return off
+    off1 = _heads_a(spatial, f64, b, chain)
+    return (off1,) + _heads_b(spatial, temporal, f64, off1, prev_feat, feat, b, tm_out, chain)
+
+
+def _heads_a(spatial, f64, b, chain=False):
+    """First half of the heads (up to the global homography offsets): SpatialNet's stage-2 trunk + contextual correlation +
+    regressNet1 -> offset_1 [b,8].  (PipelinedOnlineStitcher cuts the push between the halves.)"""
+    o2 = 1 if chain else b
     f32 = L.run_stage2(f64, spatial._prepared()['s2'])
-    off1, cv_s = spatial.forward_pair_cv(f64[:b], f64[o2:o2 + b], f32[:b], f32[o2:o2 + b], pipeline.LR_H, pipeline.LR_W)
+    return spatial.offset1_from_features(f32[:b], f32[o2:o2 + b])
+
+
+def _heads_b(spatial, temporal, f64, off1, prev_feat, feat, b, tm_out, chain=False):
+    """Second half: decomposition, warps, both nets' cost volumes, the four regressor heads in shared launches
+    -> (offset_2_ref, offset_2_tgt); temporal motions into tm_out."""
+    o2 = 1 if chain else b
+    cv_s = spatial.cv_from_offset1(f64[:b], f64[o2:o2 + b], off1, pipeline.LR_H, pipeline.LR_W)
     cv_t = ops.cost_volume(prev_feat, feat, 3)
     off_ref = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
     off_tgt = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
     L.run_regressor_quad(cv_s, cv_t.view((2, b) + tuple(cv_t.shape[1:])), L.get_quad(spatial, temporal),
                          [off_ref, off_tgt, tm_out[0], tm_out[1]])
-    return off1, off_ref, off_tgt
+    return off_ref, off_tgt
 
 
 class OnlineStitcher:

@@ -98,16 +98,23 @@ class SpatialNet(L.PreparedMixin, nn.Module):
         """forward_pair up to the stage-2 cost volumes: -> (offset_1 [B,8], cv [2,B,h/8,w/8,124]: both directions).  The caller
         runs regressNet2 ref / tgt on cv -- alone (`forward_pair`) or together with TemporalNet's regressor in shared
         launches (layers.run_regressor_quad)."""
-        p = self._prepared()
-        # stage 1: contextual correlation -> global homography offsets
+        offset_1 = self.offset1_from_features(f32_1, f32_2)
+        return offset_1, self.cv_from_offset1(f64_1, f64_2, offset_1, img_h, img_w)
+
+    @torch.no_grad()
+    def offset1_from_features(self, f32_1, f32_2):
+        """Stage 1 (spatial_network.py:291-300): contextual correlation of the 1/16 features -> global homography offsets [B,8]."""
         _, flow = ops.ccl(f32_1, f32_2, 10.0, want_nchw=False, want_nhwc4=True)
-        offset_1 = L.run_regressor(flow, p['r1'])
-        # bidirectional decomposition at 1/8 scale, warp both feature maps onto the middle plane
+        return L.run_regressor(flow, self._prepared()['r1'])
+
+    @torch.no_grad()
+    def cv_from_offset1(self, f64_1, f64_2, offset_1, img_h, img_w):
+        """Stage 2 up to its cost volumes (spatial_network.py:302-331): bidirectional decomposition at 1/8 scale, both feature maps
+        warped onto the middle plane, local cost volumes in both directions -> [2,B,h/8,w/8,124] (one launch)."""
         th_ref, th_tgt = ops.spatial_decompose(offset_1, img_h, img_w)
         fh, fw = int(img_h / 8), int(img_w / 8)
         w1, w2 = ops.homo_warp_pair(f64_1, f64_2, th_ref, th_tgt, fh, fw)
-        # stage 2: local cost volumes in both directions -> residual mesh motions
-        return offset_1, ops.cost_volume_bidir(w1, w2, 5)          # [2,b,fh,fw,124]: both directions, one launch
+        return ops.cost_volume_bidir(w1, w2, 5)
 
     @staticmethod
     def cost_volume(x1, x2, search_range, norm=True, fast=True):
