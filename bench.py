@@ -596,6 +596,23 @@ def other_configs(nets, dev, args):
     res['720p 2-view streaming (batch 1, one pair per push)']['ms_per_push_steady'] = round(dts / 200 * 1e3, 4)
     res['720p 2-view streaming (batch 1, one pair per push)']['graph_nodes'] = st1.graph_nodes      # (hipGraphGetNodes of the captured step)
     del st1
+    # two pushes in flight (opt-in; frames bit-identical, handed out one push late): PipelinedOnlineStitcher
+    from stabstitch2_amd.online import PipelinedOnlineStitcher
+    stp = PipelinedOnlineStitcher(nets, 720, 1280)
+    for t in range(12):
+        stp.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
+    sync()
+    t0 = time.perf_counter()
+    for t in range(200):
+        i = t % n
+        stp.push(hr[0][i:i + 1], hr[1][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1])
+    stp.flush()
+    sync()
+    entry('720p 2-view streaming, two pushes in flight (opt-in PipelinedOnlineStitcher)', 200, time.perf_counter() - t0, 1, stp.hc, stp.wc,
+          note='push t + 1`s trunks and stage-1 heads on a second HIP stream beside push t`s regressor heads, smoothing and render; '
+               'frames bit-identical to OnlineStitcher, handed out one push late (flush() for the last)')
+    res['720p 2-view streaming, two pushes in flight (opt-in PipelinedOnlineStitcher)']['graph_nodes'] = stp.graph_nodes
+    del stp
     std = OnlineStitcher(nets, 720, 1280, deterministic=True)
     for t in range(12):
         std.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
@@ -1001,6 +1018,7 @@ def main():
                 'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
                 'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push'),
                 'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
+                'streaming_pipelined_fps': pick('two pushes in flight'),
                 'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),
                 'wino43_one_block_per_workgroup_fps': pick('one workgroup per tile block'), 'render_eps_fold_fps': pick('folded into the row table')}
         for k, v in summ.items():

@@ -278,17 +278,33 @@ class OnlineStitcher:
         """One steady-state push on the static buffers (capturable: no host sync, no data-dependent shapes; every result
         lands in place -- no torch op in the step besides the copy of the cached features)."""
         st = self.static
-        e = 126
-        # SpatialNet and TemporalNet read the same two LR frames through trunks of identical architecture: one grouped
-        # launch per layer for both (12 launches fewer per pushed pair)
+        f2, off1 = self._stage_a(st['lr1'], st['lr2'])
+        self._stage_b(f2, off1, st['hr1'], st['hr2'], st['out'])
+
+    def _stage_a(self, lr1, lr2):
+        """First half of a steady-state push -- it touches NO stream state: both nets' stage-1 trunks on the two LR frames (one
+        grouped launch per layer: SpatialNet and TemporalNet read the same frames through trunks of identical architecture), then
+        SpatialNet's stage-2 trunk, contextual correlation and regressNet1 -> (f2 [2(net),2(view),45,60,128], offset_1 [1,8])."""
         if self.trunk_pair is None:
             self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
             self.trunk_versions = self._versions()
-        f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)            # [2(net),2(view),45,60,128]
+        f2 = L.run_stage1_pair([lr1, lr2], self.trunk_pair)
+        if not L.QUAD:
+            return f2, None
+        return f2, _heads_a(self.spatial, f2[0], 1)
+
+    def _stage_b(self, f2, off1, hr1, hr2, out):
+        """Second half: everything that reads or advances the stream's state (cached features, previous motions, the sliding
+        window) and the render of the new frame into `out`."""
+        st = self.static
+        e = 126
         ps, pt = st['pair_s'], st['pair_t']
         feat = f2[1]
-        off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f2[0], st['prev_feat'], feat, 1,
-                                                         (pt[0, 1:2], pt[1, 1:2]))
+        tm_out = (pt[0, 1:2], pt[1, 1:2])
+        if off1 is None:
+            off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f2[0], st['prev_feat'], feat, 1, tm_out)
+        else:
+            off_ref, off_tgt = _heads_b(self.spatial, self.temporal, f2[0], off1, st['prev_feat'], feat, 1, tm_out)
         ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W,
                            out=(ps[0, 1].view(1, 7, 9, 2), ps[1, 1].view(1, 7, 9, 2)))
         st['prev_feat'].copy_(feat)
@@ -303,7 +319,7 @@ class OnlineStitcher:
         if self.meshes_only:
             self.last_meshes = (m1[-1:], m2[-1:])
             return
-        self._render(st['hr1'], st['hr2'], m1[-1:], m2[-1:], out=st['out'])
+        self._render(hr1, hr2, m1[-1:], m2[-1:], out=out)
 
     def _versions(self):
         return (self.spatial.weights_version, self.temporal.weights_version, self.smooth.weights_version)
@@ -414,6 +430,141 @@ class OnlineStitcher:
             self._init_static()              # from the next push on: static buffers (+ HIP graph)
             return frames
         return [self._render(hr1, hr2, m1[-1:], m2[-1:])]
+
+
+class PipelinedOnlineStitcher(OnlineStitcher):
+    """OnlineStitcher with TWO pushes in flight (round 6; opt-in).  A batch-1 push is a dependent chain of ~80 small launches that
+    leaves most of the chip idle (profiles/r06_stream_timeline.txt: 0.86 ms, a graph node costs >= 4.5 us whatever it does), and
+    nothing inside ONE push can be overlapped further (LAB_NOTES R6.1-2).  Consecutive pushes can: the first half of a push -- both
+    trunks, SpatialNet's stage-2 trunk, contextual correlation, regressNet1 (`_stage_a`) -- touches no stream state, so push t + 1's
+    first half runs on a second HIP stream beside push t's second half (`_stage_b`: decomposition, cost volumes, regressor heads,
+    tsmotion, sliding window, SmoothNet, render).  Each half is its own HIP graph per buffer parity; hand-over buffers (LR / HR
+    frames, trunk features, offset_1, the output frame) are double-buffered, events order the halves.
+
+    Per frame the arithmetic and the launches are OnlineStitcher's: the frames are bit-identical (tests/test_gpu_round6.py).  What
+    changes is WHEN a frame is handed out: `push` returns the frame of the PREVIOUS push (valid on the caller's stream), `flush()`
+    the last one -- a caller that consumed frame t before pushing pair t + 1 would serialise the halves again.
+        st = PipelinedOnlineStitcher(nets, H, W)
+        for pair in stream: for frame in st.push(*pair): ...
+        for frame in st.flush(): ...
+    The canvas is fixed after the first window (grow='never'; overflow is counted as in OnlineStitcher)."""
+
+    def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE', deterministic=False):
+        super().__init__(nets, height, width, canvas, margin, warp_mode, fusion_mode, use_graph=True, grow='never',
+                         meshes_only=False, deterministic=deterministic)
+        if not L.QUAD:
+            raise ValueError('PipelinedOnlineStitcher needs the shared regressor launches (SS_QUAD_REGRESSOR=1)')
+        self.pipe = None
+        self._pending = None             # (event behind it, frame) of the newest enqueued push
+        self._t = 0
+
+    def _init_pipe(self):
+        d = self.dev
+        two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
+        self.pipe = {'sa': torch.cuda.Stream(d), 'sb': torch.cuda.Stream(d),
+                     'lr': two(2, 1, 3, pipeline.LR_H, pipeline.LR_W), 'hr1': two(1, 3, self.h, self.w), 'hr2': two(1, 3, self.h, self.w),
+                     'f2': two(2, 2, pipeline.LR_H // 8, pipeline.LR_W // 8, 128), 'off1': two(1, 8), 'out': two(3, self.hc, self.wc),
+                     'ga': [None, None], 'gb': [None, None], 'eB': [None, None]}
+
+    def _run_a(self, p):
+        P = self.pipe
+        f2, off1 = self._stage_a(P['lr'][p][0], P['lr'][p][1])
+        P['f2'][p].copy_(f2)
+        P['off1'][p].copy_(off1)
+
+    def _run_b(self, p):
+        P = self.pipe
+        self._stage_b(P['f2'][p], P['off1'][p], P['hr1'][p], P['hr2'][p], P['out'][p])
+
+    def _capture_pipe(self):
+        """Warm both halves up eagerly on a copy of the state (parity 0 holds the current push's inputs), then capture each half for
+        each buffer parity.  Captures do not execute: the state is the pre-push state afterwards."""
+        st = self.static
+        torch.cuda.synchronize(self.dev)
+        state = [st[k] for k in self._STATE] + [self.watch_i, self.watch_f]
+        keep = [t.clone() for t in state]
+        side = _warmup_stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self._run_a(0)
+            self._run_b(0)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        for t, v in zip(state, keep):
+            t.copy_(v)
+        nodes = 0
+        for p in (0, 1):
+            for key, fn in (('ga', self._run_a), ('gb', self._run_b)):
+                g = _new_graph()
+                with torch.cuda.graph(g):
+                    fn(p)
+                self.pipe[key][p] = g
+                if p == 0:
+                    nodes = None if nodes is None or _graph_nodes(g) is None else nodes + _graph_nodes(g)
+        self.graph_nodes = nodes             # nodes of one push (both halves)
+        for t, v in zip(state, keep):
+            t.copy_(v)
+        torch.cuda.synchronize(self.dev)
+
+    def _push_static(self, hr1, hr2, lr1, lr2):
+        if self.pipe is None:
+            self._init_pipe()
+        if self.trunk_pair is not None and self.trunk_versions != self._versions():
+            self.trunk_pair = None
+            self.pipe['ga'] = [None, None]
+        P, p = self.pipe, self._t & 1
+        cur = torch.cuda.current_stream(self.dev)
+        ev_in = torch.cuda.Event()
+        ev_in.record(cur)
+        sa, sb = P['sa'], P['sb']
+        with torch.cuda.stream(sa):
+            sa.wait_event(ev_in)
+            if P['eB'][p] is not None:
+                sa.wait_event(P['eB'][p])            # the second half of push t - 2 has read this parity's hand-over buffers
+            P['lr'][p][0].copy_(lr1.reshape(P['lr'][p][0].shape))
+            P['lr'][p][1].copy_(lr2.reshape(P['lr'][p][1].shape))
+        with torch.cuda.stream(sb):
+            sb.wait_event(ev_in)
+            P['hr1'][p].copy_(hr1.reshape(P['hr1'][p].shape))
+            P['hr2'][p].copy_(hr2.reshape(P['hr2'][p].shape))
+        for t in (hr1, hr2):
+            t.record_stream(sb)
+        for t in (lr1, lr2):
+            t.record_stream(sa)
+        if P['ga'][p] is None:
+            self._capture_pipe()
+        with torch.cuda.stream(sa):
+            P['ga'][p].replay()
+            ea = torch.cuda.Event()
+            ea.record(sa)
+        with torch.cuda.stream(sb):
+            sb.wait_event(ea)
+            P['gb'][p].replay()
+            frame = P['out'][p].clone()
+            eb = torch.cuda.Event()
+            eb.record(sb)
+        P['eB'][p] = eb
+        prev, self._pending = self._pending, (eb, frame)
+        self._t += 1
+        self.frames_in += 1
+        return self._hand_out(prev)
+
+    def _hand_out(self, item):
+        if item is None:
+            return []
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(item[0])
+        item[1].record_stream(cur)
+        return [item[1]]
+
+    def flush(self):
+        """-> the frame of the newest push (list of 0 or 1 frames), valid on the caller's stream."""
+        item, self._pending = self._pending, None
+        return self._hand_out(item)
+
+    def overflow_report(self):
+        if self.pipe is not None:
+            torch.cuda.synchronize(self.dev)
+        return super().overflow_report()
 
 
 class MultiOnlineStitcher:

@@ -274,3 +274,34 @@ def test_render_eps_fold_is_opt_in_and_within_the_gates(dev, golden, hip_nets, c
     TP.test_tps_dense_warp_and_fusion(dev, golden)                  # G6 / G7: the fused AVERAGE frame under the switch
     TP.test_pipeline_vs_reference(dev, golden, hip_nets, clip16)    # G9
     T3.test_u8_pipeline_bytes_vs_reference(dev, golden, hip_nets)   # G13: the reference writer's bytes
+
+
+def test_pipelined_stream_equals_the_plain_stream(dev, hip_nets, clip16):
+    """PipelinedOnlineStitcher (two pushes in flight: push t + 1's trunks / stage-1 heads on a second HIP stream beside push t's
+    regressor heads, smoothing and render; one HIP graph per half and buffer parity) delivers, one push late and after `flush()`,
+    exactly OnlineStitcher's frames -- bit for bit, with the same overflow bookkeeping."""
+    from stabstitch2_amd.online import OnlineStitcher, PipelinedOnlineStitcher
+    hr, lr = clip16
+    hrd = [[f.to(dev) for f in v] for v in hr]
+    lrd = [[f.to(dev) for f in v] for v in lr]
+    n = 40
+    plain = OnlineStitcher(hip_nets, 360, 480)
+    ref = []
+    for t in range(n):
+        i = t % 16
+        ref += plain.push(hrd[0][i], hrd[1][i], lrd[0][i], lrd[1][i])
+    pipe = PipelinedOnlineStitcher(hip_nets, 360, 480)
+    got, counts = [], []
+    for t in range(n):
+        i = t % 16
+        r = pipe.push(hrd[0][i], hrd[1][i], lrd[0][i], lrd[1][i])
+        counts.append(len(r))
+        got += r
+    got += pipe.flush()
+    assert counts == [0] * 6 + [7, 0] + [1] * (n - 8) and pipe.flush() == []
+    assert len(got) == len(ref) == n and (pipe.hc, pipe.wc) == (plain.hc, plain.wc)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert pipe.overflow_report() == plain.overflow_report()
+    assert pipe.graph_nodes is None or pipe.graph_nodes >= 60

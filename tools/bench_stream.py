@@ -14,7 +14,7 @@ import torch
 
 import bench
 from stabstitch2_amd import synth
-from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher
+from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher, PipelinedOnlineStitcher
 
 
 def main():
@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--eager', action='store_true')
     ap.add_argument('--fusion', default='AVERAGE')
     ap.add_argument('--deterministic', action='store_true')
+    ap.add_argument('--pipelined', action='store_true')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.set_grad_enabled(False)
@@ -36,7 +37,10 @@ def main():
         st = ThreeViewOnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion)
         push = lambda i: st.push(hr[0][i:i + 1], hr[1][i:i + 1], hr[2][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1], lr[2][i:i + 1])
     else:
-        st = OnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion, deterministic=args.deterministic)
+        if args.pipelined:
+            st = PipelinedOnlineStitcher(nets, args.height, args.width, fusion_mode=args.fusion, deterministic=args.deterministic)
+        else:
+            st = OnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion, deterministic=args.deterministic)
         push = lambda i: st.push(hr[0][i:i + 1], hr[1][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1])
     for t in range(12):
         push(t)
@@ -46,8 +50,9 @@ def main():
         push(t % n)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res = {'deterministic': args.deterministic, 'views': args.views, 'pushes': args.pushes, 'ms_per_push': round(dt / args.pushes * 1e3, 4),
+    res = {'pipelined': args.pipelined, 'deterministic': args.deterministic, 'views': args.views, 'pushes': args.pushes, 'ms_per_push': round(dt / args.pushes * 1e3, 4),
            'fps_steady': round(args.pushes / dt, 1), 'canvas': [st.hc, st.wc]}
+    res['graph_nodes'] = getattr(st, 'graph_nodes', None)
     g = getattr(st, 'graph', None)
     if g is not None:
         reps = max(20, args.pushes // 4)
