@@ -157,8 +157,8 @@ SS_API int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, const fl
                                   int n, int h, int w, int cin, int cout, int relu, int out_cs, int groups,
                                   long long in_gs, long long u_gs, long long out_gs, void* stream);
 /* Process-wide A/B knob of ss_conv3x3_wino43_nhwc (output-neutral: bit-identical results either way): 1 (default) = PERSISTENT
- * workgroups, one per CU, each walking its share of the launch's tile blocks and requesting the next block's rows and filters in
- * front of the current block's epilogue; 0 = one workgroup per tile block (rounds 4-5). */
+ * workgroups, one per CU, each walking its share of the launch's tile blocks and requesting the next block's rows in front of
+ * the current block's epilogue; 0 = the same kernel launched with one workgroup per tile block (the schedule of rounds 4-5). */
 SS_API int ss_wino43_set_persistent(int on);
 
 /* nn.MaxPool2d(k, stride, pad) on nhwc (floor mode; spatial_network.py:130,152; -inf padding) */

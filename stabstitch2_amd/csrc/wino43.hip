@@ -151,6 +151,10 @@ __device__ __forceinline__ x_f32x2 x_pk_sub(x_f32x2 a, x_f32x2 b) {             
 #define X_LO(v) __builtin_shufflevector(v, v, 0, 1)
 #define X_HI(v) __builtin_shufflevector(v, v, 2, 3)
 
+// conv_wino43_kernel: ONE workgroup per tile block, with the phase stamps and compile-time ablations the lab tools use
+// (tools/diag_wino43.py, tools/ab_wino43_stagger.py).  TUNING BUILD ONLY since round 6: the product library carries
+// conv_wino43p_kernel below (same arithmetic, bit-identical; launched with one workgroup per block it IS this kernel's schedule).
+#ifdef SS_TUNING
 // ABL (tuning build, timing only -- wrong results): compile-time ablations of the K loop: 1 no filter loads, 2 no stage 1 (raw
 // loads, row transform, LDS writes), 4 no stage-2 arithmetic, 8 no LDS reads, 16 no barrier
 // ONE: cin == 16, the single chunk is the last one (its own instantiation: with the K loop's zero-trip case in the same code hipcc
@@ -566,6 +570,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino43_kernel(W43P p) {
     }
 #endif
 }
+
+#endif      // SS_TUNING
 
 // The same kernel with PERSISTENT workgroups (round 6): one workgroup per CU walks its share of the launch's tile
 // blocks and requests block n + 1's chunk-0 rows and first two filter groups in front of block n's epilogue.  A workgroup is alone
@@ -1128,6 +1134,7 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
         int expect = 0;
         if (st8 == 0 && attr_state[dev].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) {
             const bool ok =
+#ifdef SS_TUNING
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
@@ -1136,6 +1143,7 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<true, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43_kernel<false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+#endif
                 hipFuncSetAttribute((const void*)conv_wino43p_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43p_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                 hipFuncSetAttribute((const void*)conv_wino43p_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
@@ -1152,7 +1160,12 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
     }
     dim3 g((unsigned)wgs, 1, groups);
     hipStream_t st = (hipStream_t)stream;
-    if (g_w43_persistent.load(std::memory_order_relaxed)) {
+#ifdef SS_TUNING
+    const bool use_p = g_w43_persistent.load(std::memory_order_relaxed) != 0;
+#else
+    const bool use_p = true;       // (product: ss_wino43_set_persistent(0) launches the same kernel with one workgroup per block)
+#endif
+    if (use_p) {
         // persistent workgroups: one per CU (a multiple of 8, so that a workgroup's blocks stay on its XCD), never more than blocks
         static std::atomic<int> cus[64];
         int ncu = cus[dev].load(std::memory_order_relaxed);
@@ -1163,7 +1176,7 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
             if (ncu < 8) ncu = 8;
             cus[dev].store(ncu, std::memory_order_relaxed);
         }
-        const unsigned per_group = (unsigned)(wgs < ncu ? wgs : ncu);
+        const unsigned per_group = (unsigned)((wgs < ncu || !g_w43_persistent.load(std::memory_order_relaxed)) ? wgs : ncu);
         dim3 gp(per_group, 1, groups);
 #define X_LAUNCHP(RES_, ONE_, GEO_) hipLaunchKernelGGL((conv_wino43p_kernel<RES_, ONE_, GEO_>), gp, dim3(512), lds, st, p)
         const bool onep = p.nchunk == 1;
@@ -1178,6 +1191,7 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
         return ss_launch_status();
     }
 #ifdef SS_TUNING
+    // (tuning build, ss_wino43_set_persistent(0): the instrumented one-workgroup-per-block kernel)
     if (g_w43_ablate && !res && !geo) {         // tools/diag_wino43.py <layers> <ablation masks>
         switch (g_w43_ablate) {
 #define X_ABL_CASE(m) case m: (void)hipFuncSetAttribute((const void*)conv_wino43_kernel<false, m>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1187,7 +1201,6 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
             default: break;
         }
     }
-#endif
 #define X_LAUNCH(RES_, ONE_, GEO_) hipLaunchKernelGGL((conv_wino43_kernel<RES_, 0, ONE_, GEO_>), g, dim3(512), lds, st, p)
     const bool one = p.nchunk == 1;
     if (geo) {
@@ -1198,5 +1211,6 @@ extern "C" int ss_conv3x3_wino43_nhwc(const float* in, const float* packed, cons
         else { if (res) X_LAUNCH(true, false, 0); else X_LAUNCH(false, false, 0); }
     }
 #undef X_LAUNCH
+#endif
     return ss_launch_status();
 }

@@ -67,7 +67,7 @@ def test_no_matrix_kernel_spills_or_uses_scratch(built_lib):
     ks = kernel_resources.kernels(_hip.LIB_PATH)
     mfma = {k: v for k, v in ks.items() if v['mfma_instructions'] > 0}
     assert len(ks) >= 60 and len(mfma) >= 30, (len(ks), len(mfma))
-    for want in ('conv_igemm_kernel', 'conv_wino_kernel', 'conv_wino43_kernel', 'stem_pool_kernel_half'):
+    for want in ('conv_igemm_kernel', 'conv_wino_kernel', 'conv_wino43p_kernel', 'stem_pool_kernel_half'):
         assert any(want in k for k in mfma), want
     # (SGPR spills go to VGPR lanes -- v_writelane / v_readlane, no memory: the persistent F(4x4,3x3) kernel parks up to six
     # block-loop scalars that way outside its K loop; what must never ship is a VGPR spilled to scratch memory)
