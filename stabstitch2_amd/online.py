@@ -509,8 +509,11 @@ class PipelinedOnlineStitcher(OnlineStitcher):
         if self.pipe is None:
             self._init_pipe()
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
+            # a net was reloaded / moved: the twin trunk and ALL four graphs hold the old weights by address -- drain, recapture
+            torch.cuda.synchronize(self.dev)
             self.trunk_pair = None
             self.pipe['ga'] = [None, None]
+            self.pipe['gb'] = [None, None]
         P, p = self.pipe, self._t & 1
         cur = torch.cuda.current_stream(self.dev)
         ev_in = torch.cuda.Event()

@@ -247,6 +247,21 @@ def test_bench_self_launches_ranks_and_gathers():
     assert r2.returncode != 0 and 'WORLD_SIZE=4' in (r2.stderr + r2.stdout)
 
 
+def test_ranks_sharing_a_physical_device_are_found():
+    """dist.shared_devices: ranks are grouped by (hostname, PCI bus id) -- or the UUID where the platform reports no bus id; the local
+    device index plays no part (HIP_VISIBLE_DEVICES remaps it), a rank that reports neither is left alone."""
+    from stabstitch2_amd import dist as D
+    ident = lambda host, pci=None, uuid=None: {'hostname': host, 'pci_bus_id': pci, 'uuid': uuid, 'name': 'x'}
+    eight = [ident('n0', '0000:%02x:00.0' % (5 + 8 * r)) for r in range(8)]
+    assert D.shared_devices(eight) == []
+    assert D.shared_devices(eight[:3] + [eight[1]]) == [[1, 3]]
+    assert D.shared_devices([ident('n0', '0000:05:00.0'), ident('n1', '0000:05:00.0')]) == []        # same slot, different hosts
+    assert D.shared_devices([ident('n0', None, 'GPU-a'), ident('n0', None, 'GPU-a'), ident('n0', None, 'GPU-b')]) == [[0, 1]]
+    assert D.shared_devices([ident('n0'), ident('n0')]) == []
+    assert D.gather_objects({'a': 1}) == [{'a': 1}]                  # no process group: identity
+    assert D.shard_streams(10, 1, 4) == [1, 5, 9]
+
+
 def test_default_switches_are_the_measured_configuration():
     """The headline number is plain fp32 MFMA arithmetic with every default optimisation on; the opt-in bf16-slice
     products must stay opt-in (a default flipped by accident would change what `dtype: f32` of the bench line means)."""
@@ -268,6 +283,16 @@ def test_default_switches_are_the_measured_configuration():
         assert rule(1, 3, 3, 2, 64, 128, 45, 60, 64, 1, 0, 0, 0) == 0 and rule(1, 3, 3, 1, 24, 64, 90, 120, 64, 1, 1, 1, 1) == 0
         assert rule(1, 3, 3, 1, 64, 64, 90, 120, 16, 4, 0, 0, 0) == 1           # groups count towards the launch depth
     assert pipeline.SKIP_OUTSIDE is True and pipeline.U8_FUSED is True
+    if not any(k in os.environ for k in ('SS_DETERMINISTIC', 'SS_RENDER_EPS_FOLD', 'SS_WINO43_PERSIST')):
+        # round 6: the deterministic kernel policy and the render's eps fold are opt-ins (the fold is not the reference's arithmetic);
+        # the persistent F(4x4,3x3) launch is the default; the policy context restores what it found
+        assert ops.DETERMINISTIC is False and ops.RENDER_EPS_FOLD is False and ops.WINO43_PERSIST is True
+        assert ops._avg_mode('NORMAL') == 0 and ops._avg_mode('FAST') == 1
+        with ops.deterministic():
+            assert ops.DETERMINISTIC is True and ops._conv_ws_need(1, 1, 5, 7, 256, 256, 1, 3, 3, 1, 0, 1, 1, 4) == 0
+            with ops.deterministic(False):
+                assert ops.DETERMINISTIC is True
+        assert ops.DETERMINISTIC is False and ops._conv_ws_need(1, 1, 5, 7, 256, 256, 1, 3, 3, 1, 0, 1, 1, 4) > 0
     src = open(os.path.join(ROOT, 'bench.py')).read()
     assert "'dtype': 'f32'" in src
 
