@@ -667,6 +667,20 @@ def other_configs(nets, dev, args):
           note='MultiOnlineStitcher: S independent live pairs advance one frame per push as one batch (one HIP graph); '
                'steady state, 40 pushes of %d pairs' % S)
     del stm
+    # ... and with two pushes in flight (opt-in PipelinedMultiOnlineStitcher: frames bit-identical, handed out one push late)
+    from stabstitch2_amd.online import PipelinedMultiOnlineStitcher
+    stm = PipelinedMultiOnlineStitcher(nets, 720, 1280, streams=S)
+    for _ in range(7 + 8):
+        stm.push(mh1, mh2, ml1, ml2)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        stm.push(mh1, mh2, ml1, ml2)
+    stm.flush()
+    sync()
+    entry('720p 2-view streaming, %d streams per push, two pushes in flight (opt-in, aggregate)' % S, 40 * S, time.perf_counter() - t0, 1,
+          stm.canvas_sizes[0][0], stm.canvas_sizes[0][1], note='PipelinedMultiOnlineStitcher; steady state, 40 pushes of %d pairs' % S)
+    del stm
     # the same with 16 streams whose canvases the caller fixed to ONE size (a rig of identical cameras): one render launch per push
     S2 = 16
     mh1, mh2 = hr[0][:S2].contiguous(), hr[1][:S2].contiguous()
@@ -1018,7 +1032,8 @@ def main():
                 'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
                 'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push'),
                 'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
-                'streaming_pipelined_fps': pick('two pushes in flight'),
+                'streaming_pipelined_fps': pick('streaming, two pushes in flight'),
+                'streaming_8_streams_pipelined_fps': pick('streams per push, two pushes in flight'),
                 'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),
                 'wino43_one_block_per_workgroup_fps': pick('one workgroup per tile block'), 'render_eps_fold_fps': pick('folded into the row table')}
         for k, v in summ.items():

@@ -432,56 +432,28 @@ class OnlineStitcher:
         return [self._render(hr1, hr2, m1[-1:], m2[-1:])]
 
 
-class PipelinedOnlineStitcher(OnlineStitcher):
-    """OnlineStitcher with TWO pushes in flight (round 6; opt-in).  A batch-1 push is a dependent chain of ~80 small launches that
-    leaves most of the chip idle (profiles/r06_stream_timeline.txt: 0.86 ms, a graph node costs >= 4.5 us whatever it does), and
-    nothing inside ONE push can be overlapped further (LAB_NOTES R6.1-2).  Consecutive pushes can: the first half of a push -- both
-    trunks, SpatialNet's stage-2 trunk, contextual correlation, regressNet1 (`_stage_a`) -- touches no stream state, so push t + 1's
-    first half runs on a second HIP stream beside push t's second half (`_stage_b`: decomposition, cost volumes, regressor heads,
-    tsmotion, sliding window, SmoothNet, render).  Each half is its own HIP graph per buffer parity; hand-over buffers (LR / HR
-    frames, trunk features, offset_1, the output frame) are double-buffered, events order the halves.
+class _TwoInFlight:
+    """Mixin: the steady-state push as two halves on two HIP streams, two pushes in flight (PipelinedOnlineStitcher,
+    PipelinedMultiOnlineStitcher).  A batch-1 push is a dependent chain of ~80 small launches that leaves most of the chip idle
+    (profiles/r06_stream_timeline.txt: 0.86 ms; a graph node costs >= 4.5 us whatever it does), and nothing inside ONE push overlaps
+    any further (LAB_NOTES R6.1-2).  Consecutive pushes do: the first half of a push -- both trunks, SpatialNet's stage-2 trunk,
+    contextual correlation, regressNet1 (`_stage_a`) -- touches no stream state, so push t + 1's first half runs beside push t's second
+    half (`_stage_b`: decomposition, cost volumes, regressor heads, tsmotion, sliding window, SmoothNet, render).  Each half is its own
+    HIP graph per buffer parity; hand-over buffers are double-buffered, events order the halves.  Per frame the launches and their
+    operands are the plain stitcher's: results are bit-identical.  What changes is WHEN a result is handed out: `push` returns the
+    frames of the PREVIOUS push (valid on the caller's stream), `flush()` the last ones.
+    A subclass provides _pipe_alloc / _pipe_load / _run_a / _run_b / _pipe_take / _pipe_state / _pipe_empty."""
 
-    Per frame the arithmetic and the launches are OnlineStitcher's: the frames are bit-identical (tests/test_gpu_round6.py).  What
-    changes is WHEN a frame is handed out: `push` returns the frame of the PREVIOUS push (valid on the caller's stream), `flush()`
-    the last one -- a caller that consumed frame t before pushing pair t + 1 would serialise the halves again.
-        st = PipelinedOnlineStitcher(nets, H, W)
-        for pair in stream: for frame in st.push(*pair): ...
-        for frame in st.flush(): ...
-    The canvas is fixed after the first window (grow='never'; overflow is counted as in OnlineStitcher)."""
-
-    def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE', deterministic=False):
-        super().__init__(nets, height, width, canvas, margin, warp_mode, fusion_mode, use_graph=True, grow='never',
-                         meshes_only=False, deterministic=deterministic)
-        if not L.QUAD:
-            raise ValueError('PipelinedOnlineStitcher needs the shared regressor launches (SS_QUAD_REGRESSOR=1)')
+    def _pipe_init(self):
         self.pipe = None
-        self._pending = None             # (event behind it, frame) of the newest enqueued push
+        self._pending = None             # (event behind it, result) of the newest enqueued push
         self._t = 0
-
-    def _init_pipe(self):
-        d = self.dev
-        two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
-        self.pipe = {'sa': torch.cuda.Stream(d), 'sb': torch.cuda.Stream(d),
-                     'lr': two(2, 1, 3, pipeline.LR_H, pipeline.LR_W), 'hr1': two(1, 3, self.h, self.w), 'hr2': two(1, 3, self.h, self.w),
-                     'f2': two(2, 2, pipeline.LR_H // 8, pipeline.LR_W // 8, 128), 'off1': two(1, 8), 'out': two(3, self.hc, self.wc),
-                     'ga': [None, None], 'gb': [None, None], 'eB': [None, None]}
-
-    def _run_a(self, p):
-        P = self.pipe
-        f2, off1 = self._stage_a(P['lr'][p][0], P['lr'][p][1])
-        P['f2'][p].copy_(f2)
-        P['off1'][p].copy_(off1)
-
-    def _run_b(self, p):
-        P = self.pipe
-        self._stage_b(P['f2'][p], P['off1'][p], P['hr1'][p], P['hr2'][p], P['out'][p])
 
     def _capture_pipe(self):
         """Warm both halves up eagerly on a copy of the state (parity 0 holds the current push's inputs), then capture each half for
         each buffer parity.  Captures do not execute: the state is the pre-push state afterwards."""
-        st = self.static
         torch.cuda.synchronize(self.dev)
-        state = [st[k] for k in self._STATE] + [self.watch_i, self.watch_f]
+        state = self._pipe_state()
         keep = [t.clone() for t in state]
         side = _warmup_stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -499,15 +471,17 @@ class PipelinedOnlineStitcher(OnlineStitcher):
                     fn(p)
                 self.pipe[key][p] = g
                 if p == 0:
-                    nodes = None if nodes is None or _graph_nodes(g) is None else nodes + _graph_nodes(g)
+                    n = _graph_nodes(g)
+                    nodes = None if nodes is None or n is None else nodes + n
         self.graph_nodes = nodes             # nodes of one push (both halves)
         for t, v in zip(state, keep):
             t.copy_(v)
         torch.cuda.synchronize(self.dev)
 
-    def _push_static(self, hr1, hr2, lr1, lr2):
+    def _push_pipelined(self, *inputs):
         if self.pipe is None:
-            self._init_pipe()
+            self.pipe = dict(self._pipe_alloc(), sa=torch.cuda.Stream(self.dev), sb=torch.cuda.Stream(self.dev),
+                             ga=[None, None], gb=[None, None], eB=[None, None])
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
             # a net was reloaded / moved: the twin trunk and ALL four graphs hold the old weights by address -- drain, recapture
             torch.cuda.synchronize(self.dev)
@@ -519,20 +493,11 @@ class PipelinedOnlineStitcher(OnlineStitcher):
         ev_in = torch.cuda.Event()
         ev_in.record(cur)
         sa, sb = P['sa'], P['sb']
-        with torch.cuda.stream(sa):
-            sa.wait_event(ev_in)
-            if P['eB'][p] is not None:
-                sa.wait_event(P['eB'][p])            # the second half of push t - 2 has read this parity's hand-over buffers
-            P['lr'][p][0].copy_(lr1.reshape(P['lr'][p][0].shape))
-            P['lr'][p][1].copy_(lr2.reshape(P['lr'][p][1].shape))
-        with torch.cuda.stream(sb):
-            sb.wait_event(ev_in)
-            P['hr1'][p].copy_(hr1.reshape(P['hr1'][p].shape))
-            P['hr2'][p].copy_(hr2.reshape(P['hr2'][p].shape))
-        for t in (hr1, hr2):
-            t.record_stream(sb)
-        for t in (lr1, lr2):
-            t.record_stream(sa)
+        sa.wait_event(ev_in)
+        sb.wait_event(ev_in)
+        if P['eB'][p] is not None:
+            sa.wait_event(P['eB'][p])                # the second half of push t - 2 has read this parity's hand-over buffers
+        self._pipe_load(p, sa, sb, *inputs)
         if P['ga'][p] is None:
             self._capture_pipe()
         with torch.cuda.stream(sa):
@@ -542,32 +507,99 @@ class PipelinedOnlineStitcher(OnlineStitcher):
         with torch.cuda.stream(sb):
             sb.wait_event(ea)
             P['gb'][p].replay()
-            frame = P['out'][p].clone()
+            result = self._pipe_take(p)
             eb = torch.cuda.Event()
             eb.record(sb)
         P['eB'][p] = eb
-        prev, self._pending = self._pending, (eb, frame)
+        prev, self._pending = self._pending, (eb, result)
         self._t += 1
         self.frames_in += 1
         return self._hand_out(prev)
 
     def _hand_out(self, item):
         if item is None:
-            return []
+            return self._pipe_empty()
         cur = torch.cuda.current_stream(self.dev)
         cur.wait_event(item[0])
-        item[1].record_stream(cur)
-        return [item[1]]
+        for t in _tensors_of(item[1]):
+            t.record_stream(cur)
+        return item[1]
 
     def flush(self):
-        """-> the frame of the newest push (list of 0 or 1 frames), valid on the caller's stream."""
+        """-> the result of the newest push (what `push` would have returned one push later), valid on the caller's stream."""
         item, self._pending = self._pending, None
         return self._hand_out(item)
 
     def overflow_report(self):
-        if self.pipe is not None:
+        if getattr(self, 'pipe', None) is not None:
             torch.cuda.synchronize(self.dev)
         return super().overflow_report()
+
+
+def _tensors_of(x):
+    if torch.is_tensor(x):
+        yield x
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            yield from _tensors_of(y)
+
+
+class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
+    """OnlineStitcher with TWO pushes in flight (round 6; opt-in; see _TwoInFlight).  Frames bit-identical to OnlineStitcher
+    (tests/test_gpu_round6.py), handed out one push late:
+        st = PipelinedOnlineStitcher(nets, H, W)
+        for pair in stream: for frame in st.push(*pair): ...
+        for frame in st.flush(): ...
+    0.64 ms per push = 1559 frames/s at 720p against 0.85 ms / 1171.  The canvas is fixed after the first window (grow='never';
+    overflow is counted as in OnlineStitcher)."""
+
+    def __init__(self, nets, height, width, canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE', deterministic=False):
+        OnlineStitcher.__init__(self, nets, height, width, canvas, margin, warp_mode, fusion_mode, use_graph=True, grow='never',
+                                meshes_only=False, deterministic=deterministic)
+        if not L.QUAD:
+            raise ValueError('PipelinedOnlineStitcher needs the shared regressor launches (SS_QUAD_REGRESSOR=1)')
+        self._pipe_init()
+
+    def _pipe_alloc(self):
+        d = self.dev
+        two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
+        return {'lr': two(2, 1, 3, pipeline.LR_H, pipeline.LR_W), 'hr1': two(1, 3, self.h, self.w), 'hr2': two(1, 3, self.h, self.w),
+                'f2': two(2, 2, pipeline.LR_H // 8, pipeline.LR_W // 8, 128), 'off1': two(1, 8), 'out': two(3, self.hc, self.wc)}
+
+    def _pipe_state(self):
+        return [self.static[k] for k in self._STATE] + [self.watch_i, self.watch_f]
+
+    def _pipe_empty(self):
+        return []
+
+    def _pipe_load(self, p, sa, sb, hr1, hr2, lr1, lr2):
+        P = self.pipe
+        with torch.cuda.stream(sa):
+            P['lr'][p][0].copy_(lr1.reshape(P['lr'][p][0].shape))
+            P['lr'][p][1].copy_(lr2.reshape(P['lr'][p][1].shape))
+        with torch.cuda.stream(sb):
+            P['hr1'][p].copy_(hr1.reshape(P['hr1'][p].shape))
+            P['hr2'][p].copy_(hr2.reshape(P['hr2'][p].shape))
+        for t in (hr1, hr2):
+            t.record_stream(sb)
+        for t in (lr1, lr2):
+            t.record_stream(sa)
+
+    def _run_a(self, p):
+        P = self.pipe
+        f2, off1 = self._stage_a(P['lr'][p][0], P['lr'][p][1])
+        P['f2'][p].copy_(f2)
+        P['off1'][p].copy_(off1)
+
+    def _run_b(self, p):
+        P = self.pipe
+        self._stage_b(P['f2'][p], P['off1'][p], P['hr1'][p], P['hr2'][p], P['out'][p])
+
+    def _pipe_take(self, p):
+        return [self.pipe['out'][p].clone()]
+
+    def _push_static(self, hr1, hr2, lr1, lr2):
+        return self._push_pipelined(hr1, hr2, lr1, lr2)
 
 
 class MultiOnlineStitcher:
@@ -727,20 +759,37 @@ class MultiOnlineStitcher:
         self._host_event = ev
 
     def _step_static(self):
-        st, S, e = self.static, self.S, 126
+        st = self.static
+        f64, feat, off1 = self._stage_a(st['lrc'] if self.chain else [st['lr1'], st['lr2']])
+        self._stage_b(f64, feat, off1, st['hr1'], st['hr2'], st['out_all'], st['out'])
+
+    def _stage_a(self, lr):
+        """First half of a steady-state push (no stream state): trunks, SpatialNet's stage-2 trunk, CCL, regressNet1.
+        lr: [lr1, lr2] ([S,3,360,480] each) or, chain mode, the S + 1 views' frames [S+1,3,360,480] (each view once)
+        -> (f64 SpatialNet trunk features, feat TemporalNet features [2S, view-major], offset_1 [S,8] | None)."""
+        S = self.S
         if self.trunk_pair is None:
             self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
             self.trunk_versions = self._versions()
-        ps, pt = st['pair_s'], st['pair_t']
         if self.chain:
-            fc = L.run_stage1_pair([st['lrc']], self.trunk_pair)                   # [2(net), S + 1 views, 45,60,128]: each view once
+            fc = L.run_stage1_pair([lr], self.trunk_pair)                          # [2(net), S + 1 views, 45,60,128]: each view once
             feat = torch.cat((fc[1][:S], fc[1][1:]), 0)                            # TemporalNet's features, view-major per pair
             f64 = fc[0]
         else:
-            f2 = L.run_stage1_pair([st['lr1'], st['lr2']], self.trunk_pair)        # [2(net), 2S (view-major), 45,60,128]
+            f2 = L.run_stage1_pair(list(lr), self.trunk_pair)                      # [2(net), 2S (view-major), 45,60,128]
             feat, f64 = f2[1], f2[0]
-        off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f64, st['prev_feat'], feat, S,
-                                                         (pt[0, 1], pt[1, 1]), chain=self.chain)
+        return f64, feat, (_heads_a(self.spatial, f64, S, self.chain) if L.QUAD else None)
+
+    def _stage_b(self, f64, feat, off1, hr1, hr2, out_all, out):
+        """Second half: everything that reads or advances the streams' state, and the render into out_all / out."""
+        st, S, e = self.static, self.S, 126
+        ps, pt = st['pair_s'], st['pair_t']
+        tm_out = (pt[0, 1], pt[1, 1])
+        if off1 is None:
+            off1, off_ref, off_tgt = _spatial_temporal_heads(self.spatial, self.temporal, f64, st['prev_feat'], feat, S, tm_out,
+                                                             chain=self.chain)
+        else:
+            off_ref, off_tgt = _heads_b(self.spatial, self.temporal, f64, off1, st['prev_feat'], feat, S, tm_out, self.chain)
         ops.spatial_meshes(off1, off_ref, off_tgt, pipeline.LR_H, pipeline.LR_W,
                            out=(ps[0, 1].view(S, 7, 9, 2), ps[1, 1].view(S, 7, 9, 2)))
         st['prev_feat'].copy_(feat)
@@ -764,17 +813,17 @@ class MultiOnlineStitcher:
         src = ops.stream_normalize_watch([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w, self.single[0]._guard(),
                                          st['watch_i'], st['watch_f'])                                             # [S,2,63,2]
         T = ops.tps_solve_shared(src.view(2 * S, 63, 2), self.single[0].nrigid).view(S, 2, 2, 66)
-        if st['out_all'] is not None:
+        if out_all is not None:
             # all streams render onto canvases of ONE size (e.g. the caller fixed them): the S current frames are a clip
             hc, wc = self.single[0].hc, self.single[0].wc
             if self.fusion_mode == 'AVERAGE':
                 fp = ops.render_footprints(src, T, self.h, self.w, hc, wc) if pipeline.SKIP_OUTSIDE else None
-                ops.render_average_clip([st['hr1'], st['hr2']], src, T, hc, wc, self.warp_mode, out=st['out_all'], footprint=fp)
+                ops.render_average_clip([hr1, hr2], src, T, hc, wc, self.warp_mode, out=out_all, footprint=fp)
             else:
-                ops.render_linear_clip([st['hr1'], st['hr2']], src, T, hc, wc, self.warp_mode, out=st['out_all'])
+                ops.render_linear_clip([hr1, hr2], src, T, hc, wc, self.warp_mode, out=out_all)
             return
         for s, one in enumerate(self.single):
-            one._render_solved(st['hr1'][s:s + 1], st['hr2'][s:s + 1], src[s], T[s], out=st['out'][s])
+            one._render_solved(hr1[s:s + 1], hr2[s:s + 1], src[s], T[s], out=out[s])
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static
@@ -842,6 +891,71 @@ class MultiOnlineStitcher:
             self.last_meshes = (torch.stack([o[0] for o in outs], 0), torch.stack([o[1] for o in outs], 0))   # [S,7,7,9,2]
             return self.last_meshes
         return outs
+
+
+class PipelinedMultiOnlineStitcher(_TwoInFlight, MultiOnlineStitcher):
+    """MultiOnlineStitcher (S live pairs advancing together) with TWO pushes in flight (round 6; opt-in; see _TwoInFlight): every
+    stream's frames bit-identical to MultiOnlineStitcher's, handed out one push late:
+        st = PipelinedMultiOnlineStitcher(nets, H, W, streams=8)
+        for batch in source: per_stream = st.push(*batch)        # S lists: [] x 6, 7 frames, [] (one push of lag), then 1 frame each
+        per_stream = st.flush()
+    Canvases are fixed after the first window (grow='never')."""
+
+    def __init__(self, nets, height, width, streams, canvases=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE',
+                 deterministic=False):
+        MultiOnlineStitcher.__init__(self, nets, height, width, streams, canvases, margin, warp_mode, fusion_mode, use_graph=True,
+                                     grow='never', meshes_only=False, deterministic=deterministic)
+        if not L.QUAD:
+            raise ValueError('PipelinedMultiOnlineStitcher needs the shared regressor launches (SS_QUAD_REGRESSOR=1)')
+        self._pipe_init()
+
+    def _pipe_alloc(self):
+        d, S = self.dev, self.S
+        two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
+        fh, fw = pipeline.LR_H // 8, pipeline.LR_W // 8
+        P = {'lr': two(2, S, 3, pipeline.LR_H, pipeline.LR_W), 'hr': two(2, S, 3, self.h, self.w),
+             'f64': two(2 * S, fh, fw, 128), 'feat': two(2 * S, fh, fw, 128), 'off1': two(S, 8)}
+        if self.static['out_all'] is not None:
+            P['out_all'] = two(*self.static['out_all'].shape)
+            P['out'] = [[oa[s] for s in range(S)] for oa in P['out_all']]
+        else:
+            P['out_all'] = [None, None]
+            P['out'] = [[torch.empty_like(o) for o in self.static['out']] for _ in range(2)]
+        return P
+
+    def _pipe_state(self):
+        return [self.static[k] for k in self._STATE + ('watch_i', 'watch_f')]
+
+    def _pipe_empty(self):
+        return [[] for _ in range(self.S)]
+
+    def _pipe_load(self, p, sa, sb, hr1, hr2, lr1, lr2):
+        P = self.pipe
+        with torch.cuda.stream(sa):
+            P['lr'][p][0].copy_(lr1); P['lr'][p][1].copy_(lr2)
+        with torch.cuda.stream(sb):
+            P['hr'][p][0].copy_(hr1); P['hr'][p][1].copy_(hr2)
+        for t in (hr1, hr2):
+            t.record_stream(sb)
+        for t in (lr1, lr2):
+            t.record_stream(sa)
+
+    def _run_a(self, p):
+        P = self.pipe
+        f64, feat, off1 = self._stage_a([P['lr'][p][0], P['lr'][p][1]])
+        P['f64'][p].copy_(f64)
+        P['feat'][p].copy_(feat)
+        P['off1'][p].copy_(off1)
+
+    def _run_b(self, p):
+        P = self.pipe
+        self._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], P['hr'][p][0], P['hr'][p][1], P['out_all'][p], P['out'][p])
+
+    def _pipe_take(self, p):
+        return [[o.clone()] for o in self.pipe['out'][p]]
+
+    def _push_static(self, hr1, hr2, lr1, lr2):
+        return self._push_pipelined(hr1, hr2, lr1, lr2)
 
 
 class ThreeViewOnlineStitcher:

@@ -305,3 +305,39 @@ def test_pipelined_stream_equals_the_plain_stream(dev, hip_nets, clip16):
         assert torch.equal(a, b)
     assert pipe.overflow_report() == plain.overflow_report()
     assert pipe.graph_nodes is None or pipe.graph_nodes >= 60
+
+
+def test_pipelined_multi_stream_equals_the_plain_batch(dev, hip_nets, clip16):
+    """PipelinedMultiOnlineStitcher (S live pairs per push, two pushes in flight) against MultiOnlineStitcher: every stream's
+    frames bit for bit, one push late; per-stream canvases of different sizes and the one-size clip-style render."""
+    from stabstitch2_amd.online import MultiOnlineStitcher, PipelinedMultiOnlineStitcher
+    hr, lr = clip16
+    H1 = torch.cat([f.to(dev) for f in hr[0]], 0); H2 = torch.cat([f.to(dev) for f in hr[1]], 0)
+    L1 = torch.cat([f.to(dev) for f in lr[0]], 0); L2 = torch.cat([f.to(dev) for f in lr[1]], 0)
+    S, n = 3, 20
+
+    def batch(t):      # stream s shows the clip s frames ahead (stream 2 with the views swapped: another canvas size)
+        idx = [(t + s) % 16 for s in range(S)]
+        a, b, c, d = H1[idx].clone(), H2[idx].clone(), L1[idx].clone(), L2[idx].clone()
+        a[2], b[2] = H2[idx[2]], H1[idx[2]]
+        c[2], d[2] = L2[idx[2]], L1[idx[2]]
+        return a, b, c, d
+    for canvases in (None, [(-20.0, 700.0, -15.0, 375.0)] * S):
+        plain = MultiOnlineStitcher(hip_nets, 360, 480, streams=S, canvases=canvases)
+        pipe = PipelinedMultiOnlineStitcher(hip_nets, 360, 480, streams=S, canvases=canvases)
+        ref = [[] for _ in range(S)]
+        got = [[] for _ in range(S)]
+        for t in range(n):
+            for s, fr in enumerate(plain.push(*batch(t))):
+                ref[s] += fr
+            for s, fr in enumerate(pipe.push(*batch(t))):
+                got[s] += fr
+        for s, fr in enumerate(pipe.flush()):
+            got[s] += fr
+        torch.cuda.synchronize()
+        assert pipe.canvas_sizes == plain.canvas_sizes
+        for s in range(S):
+            assert len(got[s]) == len(ref[s]) == n
+            for a, b in zip(got[s], ref[s]):
+                assert torch.equal(a, b)
+        assert pipe.overflow_report() == plain.overflow_report()
