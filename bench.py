@@ -641,6 +641,20 @@ def other_configs(nets, dev, args):
           note='ThreeViewOnlineStitcher, steady state (graph replays), 100 pushes; the middle view passes the trunks once')
     res['720p 3-view streaming (batch 1, one triple per push)']['graph_nodes'] = st3.graph_nodes
     del st3
+    from stabstitch2_amd.online import PipelinedThreeViewOnlineStitcher
+    st3 = PipelinedThreeViewOnlineStitcher(nets, 720, 1280)
+    for t in range(12):
+        st3.push(hr[0][t:t + 1], hr[1][t:t + 1], hr[2][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1], lr[2][t:t + 1])
+    sync()
+    t0 = time.perf_counter()
+    for t in range(100):
+        i = t % n
+        st3.push(hr[0][i:i + 1], hr[1][i:i + 1], hr[2][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1], lr[2][i:i + 1])
+    st3.flush()
+    sync()
+    entry('720p 3-view streaming, two pushes in flight (opt-in PipelinedThreeViewOnlineStitcher)', 100, time.perf_counter() - t0, 1, st3.hc, st3.wc,
+          note='frames bit-identical to ThreeViewOnlineStitcher, handed out one push late')
+    del st3
     # batch of S independent live streams advancing together (one graph launch per push of S pairs)
     from stabstitch2_amd.online import MultiOnlineStitcher
     S = 8
@@ -1034,6 +1048,7 @@ def main():
                 'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
                 'streaming_pipelined_fps': pick('streaming, two pushes in flight'),
                 'streaming_8_streams_pipelined_fps': pick('streams per push, two pushes in flight'),
+                'three_view_streaming_pipelined_fps': pick('3-view streaming, two pushes in flight'),
                 'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),
                 'wino43_one_block_per_workgroup_fps': pick('one workgroup per tile block'), 'render_eps_fold_fps': pick('folded into the row table')}
         for k, v in summ.items():

@@ -1128,3 +1128,64 @@ class ThreeViewOnlineStitcher:
                        'hr': torch.empty((3, 3, self.h, self.w), device=self.dev)}
         self.versions = self._versions()
         return frames
+
+
+class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
+    """ThreeViewOnlineStitcher with TWO pushes in flight (round 6; opt-in; see _TwoInFlight): the three views' trunks and the two
+    pairs' stage-1 heads of triple t + 1 run beside triple t's regressor heads, smoothing, composition and three-image render.  Frames
+    bit-identical to ThreeViewOnlineStitcher's, handed out one push late (`flush()` for the last); boxes fixed after the first window."""
+
+    def __init__(self, nets, height, width, canvas=None, first_canvas=None, margin=0.03, warp_mode='NORMAL', fusion_mode='AVERAGE'):
+        ThreeViewOnlineStitcher.__init__(self, nets, height, width, canvas, first_canvas, margin, warp_mode, fusion_mode,
+                                         use_graph=True, grow='never')
+        if not L.QUAD:
+            raise ValueError('PipelinedThreeViewOnlineStitcher needs the shared regressor launches (SS_QUAD_REGRESSOR=1)')
+        self._pipe_init()
+
+    # the twin trunk lives in the pair chains
+    trunk_pair = property(lambda self: self.chains.trunk_pair, lambda self, v: setattr(self.chains, 'trunk_pair', v))
+    trunk_versions = property(lambda self: self.chains.trunk_versions, lambda self, v: setattr(self.chains, 'trunk_versions', v))
+
+    def _pipe_alloc(self):
+        d = self.dev
+        two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
+        fh, fw = pipeline.LR_H // 8, pipeline.LR_W // 8
+        return {'lrc': two(3, 3, pipeline.LR_H, pipeline.LR_W), 'hr': two(3, 3, self.h, self.w), 'f64': two(3, fh, fw, 128),
+                'feat': two(4, fh, fw, 128), 'off1': two(2, 8), 'out': two(3, self.hc, self.wc)}
+
+    def _pipe_state(self):
+        return self._state()
+
+    def _pipe_empty(self):
+        return []
+
+    def _pipe_load(self, p, sa, sb, hr1, hr2, hr3, lr1, lr2, lr3):
+        P = self.pipe
+        for k, (h, l) in enumerate(((hr1, lr1), (hr2, lr2), (hr3, lr3))):
+            with torch.cuda.stream(sa):
+                P['lrc'][p][k:k + 1].copy_(l.reshape(P['lrc'][p][k:k + 1].shape))
+            with torch.cuda.stream(sb):
+                P['hr'][p][k:k + 1].copy_(h.reshape(P['hr'][p][k:k + 1].shape))
+            h.record_stream(sb)
+            l.record_stream(sa)
+
+    def _run_a(self, p):
+        P = self.pipe
+        f64, feat, off1 = self.chains._stage_a(P['lrc'][p])
+        P['f64'][p].copy_(f64)
+        P['feat'][p].copy_(feat)
+        P['off1'][p].copy_(off1)
+
+    def _run_b(self, p):
+        P, ch = self.pipe, self.chains
+        ch._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], None, None, None, None)
+        m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
+        meshes = self._compose((m1[0], m2[0]), (m1[1], m2[1]))
+        hr = P['hr'][p]
+        self._render([hr[0:1], hr[1:2], hr[2:3]], meshes, out=P['out'][p])
+
+    def _pipe_take(self, p):
+        return [self.pipe['out'][p].clone()]
+
+    def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3):
+        return self._push_pipelined(hr1, hr2, hr3, lr1, lr2, lr3)

@@ -341,3 +341,26 @@ def test_pipelined_multi_stream_equals_the_plain_batch(dev, hip_nets, clip16):
             for a, b in zip(got[s], ref[s]):
                 assert torch.equal(a, b)
         assert pipe.overflow_report() == plain.overflow_report()
+
+
+def test_pipelined_three_view_stream_equals_the_plain_one(dev, hip_nets):
+    """PipelinedThreeViewOnlineStitcher against ThreeViewOnlineStitcher: the same frames bit for bit, one push late."""
+    from stabstitch2_amd.online import ThreeViewOnlineStitcher, PipelinedThreeViewOnlineStitcher
+    n, h, w = 16, 180, 320
+    hr, lr = synth.make_clip(n, h, w, seed=4, views=3)
+    hrd = [[f.to(dev) for f in v] for v in hr]
+    lrd = [[f.to(dev) for f in v] for v in lr]
+    for fusion in ('AVERAGE', 'LINEAR'):
+        plain = ThreeViewOnlineStitcher(hip_nets, h, w, fusion_mode=fusion)
+        pipe = PipelinedThreeViewOnlineStitcher(hip_nets, h, w, fusion_mode=fusion)
+        ref, got = [], []
+        for t in range(24):
+            i = t % n
+            ref += plain.push(hrd[0][i], hrd[1][i], hrd[2][i], lrd[0][i], lrd[1][i], lrd[2][i])
+            got += pipe.push(hrd[0][i], hrd[1][i], hrd[2][i], lrd[0][i], lrd[1][i], lrd[2][i])
+        got += pipe.flush()
+        torch.cuda.synchronize()
+        assert len(got) == len(ref) == 24 and (pipe.hc, pipe.wc) == (plain.hc, plain.wc)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        assert pipe.overflow_report() == plain.overflow_report()

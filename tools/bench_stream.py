@@ -14,7 +14,7 @@ import torch
 
 import bench
 from stabstitch2_amd import synth
-from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher, PipelinedOnlineStitcher
+from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher, PipelinedOnlineStitcher, PipelinedThreeViewOnlineStitcher
 
 
 def main():
@@ -34,7 +34,10 @@ def main():
     n = 32
     hr, lr = synth.make_clip_device(n, args.height, args.width, seed=0, views=args.views, device=dev)
     if args.views == 3:
-        st = ThreeViewOnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion)
+        if args.pipelined:
+            st = PipelinedThreeViewOnlineStitcher(nets, args.height, args.width, fusion_mode=args.fusion)
+        else:
+            st = ThreeViewOnlineStitcher(nets, args.height, args.width, use_graph=not args.eager, fusion_mode=args.fusion)
         push = lambda i: st.push(hr[0][i:i + 1], hr[1][i:i + 1], hr[2][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1], lr[2][i:i + 1])
     else:
         if args.pipelined:
