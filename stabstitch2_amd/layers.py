@@ -344,7 +344,7 @@ def run_regressor_quad(cv_s, cv_t, q, outs):
                          % (q['fc'][0][0].shape[2], h.shape[2]))
     for l in (0, 1):
         w, bias = q['fc'][l]
-        if b >= FC_GEMM_ROWS and not ops.DETERMINISTIC:
+        if b >= FC_GEMM_ROWS and not ops.is_deterministic():
             # enough rows for a matrix-core tile: the grouped product as a 1x1 convolution on the conv engine (tools/ab_fc_grouped.py,
             # 4 heads x 32 rows: 1536 -> 1024 in 14.9 us against 34.8 for the one-wave-per-neuron kernel, 1024 -> 512 in 9.0 against 13.9)
             h = ops.conv_grouped(h.view(g, 1, 1, b, h.shape[2]), w.view(g, w.shape[1], 1, 1, 1, w.shape[2]), bias, None, stride=1,

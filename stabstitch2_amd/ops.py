@@ -2,6 +2,7 @@
 device that owns the tensors, return device tensors.  These wrappers do no arithmetic of their own (the few
 mesh-sized torch expressions of the path live in pipeline.py and are named there)."""
 import os
+import threading
 
 import torch
 
@@ -159,27 +160,37 @@ def stem_pool(buf, wgt, bias=None):
 # bit-identical whatever the batch: resident clip == chunked passes == streamed (tests/test_gpu_round6.py).  Price: small launches
 # lose split-K's parallelism (batch-1 streaming ~1.6x slower, clips unchanged to ~1 %).
 #     with ops.deterministic(): ...          or        pipeline.run_two_view(..., deterministic=True), OnlineStitcher(..., deterministic=True)
-DETERMINISTIC = os.environ.get('SS_DETERMINISTIC', '0') == '1'
+DETERMINISTIC = os.environ.get('SS_DETERMINISTIC', '0') == '1'        # the process default; `with ops.deterministic():` overrides it per THREAD
 _PIN_IMAGES = 1 << 20
+_policy_tls = threading.local()
+
+
+def is_deterministic():
+    """Is the geometry-only kernel policy in force for the calling thread (a `with ops.deterministic():` block, else the process
+    default SS_DETERMINISTIC)?"""
+    return getattr(_policy_tls, 'on', DETERMINISTIC)
 
 
 class deterministic:
-    """Context manager: the geometry-only kernel policy inside the block (flag=False: leave the current policy as it is)."""
+    """Context manager: the geometry-only kernel policy inside the block, for the calling thread (flag=False: leave the policy in
+    force as it is)."""
 
     def __init__(self, flag=True):
         self.flag = bool(flag)
         self.old = None
 
     def __enter__(self):
-        global DETERMINISTIC
-        self.old = DETERMINISTIC
+        self.old = getattr(_policy_tls, 'on', None)
         if self.flag:
-            DETERMINISTIC = True
+            _policy_tls.on = True
         return self
 
     def __exit__(self, *exc):
-        global DETERMINISTIC
-        DETERMINISTIC = self.old
+        if self.old is None:
+            if hasattr(_policy_tls, 'on'):
+                del _policy_tls.on
+        else:
+            _policy_tls.on = self.old
         return False
 
 
@@ -193,7 +204,7 @@ def conv_workspace(device, floats):
 
 
 def _conv_ws_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups):
-    if DETERMINISTIC:          # no workspace = no split-K (ss_conv_nhwc: "a NULL workspace disables splitting")
+    if is_deterministic():     # no workspace = no split-K (ss_conv_nhwc: "a NULL workspace disables splitting")
         return 0
     return int(H.lib().ss_conv_workspace_need(n, t, h, w, c, cout, kt, kh, kw, stride, pt, ph, pw, groups))
 
@@ -218,7 +229,7 @@ def _uses_wino43(kt, kh, kw, stride, pad, cin, cout, ho, wo, images, groups=1):
         return False
     forced = WINO43 == '1'
     return bool(H.lib().ss_conv_uses_wino43(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho), int(wo),
-                                            int(images), int(groups), 1 if (forced or DETERMINISTIC) else WINO43_MIN_WGS,
+                                            int(images), int(groups), 1 if (forced or is_deterministic()) else WINO43_MIN_WGS,
                                             1 if forced else WINO43_MIN_CIN, 1 if forced else 0))
 
 
@@ -254,7 +265,7 @@ def _try_wino43(x, wgt, bias, res, relu, out):
 def _uses_winograd(kt, kh, kw, stride, pad, cin, cout, ho, wo, images):
     return bool(WINOGRAD and kt == 1 and tuple(pad) == (0, 1, 1) and
                 H.lib().ss_conv_uses_winograd(int(kt), int(kh), int(kw), int(stride), int(cin), int(cout), int(ho),
-                                              int(wo), _PIN_IMAGES if DETERMINISTIC else int(images)))
+                                              int(wo), _PIN_IMAGES if is_deterministic() else int(images)))
 
 
 # which kernel the most recent ops.conv / ops.conv_grouped / ops.conv_winograd call launched ('wino' | 'igemm'): read by

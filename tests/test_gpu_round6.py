@@ -364,3 +364,36 @@ def test_pipelined_three_view_stream_equals_the_plain_one(dev, hip_nets):
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
         assert pipe.overflow_report() == plain.overflow_report()
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 90, 120, 24), (128, 128, 45, 60, 40), (256, 256, 23, 30, 48), (16, 64, 45, 60, 40),
+                                   (64, 64, 37, 61, 33)])
+def test_wino43_persistent_workgroups_are_output_neutral(dev, shape):
+    """conv_wino43p_kernel walking SEVERAL tile blocks per workgroup (one workgroup per CU, the next block's rows requested in front
+    of the epilogue) against the same kernel launched with one workgroup per block (`ss_wino43_set_persistent(0)`): bit-identical,
+    both block geometries (8 x 60, 16 x 32), with / without residual, the single-chunk (cin = 16) instantiation, a ragged map; and
+    within the engine's usual gate of fp64 direct convolution."""
+    from stabstitch2_amd import ops, _hip as H
+    cin, cout, h, w, n = shape
+    g = torch.Generator(device='cpu').manual_seed(cin + 7 * h)
+    x = torch.randn((n, h, w, cin), generator=g).to(dev)
+    wgt = (torch.randn((cout, 1, 3, 3, cin), generator=g) / np.sqrt(9 * cin)).to(dev)
+    bias = torch.randn((cout,), generator=g).to(dev)
+    res = torch.randn((n, h, w, cout), generator=g).to(dev)
+    try:
+        for r in (None, res):
+            H.lib().ss_wino43_set_persistent(0)
+            a = ops.conv_winograd43(x, wgt, bias, r, True)
+            H.lib().ss_wino43_set_persistent(1)
+            b = ops.conv_winograd43(x, wgt, bias, r, True)
+            c = ops.conv_winograd43(x, wgt, bias, r, True)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b) and torch.equal(b, c)
+            want = torch.nn.functional.conv2d(x[:4].double().permute(0, 3, 1, 2), wgt[:, 0].double().permute(0, 3, 1, 2), bias.double(), padding=1)
+            if r is not None:
+                want = want + r[:4].double().permute(0, 3, 1, 2)
+            want = want.clamp_min(0).permute(0, 2, 3, 1)
+            assert float((b[:4].double() - want).abs().max()) < 3e-4
+    finally:
+        H.lib().ss_wino43_set_persistent(1)
+        ops._w43_persist_set[0] = None

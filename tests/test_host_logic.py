@@ -288,11 +288,16 @@ def test_default_switches_are_the_measured_configuration():
         # the persistent F(4x4,3x3) launch is the default; the policy context restores what it found
         assert ops.DETERMINISTIC is False and ops.RENDER_EPS_FOLD is False and ops.WINO43_PERSIST is True
         assert ops._avg_mode('NORMAL') == 0 and ops._avg_mode('FAST') == 1
+        import threading
+        seen = []
         with ops.deterministic():
-            assert ops.DETERMINISTIC is True and ops._conv_ws_need(1, 1, 5, 7, 256, 256, 1, 3, 3, 1, 0, 1, 1, 4) == 0
+            assert ops.is_deterministic() and ops._conv_ws_need(1, 1, 5, 7, 256, 256, 1, 3, 3, 1, 0, 1, 1, 4) == 0
             with ops.deterministic(False):
-                assert ops.DETERMINISTIC is True
-        assert ops.DETERMINISTIC is False and ops._conv_ws_need(1, 1, 5, 7, 256, 256, 1, 3, 3, 1, 0, 1, 1, 4) > 0
+                assert ops.is_deterministic()
+            th = threading.Thread(target=lambda: seen.append(ops.is_deterministic()))        # the policy is per thread
+            th.start(); th.join()
+        assert seen == [False]
+        assert not ops.is_deterministic() and ops._conv_ws_need(1, 1, 5, 7, 256, 256, 1, 3, 3, 1, 0, 1, 1, 4) > 0
     src = open(os.path.join(ROOT, 'bench.py')).read()
     assert "'dtype': 'f32'" in src
 
