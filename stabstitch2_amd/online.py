@@ -20,6 +20,8 @@ captured ONCE into a HIP graph (state lives in static tensors: the rings are shi
 two input copies + one graph launch: the Python / ctypes launch overhead (~1 ms per pair, more than the kernels'
 own time at batch 1) disappears.  `use_graph=False` runs the same code eagerly.
 """
+import time
+
 import torch
 
 from . import layers as L
@@ -432,6 +434,10 @@ class OnlineStitcher:
         return [self._render(hr1, hr2, m1[-1:], m2[-1:])]
 
 
+PIPE_STREAM_CANDIDATES = 5        # streams tried pairwise by _TwoInFlight._pick_streams
+PIPE_PROBE_PUSHES = 8
+
+
 class _TwoInFlight:
     """Mixin: the steady-state push as two halves on two HIP streams, two pushes in flight (PipelinedOnlineStitcher,
     PipelinedMultiOnlineStitcher).  A batch-1 push is a dependent chain of ~80 small launches that leaves most of the chip idle
@@ -478,28 +484,18 @@ class _TwoInFlight:
             t.copy_(v)
         torch.cuda.synchronize(self.dev)
 
-    def _push_pipelined(self, *inputs):
-        if self.pipe is None:
-            self.pipe = dict(self._pipe_alloc(), sa=torch.cuda.Stream(self.dev), sb=torch.cuda.Stream(self.dev),
-                             ga=[None, None], gb=[None, None], eB=[None, None])
-        if self.trunk_pair is not None and self.trunk_versions != self._versions():
-            # a net was reloaded / moved: the twin trunk and ALL four graphs hold the old weights by address -- drain, recapture
-            torch.cuda.synchronize(self.dev)
-            self.trunk_pair = None
-            self.pipe['ga'] = [None, None]
-            self.pipe['gb'] = [None, None]
-        P, p = self.pipe, self._t & 1
+    def _enqueue(self, p, sa, sb, load=None):
+        """One push's two halves behind the events that order them; -> the event behind the second half."""
+        P = self.pipe
         cur = torch.cuda.current_stream(self.dev)
         ev_in = torch.cuda.Event()
         ev_in.record(cur)
-        sa, sb = P['sa'], P['sb']
         sa.wait_event(ev_in)
         sb.wait_event(ev_in)
         if P['eB'][p] is not None:
             sa.wait_event(P['eB'][p])                # the second half of push t - 2 has read this parity's hand-over buffers
-        self._pipe_load(p, sa, sb, *inputs)
-        if P['ga'][p] is None:
-            self._capture_pipe()
+        if load is not None:
+            load()
         with torch.cuda.stream(sa):
             P['ga'][p].replay()
             ea = torch.cuda.Event()
@@ -507,6 +503,67 @@ class _TwoInFlight:
         with torch.cuda.stream(sb):
             sb.wait_event(ea)
             P['gb'][p].replay()
+            eb = torch.cuda.Event()
+            eb.record(sb)
+        P['eB'][p] = eb
+        return eb
+
+    def _pick_streams(self):
+        """Choose the two streams by measurement.  Which hardware queue (and which of the command processor's pipes) a HIP stream
+        lands on is the runtime's choice -- round-robin over GPU_MAX_HW_QUEUES by creation order, so it depends on every stream the
+        process has made before -- and two streams that share a queue, or whose queues the firmware serves from one pipe, turn the
+        0.89 ms three-view push into 1.3 - 4 ms (LAB_NOTES R6.5; priorities do not help).  The graphs replay on any stream, so: make
+        PIPE_STREAM_CANDIDATES streams, replay the captured halves with the push's own event pattern on every pair, keep the fastest
+        pair, restore the state the replays advanced.  ~0.1 s, once."""
+        state = self._pipe_state()
+        keep = [t.clone() for t in state]
+        cands = [torch.cuda.Stream(self.dev) for _ in range(PIPE_STREAM_CANDIDATES)]
+        cur = torch.cuda.current_stream(self.dev)
+        best, self.stream_probe_ms = None, []
+        for i, sa in enumerate(cands):
+            for sb in cands[i + 1:]:
+                ms = None
+                for pushes in (2, PIPE_PROBE_PUSHES):        # the first pass pages the graphs onto the streams
+                    self.pipe['eB'] = [None, None]
+                    torch.cuda.synchronize(self.dev)
+                    t0 = time.perf_counter()
+                    prev = None
+                    for t in range(pushes):
+                        eb = self._enqueue(t & 1, sa, sb)
+                        if prev is not None:
+                            cur.wait_event(prev)
+                        prev = eb
+                    torch.cuda.synchronize(self.dev)
+                    ms = (time.perf_counter() - t0) / pushes * 1e3
+                self.stream_probe_ms.append(round(ms, 4))
+                if best is None or ms < best[0]:
+                    best = (ms, sa, sb)
+        self.pipe['eB'] = [None, None]
+        for t, v in zip(state, keep):
+            t.copy_(v)
+        torch.cuda.synchronize(self.dev)
+        self.pipe['sa'], self.pipe['sb'] = best[1], best[2]
+
+    def _push_pipelined(self, *inputs):
+        if self.pipe is None:
+            self.pipe = dict(self._pipe_alloc(), sa=None, sb=None, ga=[None, None], gb=[None, None], eB=[None, None])
+        if self.trunk_pair is not None and self.trunk_versions != self._versions():
+            # a net was reloaded / moved: the twin trunk and ALL four graphs hold the old weights by address -- drain, recapture
+            torch.cuda.synchronize(self.dev)
+            self.trunk_pair = None
+            self.pipe['ga'] = [None, None]
+            self.pipe['gb'] = [None, None]
+        P, p = self.pipe, self._t & 1
+        if P['ga'][p] is None:
+            # the capture warm-up reads parity 0's inputs: load them on the caller's stream first
+            cur = torch.cuda.current_stream(self.dev)
+            self._pipe_load(p, cur, cur, *inputs)
+            self._capture_pipe()
+            if P['sa'] is None:
+                self._pick_streams()
+        sa, sb = P['sa'], P['sb']
+        eb = self._enqueue(p, sa, sb, lambda: self._pipe_load(p, sa, sb, *inputs))
+        with torch.cuda.stream(sb):
             result = self._pipe_take(p)
             eb = torch.cuda.Event()
             eb.record(sb)

@@ -366,6 +366,37 @@ def test_pipelined_three_view_stream_equals_the_plain_one(dev, hip_nets):
         assert pipe.overflow_report() == plain.overflow_report()
 
 
+def test_pipelined_stitcher_measures_its_stream_pair(dev, hip_nets):
+    """Which hardware queue a HIP stream lands on depends on every stream the process made before, and an unlucky pair turns the
+    pipelined push 1.5 - 4x slower (LAB_NOTES R6.5).  _TwoInFlight._pick_streams tries PIPE_STREAM_CANDIDATES streams pairwise on
+    the captured halves and keeps the fastest pair: stitchers built after 0 .. 5 further streams exist all run at the same rate, and
+    the probe leaves the stream state untouched (frames equal to the plain stitcher's are checked by the tests above)."""
+    import time
+    from stabstitch2_amd import online
+    from stabstitch2_amd.online import PipelinedThreeViewOnlineStitcher
+    n, h, w = 16, 360, 640
+    hr, lr = synth.make_clip_device(n, h, w, seed=2, views=3, device=dev)
+    rates, dummies = [], []
+    for k in range(6):
+        st = PipelinedThreeViewOnlineStitcher(hip_nets, h, w)
+        push = lambda i: st.push(hr[0][i:i + 1], hr[1][i:i + 1], hr[2][i:i + 1], lr[0][i:i + 1], lr[1][i:i + 1], lr[2][i:i + 1])
+        for t in range(12):
+            push(t % n)
+        torch.cuda.synchronize()
+        c = online.PIPE_STREAM_CANDIDATES
+        assert len(st.stream_probe_ms) == c * (c - 1) // 2
+        t0 = time.perf_counter()
+        for t in range(60):
+            push(t % n)
+        torch.cuda.synchronize()
+        rates.append((time.perf_counter() - t0) / 60 * 1e3)
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            torch.zeros(1, device=dev)
+        dummies.append(s)
+    assert max(rates) < 1.25 * min(rates), rates
+
+
 @pytest.mark.parametrize('shape', [(64, 64, 90, 120, 24), (128, 128, 45, 60, 40), (256, 256, 23, 30, 48), (16, 64, 45, 60, 40),
                                    (64, 64, 37, 61, 33)])
 def test_wino43_persistent_workgroups_are_output_neutral(dev, shape):
