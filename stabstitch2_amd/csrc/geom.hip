@@ -258,13 +258,207 @@ extern "C" int ss_homo_warp_nchw(const float* in, const float* theta, float* out
 // TPS: 66x66 system [[P,R],[0,P^T]] assembled in fp32 as the reference does, solved in fp64.
 #define TPS_LD 68
 #define TPS_TQ 17        // columns per thread: 4 x 17 = 66 system columns + 2 right-hand sides
+// Round 6: one workgroup of TPS_NW waves per system; wave q owns columns TPS_CPW q .. TPS_CPW q + TPS_CPW - 1 of ALL rows, lane l
+// holds row l (`lo`) and lanes 0, 1 rows 64, 65 as well (`hi`).  Gauss-Jordan with the pivot rule and the arithmetic of the round-4
+// kernel below (same pivots, same factors; the update is an fma now), but a step costs ONE barrier, no row travels through LDS, and
+// the pivot search runs under the previous step's update:
+//   * the wave that owns the NEXT column updates that column first, finds its pivot (keys of 66 rows: 4 DPP rotations + 4
+//     readlanes), divides once and publishes the 66 factors f = A[r][col] / pivot lane-aligned (8 bytes per lane, double-buffered by
+//     step parity) with the pivot's row index -- and only then updates its other columns, while the other waves are still busy with
+//     theirs;
+//   * behind the barrier every wave fetches ITS entries of the pivot row from its own registers (`v_readlane`, the lane is
+//     wave-uniform) and updates the columns that are still live: none in the waves left of the pivot column, the ones right of it
+//     in the owner (columns left of the pivot are unit columns: never read again).
+// Round 4 (thread = (row, column quarter), 5 waves): key reduction -> barrier -> pivot row + 1 / pivot through LDS -> barrier ->
+// update: 47.5 us per launch back to back, 49.6 us cold; this form 39.9 / 44.1 us (tools/ab_tps_solve.py); LAB_NOTES R6.6 has the
+// anatomy and why it is not 2x: broadcasting a pivot-row entry costs as much as five fp64 fmas, whichever way it travels.
+// src_stride = 0 shares one source mesh across the batch.
+#ifndef TPS_NW
+#define TPS_NW 4
+#endif
+#define TPS_CPW ((68 + TPS_NW - 1) / TPS_NW)           // columns per wave: 66 system columns + 2 right-hand sides (+ padding)
+#define TPS_RHS (SS_NT - (TPS_NW - 1) * TPS_CPW)       // local index of the first right-hand side in the last wave
+
+__device__ __forceinline__ double tps_entry(int r, int c, const float* sx, const float* sy, const float* tgt) {
+    if (c >= SS_NT + 2) return 0.0;
+    if (r < SS_NV) {
+        if (c == 0) return 1.0;
+        if (c == 1) return (double)sx[r];
+        if (c == 2) return (double)sy[r];
+        if (c < SS_NT) {
+            // fp32 kernel entries like the reference, but with a correctly rounded log (via fp64): the
+            // 66x66 system amplifies last-bit differences of logf ~100x into T (measured 3e-5 on |T|<2)
+            float dx = __fsub_rn(sx[r], sx[c - 3]), dy = __fsub_rn(sy[r], sy[c - 3]);
+            float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            return (double)__fmul_rn(d2, (float)log((double)__fadd_rn(d2, 1e-6f)));
+        }
+        return (double)tgt[r * 2 + (c - SS_NT)];
+    }
+    return (c >= 3 && c < SS_NT) ? 1.0 : 0.0;            // row 63: the ones row of P^T
+}
+
+__device__ __forceinline__ double tps_readlane(double v, int l) {
+    const long long bits = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ unsigned tps_key(double v, int r) {
+    // top 25 bits of the fp64 magnitude (11 exponent + 14 mantissa bits: monotone in |v| over the whole range) above 127 - row:
+    // a maximum carries its row.  RELAXED partial pivoting: the largest candidate up to a relative 2^-14, the lowest row among
+    // candidates that close; tests/test_gpu_round4.py checks residuals on near-degenerate control points against an fp64 solve
+    return ((unsigned)((unsigned long long)__double_as_longlong(fabs(v)) >> 38) << 7) | (unsigned)(127 - r);
+}
+
+struct TpsShared {
+    float sx[SS_NV], sy[SS_NV];
+    double fx[2][2][64];          // [step parity][lo / hi][lane]
+    int piv[2];                   // pivot lane | 64 when the pivot row sits in `hi` of that lane (the waves swap it into `lo`)
+    double diag[SS_NT];           // pivot value by COLUMN
+};
+
+// pivot of column `col`, held in (cl, ch), among the unused rows; publishes the factors (as they are AFTER the pivot lane's
+// lo / hi exchange, if there is one), the pivot lane and the pivot value for step parity `slot`, and hands them to the caller
+// (the wave that searches a column is the one that uses the result first: no LDS round trip on its own chain).
+// The reciprocals of BOTH candidates of every lane are formed beside the key reduction (the division's ~15 dependent fp64
+// instructions are the longest chain of the search; forming only `lo`'s and dividing again for rows 64, 65 measured slower);
+// the pivot's is fetched once the lane is known.
+__device__ __forceinline__ void tps_search(TpsShared& sh, int slot, int col, int lane, double cl, double ch, int rid_lo, int rid_hi,
+                                           bool used_lo, bool used_hi, int& pcode, double& f0, double& f1) {
+    const double r0 = 1.0 / cl, r1 = 1.0 / ch;
+    unsigned key = max(used_lo ? 0u : tps_key(cl, rid_lo), used_hi ? 0u : tps_key(ch, rid_hi));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x121, 0xF, 0xF, false));   // row_ror:1
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x122, 0xF, 0xF, false));   // row_ror:2
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x124, 0xF, 0xF, false));   // row_ror:4
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x128, 0xF, 0xF, false));   // row_ror:8
+    const unsigned k0 = __builtin_amdgcn_readlane((int)key, 0), k1 = __builtin_amdgcn_readlane((int)key, 16);
+    const unsigned k2 = __builtin_amdgcn_readlane((int)key, 32), k3 = __builtin_amdgcn_readlane((int)key, 48);
+    const int prow = 127 - (int)(max(max(k0, k1), max(k2, k3)) & 127u);         // the pivot's ROW
+    // the lane that holds it: rows 0..63 start in lane = row, rows 64, 65 in lanes 0, 1 -- and they only ever trade places
+    // with the other row of their lane
+    const unsigned long long in_lo = __ballot(rid_lo == prow), in_hi = __ballot(rid_hi == prow);
+    const bool inhi = in_lo == 0ull;
+    const int pl = __builtin_ctzll(inhi ? in_hi : in_lo);
+    const double pinv = tps_readlane(inhi ? r1 : r0, pl);
+    f0 = cl * pinv;
+    f1 = ch * pinv;
+    if (lane == pl) {
+        sh.diag[col] = inhi ? ch : cl;
+        if (inhi) f1 = f0;
+        f0 = 0.0;                                                 // the pivot row (in `lo` after the exchange) stays as it is
+    }
+    if (lane >= 2) f1 = 0.0;
+    pcode = pl | (inhi ? 64 : 0);
+    sh.fx[slot][0][lane] = f0;
+    if (lane < 2) sh.fx[slot][1][lane] = f1;
+    if (lane == 0) sh.piv[slot] = pcode;
+}
+
+__global__ __launch_bounds__(64 * TPS_NW) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
+                                                               const float* __restrict__ target, long long tgt_stride,
+                                                               float* __restrict__ T) {
+    __shared__ TpsShared sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* src = source + (long long)b * src_stride;
+    const float* tgt = target + (long long)b * tgt_stride;
+    if (tid < SS_NV) { sh.sx[tid] = src[tid * 2]; sh.sy[tid] = src[tid * 2 + 1]; }
+    __syncthreads();
+    double lo[TPS_CPW], hi[TPS_CPW];
+#pragma unroll
+    for (int j = 0; j < TPS_CPW; ++j) {
+        const int c = q * TPS_CPW + j;
+        lo[j] = tps_entry(lane, c, sh.sx, sh.sy, tgt);
+        double bottom = 0.0;                  // rows 64, 65 = the x / y rows of P^T
+        if (lane < 2 && c >= 3 && c < SS_NT) bottom = (double)(lane == 0 ? sh.sx[c - 3] : sh.sy[c - 3]);
+        hi[j] = bottom;
+    }
+    int rid_lo = lane, rid_hi = 64 + lane;
+    bool used_lo = false, used_hi = lane >= 2;
+    int col_lo = 0, col_hi = 0;
+    int my_pcode = 0;                    // the result of this wave's last search
+    double my_f0 = 0.0, my_f1 = 0.0;
+    if (q == 0) tps_search(sh, 0, 0, lane, lo[0], hi[0], rid_lo, rid_hi, used_lo, used_hi, my_pcode, my_f0, my_f1);
+#define TPS_UPD(jj_) do { const double pr_ = tps_readlane(lo[jj_], pl); \
+                          lo[jj_] = fma(-f0, pr_, lo[jj_]); hi[jj_] = fma(-f1, pr_, hi[jj_]); } while (0)
+    for (int qq = 0; qq < TPS_NW; ++qq) {         // rolled on purpose (all 66 steps in one straight-line body: instruction-cache bound)
+#pragma unroll
+        for (int j = 0; j < TPS_CPW; ++j) {
+            const int col = qq * TPS_CPW + j;
+            if (col < SS_NT) {
+                const int slot = col & 1;
+                __syncthreads();
+                int pcode;
+                double f0, f1;
+                if (q == qq) { pcode = my_pcode; f0 = my_f0; f1 = my_f1; }      // this wave searched column `col` itself
+                else {
+                    pcode = __builtin_amdgcn_readfirstlane(sh.piv[slot]);
+                    f0 = sh.fx[slot][0][lane];
+                    f1 = lane < 2 ? sh.fx[slot][1][lane & 1] : 0.0;
+                }
+                const int pl = pcode & 63;
+                if (pcode & 64) {          // rows 64, 65 become pivots once each: they move into `lo` of their lane
+                    if (lane == pl) {
+#pragma unroll
+                        for (int jj = 0; jj < TPS_CPW; ++jj) { const double t_ = lo[jj]; lo[jj] = hi[jj]; hi[jj] = t_; }
+                        const int r_ = rid_lo; rid_lo = rid_hi; rid_hi = r_;
+                        const bool u_ = used_lo; used_lo = used_hi; used_hi = u_;
+                        const int c_ = col_lo; col_lo = col_hi; col_hi = c_;
+                    }
+                }
+                if (lane == pl) { used_lo = true; col_lo = col; }
+                if (j + 1 < TPS_CPW) {
+                    // the next pivot column is this wave's column j + 1 (the owner) or nobody's business yet
+                    if (q == qq) {
+                        const int jn = j + 1 < TPS_CPW ? j + 1 : 0;
+                        TPS_UPD(jn);
+                        if (col + 1 < SS_NT) tps_search(sh, slot ^ 1, col + 1, lane, lo[jn], hi[jn], rid_lo, rid_hi, used_lo, used_hi, my_pcode, my_f0, my_f1);
+#pragma unroll
+                        for (int jj = 0; jj < TPS_CPW; ++jj) if (jj >= j + 2) TPS_UPD(jj);
+                    } else if (q > qq) {
+#pragma unroll
+                        for (int jj = 0; jj < TPS_CPW; ++jj) TPS_UPD(jj);
+                    }
+                } else {
+                    // last column of wave qq: wave qq + 1 owns the next one
+                    if (q == qq + 1) {
+                        TPS_UPD(0);
+                        if (col + 1 < SS_NT) tps_search(sh, slot ^ 1, col + 1, lane, lo[0], hi[0], rid_lo, rid_hi, used_lo, used_hi, my_pcode, my_f0, my_f1);
+#pragma unroll
+                        for (int jj = 0; jj < TPS_CPW; ++jj) if (jj >= 1) TPS_UPD(jj);
+                    } else if (q > qq) {
+#pragma unroll
+                        for (int jj = 0; jj < TPS_CPW; ++jj) TPS_UPD(jj);
+                    }
+                }
+            }
+        }
+    }
+#undef TPS_UPD
+    __syncthreads();
+    if (q == TPS_NW - 1) {     // right-hand sides are columns 66, 67
+        float* t = T + (long long)b * 2 * SS_NT;
+        const double d0 = sh.diag[col_lo];
+        t[col_lo] = (float)(lo[TPS_RHS] / d0);
+        t[SS_NT + col_lo] = (float)(lo[TPS_RHS + 1] / d0);
+        if (lane < 2) {
+            const double d1 = sh.diag[col_hi];
+            t[col_hi] = (float)(hi[TPS_RHS] / d1);
+            t[SS_NT + col_hi] = (float)(hi[TPS_RHS + 1] / d1);
+        }
+    }
+}
+
+#ifdef SS_TUNING
+// The round-4 kernel (A/B and bit-identity checks: tools/ab_tps_solve.py; tuning build only).
 // One workgroup of 320 threads per system, the augmented 66x68 matrix lives in REGISTERS: thread (r, q) = (tid>>2,
 // tid&3) owns columns 17q..17q+16 of row r.  Gauss-Jordan with partial pivoting and no physical row swaps (a used-row
 // flag instead); per column: pivot = the unused row with the largest |A[r][col]| (wave-level DPP reduction, see below) ->
 // pivot row (and 1 / pivot) broadcast through LDS -> every row subtracts f * pivot_row with f fetched from its 4-lane
 // row group by a shuffle.  All register indices are static (steps unrolled per 17-column quarter); two barriers per
 // step.  src_stride = 0 shares one source mesh across the batch.
-__global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
+__global__ __launch_bounds__(320) void tps_solve_r4_kernel(const float* __restrict__ source, long long src_stride,
                                                         const float* __restrict__ target, long long tgt_stride,
                                                         float* __restrict__ T) {
     __shared__ float sx[SS_NV], sy[SS_NV];
@@ -358,9 +552,17 @@ __global__ __launch_bounds__(320) void tps_solve_kernel(const float* __restrict_
     }
 }
 
+extern "C" __attribute__((visibility("default"))) int ss_tps_solve_r4(const float* source, const float* target, float* T, int n, void* stream) {
+    if (!source || !target || !T || n <= 0) return SS_ERR_ARG;
+    hipLaunchKernelGGL(tps_solve_r4_kernel, dim3(n), dim3(320), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
+                       target, (long long)SS_NV * 2, T);
+    return ss_launch_status();
+}
+#endif
+
 extern "C" int ss_tps_solve(const float* source, const float* target, float* T, int n, void* stream) {
     if (!source || !target || !T || n <= 0) return SS_ERR_ARG;
-    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(64 * TPS_NW), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
                        target, (long long)SS_NV * 2, T);
     return ss_launch_status();
 }
@@ -369,7 +571,7 @@ extern "C" int ss_tps_solve(const float* source, const float* target, float* T, 
 // onto the same rigid mesh, test_online_tra.py:129-137) -- no [n,63,2] broadcast copy of the target
 extern "C" int ss_tps_solve_shared_target(const float* source, const float* target, float* T, int n, void* stream) {
     if (!source || !target || !T || n <= 0) return SS_ERR_ARG;
-    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(64 * TPS_NW), 0, (hipStream_t)stream, source, (long long)SS_NV * 2,
                        target, 0ll, T);
     return ss_launch_status();
 }
@@ -621,7 +823,7 @@ extern "C" int ss_tsmotion_lag(const float* smotion, const float* tmotion, float
     float* ntgt = ws + 126;
     float* T = ntgt + (long long)n * 252;
     if (!rigid_winv)
-        hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(320), 0, st, (const float*)ws, 0ll, (const float*)ntgt, (long long)SS_NV * 2, T);
+        hipLaunchKernelGGL(tps_solve_kernel, dim3(n), dim3(64 * TPS_NW), 0, st, (const float*)ws, 0ll, (const float*)ntgt, (long long)SS_NV * 2, T);
     hipLaunchKernelGGL(tsm_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)ws, (const float*)smesh, rigid_winv,
                        tsmotion, n, img_h, img_w, lag);
     return ss_launch_status();

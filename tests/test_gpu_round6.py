@@ -397,6 +397,65 @@ def test_pipelined_stitcher_measures_its_stream_pair(dev, hip_nets):
     assert max(rates) < 1.25 * min(rates), rates
 
 
+def test_tps_solve_round6_kernel_against_round4(dev, request):
+    """tps_solve_kernel of round 6 (four waves, lane = row, one barrier per column, pivot search under the previous update) against
+    the round-4 kernel kept in the tuning build (`ss_tps_solve_r4`): same pivot rule and factors, the update an fma instead of
+    mul + sub -- T agrees to 1e-6 of max |T| (bit for bit on ordinary meshes), on clip-like, strongly deformed and near-degenerate
+    control points (two pairs of points 1e-4 / 1e-5 apart: |T| ~ 1e7), with per-system and shared targets; residual of the fp64
+    system on the deformed set."""
+    import ctypes
+    import importlib.util
+    from stabstitch2_amd import _hip, ops
+    spec = importlib.util.spec_from_file_location('_tuning', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'tools', '_tuning.py'))
+    tuning = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tuning)
+    product = _hip.lib()
+    request.addfinalizer(lambda: setattr(_hip, '_lib', product))
+    lib = tuning.lib()
+    _hip._lib = product
+    lib.ss_tps_solve_r4.restype = ctypes.c_int
+    lib.ss_tps_solve_r4.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]
+    g = torch.Generator().manual_seed(11)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, 7), torch.linspace(-1, 1, 9), indexing='ij')
+    rigid = torch.stack([xs, ys], -1).reshape(1, 63, 2)
+    n = 48
+    sets = {'clip': rigid + 0.05 * torch.randn((n, 63, 2), generator=g), 'deformed': rigid + 0.4 * torch.randn((n, 63, 2), generator=g)}
+    deg = rigid.repeat(n, 1, 1).clone()
+    deg[:, 1] = deg[:, 0] + 1e-4 * torch.randn((n, 2), generator=g)
+    deg[:, 40] = deg[:, 41] + 1e-5
+    sets['degenerate'] = deg
+    for name, src in sets.items():
+        src = src.to(dev).contiguous()
+        tgt = (rigid.repeat(n, 1, 1) + 0.02 * torch.randn((n, 63, 2), generator=g)).to(dev).contiguous()
+        new = ops.tps_solve(src, tgt)
+        old = torch.empty_like(new)
+        rc = lib.ss_tps_solve_r4(src.data_ptr(), tgt.data_ptr(), old.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(new).all(), name
+        assert float((new - old).abs().max()) <= 1e-6 * float(old.abs().max()), name
+        if name != 'degenerate':
+            assert torch.equal(new, old), name
+    # residual: A [a; w] = [Y; 0] in fp64 with the kernel's own fp32 entries
+    src = sets['deformed'][:4].double()
+    tgt = rigid.repeat(4, 1, 1).double()
+    T = ops.tps_solve(src.float().to(dev).contiguous(), tgt.float().to(dev).contiguous()).double().cpu()     # [4,2,66]
+    for i in range(4):
+        s32 = src[i].float()
+        d2 = ((s32[:, None, :] - s32[None, :, :]) ** 2).sum(-1)
+        K = (d2 * torch.log((d2 + torch.tensor(1e-6, dtype=torch.float32)).double()).float()).double()
+        P = torch.cat([torch.ones(63, 1, dtype=torch.float64), s32.double()], 1)
+        A = torch.zeros((66, 66), dtype=torch.float64)
+        A[:63, :3] = P
+        A[:63, 3:] = K
+        A[63:, 3:] = P.t()
+        Y = torch.zeros((66, 2), dtype=torch.float64)
+        Y[:63] = tgt[i]
+        ref = torch.linalg.solve(A, Y)
+        assert float((T[i].t() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize('shape', [(64, 64, 90, 120, 24), (128, 128, 45, 60, 40), (256, 256, 23, 30, 48), (16, 64, 45, 60, 40),
                                    (64, 64, 37, 61, 33)])
 def test_wino43_persistent_workgroups_are_output_neutral(dev, shape):
