@@ -219,6 +219,11 @@ SS_API int ss_spatial_meshes(const float* offset8, const float* off_ref, const f
  * theta [n][3][3]; nhwc variant for the 1/8 feature maps, nchw variant = the reference API. */
 SS_API int ss_homo_warp_nhwc(const float* in, const float* theta, float* out, int n, int h, int w, int c,
                       int out_h, int out_w, void* stream);
+/* (warp(in1, theta[0:n]), warp(in2, theta[n:2n])) -> out [2n][out_h][out_w][c] as ONE launch.  in1 and in2 are images of ONE
+ * NHWC tensor a whole number of images apart and may overlap: a chain of pairs (view 1, view 2), (view 2, view 3) reads views
+ * [0:n] and [1:n+1] of its trunk output (spatial_network.py:302-318 per pair).  SS_ERR_ARG when in2 - in1 is not that. */
+SS_API int ss_homo_warp_pair_nhwc(const float* in1, const float* in2, const float* theta, float* out, int n, int h, int w, int c,
+                                  int out_h, int out_w, void* stream);
 SS_API int ss_homo_warp_nchw(const float* in, const float* theta, float* out, int n, int c, int h, int w,
                       int out_h, int out_w, void* stream);
 
@@ -299,6 +304,11 @@ SS_API int ss_render_average_clip_u8(const unsigned char* const* views_base, con
 SS_API long long ss_render_footprint_floats(int views, int hc, int wc);
 SS_API int ss_render_footprints(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
                                 int hc, int wc, void* stream);
+/* ss_render_footprints + the streaming canvas' overflow watcher inside the same launches: ss_canvas_watch's update of
+ * watch_i / watch_f [frames][4] from `source` (frame = stream), for pushes that normalise their control points elsewhere
+ * (ss_three_view_splines).  One graph node less on a batch-1 push. */
+SS_API int ss_render_footprints_watch(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
+                                      int hc, int wc, float guard, int* watch_i, float* watch_f, void* stream);
 /* LINEAR fusion (linear_blender): ref, tgt [3][hc][wc]; ref_m, tgt_m [hc][wc]; out [3][hc][wc];
  * mask1_out optional [hc][wc]; ws: ss_linear_blend_workspace_floats(hc, wc) floats. */
 SS_API long long ss_linear_blend_workspace_floats(int hc, int wc);
@@ -353,6 +363,18 @@ SS_API int ss_three_view_normalize(const float* a1, const float* a2, const float
                             const float* bbox, float* out, long long n_points, void* stream);
 SS_API int ss_three_view_finish(const float* n1, const float* n3, const float* mid, const float* bbox, float* mesh1,
                          float* middle, float* mesh3, long long n_points, void* stream);
+/* The streaming three-view push between the pair chains' smoothed meshes and the render (test_online_tra_threeview.py:345-420 +
+ * the splines of :421-505) as ONE launch of 3 workgroups per frame: ss_three_view_align -> ss_three_view_normalize ->
+ * ss_tps_solve -> ss_tps_points -> ss_three_view_finish on the FIRST canvas `first_box`, then every view's final mesh normalised
+ * on the OUTPUT canvas `out_box` (ss_stream_normalize_watch's arithmetic) and ss_tps_solve_shared_target onto `nrigid` [63][2].
+ * Same device functions in the same order: bit-identical to those seven launches.  w*_m*: [frames][63][2] at LR scale, frame f
+ * at + f * mesh_frame_stride floats; boxes: device (wmin, wmax, hmin, hmax); -> mesh1 / middle / mesh3 [frames][63][2] in
+ * first-canvas pixels, src [frames][3][63][2], T [frames][3][2][66].  The watcher is NOT updated here: ss_render_footprints_watch
+ * or ss_canvas_watch on `src`. */
+SS_API int ss_three_view_splines(const float* w12_m1, const float* w12_m2, const float* w23_m1, const float* w23_m2,
+                                 long long mesh_frame_stride, const float* first_box, const float* out_box, const float* nrigid,
+                                 float* mesh1, float* middle, float* mesh3, float* src, float* T, int frames, float img_h,
+                                 float img_w, void* stream);
 /* Streaming mode (stabstitch2_amd/online.py): the reference sizes the canvas from ALL frames of the clip (test_online_tra.py:
  * 106-120); a live stream fixes it after its first window, so a mesh that drifts past it later would be cropped silently.  This
  * launch (one wave per stream, capturable) looks at the push's control points src [streams][views][63][2], already normalised to

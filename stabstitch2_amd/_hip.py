@@ -58,6 +58,7 @@ SIGNATURES = {
     'ss_spatial_decompose': (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
     'ss_spatial_meshes': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
     'ss_homo_warp_nhwc': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    'ss_homo_warp_pair_nhwc': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_homo_warp_nchw': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_tps_solve': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
     'ss_tps_solve_shared_target': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     'ss_render_average_clip_u8': (c_i, [ctypes.POINTER(c_fp), c_fp, c_fp, c_fp, c_ll, c_fp] + [c_i] * 7 + [c_st]),
     'ss_render_footprint_floats': (c_ll, [c_i, c_i, c_i]),
     'ss_render_footprints': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_st]),
+    'ss_render_footprints_watch': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_f, c_fp, c_fp, c_st]),
     'ss_linear_blend_workspace_floats': (c_ll, [c_i, c_i]),
     'ss_linear_blend': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_st]),
     'ss_linear_clip_workspace_floats': (c_ll, [c_i, c_i, c_i, c_i]),
@@ -95,6 +97,7 @@ SIGNATURES = {
     'ss_h2mesh': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_st]),
     'ss_three_view_align': (c_i, [c_fp] * 9 + [c_i, c_f, c_f, c_st]),
     'ss_three_view_finish': (c_i, [c_fp] * 7 + [c_ll, c_st]),
+    'ss_three_view_splines': (c_i, [c_fp] * 4 + [c_ll] + [c_fp] * 8 + [c_i, c_f, c_f, c_st]),
     'ss_three_view_normalize': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_st]),
     'ss_smooth_embed': (c_i, [c_fp] * 9 + [c_i] * 4 + [c_st]),
     'ss_smooth_finalize': (c_i, [c_fp] * 13 + [c_i] * 4 + [c_st]),

@@ -64,6 +64,29 @@ __device__ __forceinline__ float ss_wave_min(float v) {
     return v;
 }
 
+// overflow watcher of a streaming canvas (geom.hip: ss_canvas_watch has the state's layout); used by geom.hip and render.hip
+__device__ __forceinline__ void canvas_watch_update(float xmin, float xmax, float ymin, float ymax, bool bad, float guard, int* wi,
+                                                    float* wf) {
+    xmin = ss_wave_min(xmin); xmax = ss_wave_max(xmax); ymin = ss_wave_min(ymin); ymax = ss_wave_max(ymax);
+    // fminf / fmaxf drop a NaN operand: a NaN control point would vanish from the extremes, so it is carried as a flag of its own
+    const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+    if (threadIdx.x == 0) {
+        const float lo = fminf(xmin, ymin), hi = fmaxf(xmax, ymax);
+        const int seen = wi[0];
+        // (half a pixel of a 4096-wide canvas: the canvas is the first window's OWN bbox when margin = 0, its extremes sit on +-1;
+        // `near` gets the same slack when the guard is smaller than it, else fp32 rounding alone would ask for a growth)
+        const float slack = 2.5e-4f;
+        const bool out = anybad || lo < -1.0f - slack || hi > 1.0f + slack;
+        const float g = guard > slack ? guard : -slack;
+        const bool near = out || lo < -1.0f + g || hi > 1.0f - g;
+        if (out) { wi[1] += 1; if (wi[2] < 0) wi[2] = seen; }
+        if (near) wi[3] += 1;
+        wi[0] = seen + 1;
+        wf[0] = fminf(wf[0], xmin); wf[1] = fmaxf(wf[1], xmax); wf[2] = fminf(wf[2], ymin); wf[3] = fmaxf(wf[3], ymax);
+    }
+}
+
+
 #ifdef SS_TUNING
 // tools/ build only: buffer for per-workgroup s_memtime stamps (set through ss_debug_ptr, conv.hip)
 extern unsigned long long* ss_tuning_dbg;

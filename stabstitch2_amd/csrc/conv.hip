@@ -570,6 +570,11 @@ static void launch_auto(const ConvP& p, int groups, hipStream_t st, int taps, bo
 static int conv_splits(long long M, int cout, int groups, int nk) {
     long long b64 = (long long)ss_cdiv(M, 64) * ss_cdiv(cout, 64) * groups;
     int want = (int)((g_split_target + b64 - 1) / b64);
+    // (round 6) a launch with a SHORT K that already has 0.6 of the target gains little from a two-way cut and pays a reduction pass
+    // over its whole output for it: twin-trunk layer2 head (K = 576) on 3 / 2 views, 508 / 340 tiles: 42.6 -> 26.8 us, 33.1 ->
+    // 24.4 us without the cut (tools/ab_splitk_stream.py).  Long K keeps it (SmoothNet's 3-D convolutions of a clip, K = 3456, 442
+    // tiles: the clip's implicit-GEMM launches lose 12 % without); rounding the quotient down everywhere loses the same.
+    if (want == 2 && nk < 32 && b64 * 5 >= (long long)g_split_target * 3) want = 1;
     int maxs = nk / 4 > 0 ? nk / 4 : 1;
     int splits = want < maxs ? want : maxs;
     if (splits <= 1) return 1;

@@ -408,10 +408,16 @@ extern "C" int ss_ccl(const float* f1, const float* f2, float* flow_nchw, float*
     float* n2 = n1 + (long long)n * P * c;
     float* Dm = n2 + (long long)n * P * c;
     long long npix = (long long)n * P;
-    if (f2 == f1 + npix * c) {
+    const long long gap = f2 - f1, img = (long long)P * c;
+    if (gap == npix * c) {
         // the two views' maps are the halves of one tensor (SpatialNet's trunk output, view 1 first) and n1 / n2 are adjacent in
         // the workspace: one launch normalises both (a batch-1 push pays per launch)
         hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(2 * npix, 4)), dim3(256), 0, st, f1, n1, 2 * npix, c);
+    } else if (gap > 0 && gap < npix * c && gap % img == 0) {
+        // the batches OVERLAP (a chain of pairs: f1 = views [0:n], f2 = views [k:k+n] of one tensor): every view once, one launch
+        const long long k = gap / img;
+        hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv((n + k) * (long long)P, 4)), dim3(256), 0, st, f1, n1, (n + k) * (long long)P, c);
+        n2 = n1 + gap;
     } else {
         hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(npix, 4)), dim3(256), 0, st, f1, n1, npix, c);
         hipLaunchKernelGGL(l2norm_kernel, dim3(ss_cdiv(npix, 4)), dim3(256), 0, st, f2, n2, npix, c);

@@ -192,8 +192,9 @@ extern "C" int ss_spatial_meshes(const float* offset8, const float* off_ref, con
 // ------------------------------------------------------------------------------------------------
 template <bool NHWC>
 __global__ void homo_warp_kernel(const float* __restrict__ in, const float* __restrict__ theta,
-                                 float* __restrict__ out, int n, int c, int h, int w, int oh, int ow) {
+                                 float* __restrict__ out, int n, int c, int h, int w, int oh, int ow, int split, int shift) {
     // NHWC: thread = (pixel, channel quad); NCHW: thread = (pixel), loops channels
+    // output image b samples input image b + (b >= split ? shift : 0): two batches whose inputs overlap in memory as one launch
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int cq = NHWC ? c / 4 : 1;
     long long total = (long long)n * oh * ow * cq;
@@ -213,7 +214,8 @@ __global__ void homo_warp_kernel(const float* __restrict__ in, const float* __re
     float xn = xs / ts, yn = ys / ts;
     SsTaps t = taps_normal(xn, yn, w, h);
     if (NHWC) {
-        const float4* base = reinterpret_cast<const float4*>(in) + (long long)b * h * w * cq;
+        const int ib = b + (b >= split ? shift : 0);
+        const float4* base = reinterpret_cast<const float4*>(in) + (long long)ib * h * w * cq;
         float4 a = base[((long long)t.y0 * w + t.x0) * cq + q];
         float4 bb = base[((long long)t.y1 * w + t.x0) * cq + q];
         float4 cc = base[((long long)t.y0 * w + t.x1) * cq + q];
@@ -227,7 +229,7 @@ __global__ void homo_warp_kernel(const float* __restrict__ in, const float* __re
     } else {
         long long hw = (long long)h * w, ohw = (long long)oh * ow;
         for (int ch = 0; ch < c; ++ch) {
-            const float* pl = in + ((long long)b * c + ch) * hw;
+            const float* pl = in + ((long long)(b + (b >= split ? shift : 0)) * c + ch) * hw;
             float v = blend4(t, pl[(long long)t.y0 * w + t.x0], pl[(long long)t.y1 * w + t.x0],
                              pl[(long long)t.y0 * w + t.x1], pl[(long long)t.y1 * w + t.x1]);
             out[((long long)b * c + ch) * ohw + (long long)y * ow + x] = v;
@@ -241,7 +243,20 @@ extern "C" int ss_homo_warp_nhwc(const float* in, const float* theta, float* out
         return SS_ERR_ARG;
     long long total = (long long)n * out_h * out_w * (c / 4);
     hipLaunchKernelGGL((homo_warp_kernel<true>), dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
-                       theta, out, n, c, h, w, out_h, out_w);
+                       theta, out, n, c, h, w, out_h, out_w, n, 0);
+    return ss_launch_status();
+}
+
+// (warp(in1, theta[0:n]), warp(in2, theta[n:2n])) -> out [2n] as ONE launch; in1 and in2 must be images of ONE tensor a whole
+// number of images apart (they may overlap: a chain of pairs (view 1, view 2), (view 2, view 3) reads views [0:n] and [1:n+1])
+extern "C" int ss_homo_warp_pair_nhwc(const float* in1, const float* in2, const float* theta, float* out, int n, int h, int w, int c,
+                                      int out_h, int out_w, void* stream) {
+    if (!in1 || !in2 || !theta || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || out_h < 2 || out_w < 2) return SS_ERR_ARG;
+    const long long img = (long long)h * w * c, d = in2 - in1;
+    if (d < 0 || d % img != 0 || d / img > (1 << 20)) return SS_ERR_ARG;
+    const long long total = 2ll * n * out_h * out_w * (c / 4);
+    hipLaunchKernelGGL((homo_warp_kernel<true>), dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in1,
+                       theta, out, 2 * n, c, h, w, out_h, out_w, n, (int)(d / img) - n);
     return ss_launch_status();
 }
 
@@ -250,7 +265,7 @@ extern "C" int ss_homo_warp_nchw(const float* in, const float* theta, float* out
     if (!in || !theta || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || out_h < 2 || out_w < 2) return SS_ERR_ARG;
     long long total = (long long)n * out_h * out_w;
     hipLaunchKernelGGL((homo_warp_kernel<false>), dim3(ss_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
-                       theta, out, n, c, h, w, out_h, out_w);
+                       theta, out, n, c, h, w, out_h, out_w, n, 0);
     return ss_launch_status();
 }
 
@@ -355,16 +370,10 @@ __device__ __forceinline__ void tps_search(TpsShared& sh, int slot, int col, int
     if (lane == 0) sh.piv[slot] = pcode;
 }
 
-__global__ __launch_bounds__(64 * TPS_NW) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
-                                                               const float* __restrict__ target, long long tgt_stride,
-                                                               float* __restrict__ T) {
-    __shared__ TpsShared sh;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* src = source + (long long)b * src_stride;
-    const float* tgt = target + (long long)b * tgt_stride;
-    if (tid < SS_NV) { sh.sx[tid] = src[tid * 2]; sh.sy[tid] = src[tid * 2 + 1]; }
-    __syncthreads();
+// The elimination of one system by the 64 * TPS_NW threads of a workgroup: control points in sh.sx / sh.sy (filled and
+// synchronised by the caller), targets tgt [63][2], coefficients to t [2][66] (either may live in LDS: generic pointers).  Ends
+// behind a barrier-free tail: the caller synchronises before it reads t or reuses `sh`.
+__device__ __forceinline__ void tps_eliminate(TpsShared& sh, const float* tgt, float* t, int lane, int q) {
     double lo[TPS_CPW], hi[TPS_CPW];
 #pragma unroll
     for (int j = 0; j < TPS_CPW; ++j) {
@@ -438,7 +447,6 @@ __global__ __launch_bounds__(64 * TPS_NW) void tps_solve_kernel(const float* __r
 #undef TPS_UPD
     __syncthreads();
     if (q == TPS_NW - 1) {     // right-hand sides are columns 66, 67
-        float* t = T + (long long)b * 2 * SS_NT;
         const double d0 = sh.diag[col_lo];
         t[col_lo] = (float)(lo[TPS_RHS] / d0);
         t[SS_NT + col_lo] = (float)(lo[TPS_RHS + 1] / d0);
@@ -448,6 +456,17 @@ __global__ __launch_bounds__(64 * TPS_NW) void tps_solve_kernel(const float* __r
             t[SS_NT + col_hi] = (float)(hi[TPS_RHS + 1] / d1);
         }
     }
+}
+
+__global__ __launch_bounds__(64 * TPS_NW) void tps_solve_kernel(const float* __restrict__ source, long long src_stride,
+                                                               const float* __restrict__ target, long long tgt_stride,
+                                                               float* __restrict__ T) {
+    __shared__ TpsShared sh;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* src = source + (long long)b * src_stride;
+    if (tid < SS_NV) { sh.sx[tid] = src[tid * 2]; sh.sy[tid] = src[tid * 2 + 1]; }
+    __syncthreads();
+    tps_eliminate(sh, target + (long long)b * tgt_stride, T + (long long)b * 2 * SS_NT, tid & 63, __builtin_amdgcn_readfirstlane(tid >> 6));
 }
 
 #ifdef SS_TUNING
@@ -953,27 +972,6 @@ extern "C" int ss_mesh_normalize_views_boxes(const float* mesh, long long mesh_f
 // running {xmin, xmax, ymin, ymax} of the normalised coordinates over all frames seen -- what a grown canvas must cover.  State
 // lives on the device and is only read when somebody asks (no sync on the push path); capturable (one fixed-size launch).
 // (the wave's running extremes, NaN flag OR-ed over the lanes -> the stream's watcher state; lane 0 writes)
-__device__ __forceinline__ void canvas_watch_update(float xmin, float xmax, float ymin, float ymax, bool bad, float guard, int* wi,
-                                                    float* wf) {
-    xmin = ss_wave_min(xmin); xmax = ss_wave_max(xmax); ymin = ss_wave_min(ymin); ymax = ss_wave_max(ymax);
-    // fminf / fmaxf drop a NaN operand: a NaN control point would vanish from the extremes, so it is carried as a flag of its own
-    const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
-    if (threadIdx.x == 0) {
-        const float lo = fminf(xmin, ymin), hi = fmaxf(xmax, ymax);
-        const int seen = wi[0];
-        // (half a pixel of a 4096-wide canvas: the canvas is the first window's OWN bbox when margin = 0, its extremes sit on +-1;
-        // `near` gets the same slack when the guard is smaller than it, else fp32 rounding alone would ask for a growth)
-        const float slack = 2.5e-4f;
-        const bool out = anybad || lo < -1.0f - slack || hi > 1.0f + slack;
-        const float g = guard > slack ? guard : -slack;
-        const bool near = out || lo < -1.0f + g || hi > 1.0f - g;
-        if (out) { wi[1] += 1; if (wi[2] < 0) wi[2] = seen; }
-        if (near) wi[3] += 1;
-        wi[0] = seen + 1;
-        wf[0] = fminf(wf[0], xmin); wf[1] = fmaxf(wf[1], xmax); wf[2] = fminf(wf[2], ymin); wf[3] = fmaxf(wf[3], ymax);
-    }
-}
-
 __global__ __launch_bounds__(64) void canvas_watch_kernel(const float* __restrict__ src, int npts, float guard, int* __restrict__ watch_i,
                                                           float* __restrict__ watch_f) {
     const float* s = src + (long long)blockIdx.x * npts * 2;
@@ -1152,5 +1150,108 @@ extern "C" int ss_three_view_finish(const float* n1, const float* n3, const floa
     if (!n1 || !n3 || !mid || !bbox || !mesh1 || !middle || !mesh3 || n_points <= 0) return SS_ERR_ARG;
     hipLaunchKernelGGL(three_view_finish_kernel, dim3(ss_cdiv(n_points, 256)), dim3(256), 0, (hipStream_t)stream, n1, n3, mid,
                        bbox, mesh1, middle, mesh3, n_points);
+    return ss_launch_status();
+}
+
+// Streaming three-view push: everything between the pair chains' smoothed meshes and the render's splines as ONE launch
+// (round 6; it was align, normalise, solve, points, finish, normalise + watch, solve = 7 graph nodes on the push's critical path).
+// Workgroup (view k, frame f): the alignment of frame f (three_view_align_kernel's arithmetic, recomputed by each of the three
+// workgroups: 63 vertices); for the outer views the re-projection through the pair's spline on the FIRST canvas (three_view_normalize
+// -> tps_solve -> tps_points -> three_view_finish, same device functions, same order); then the view's final mesh normalised on the
+// OUTPUT canvas and the render's spline onto the rigid mesh (stream_normalize_watch's arithmetic -> tps_solve_shared_target).  The two
+// eliminations of an outer view are the same code run twice (second pass: instruction cache warm).  Bit-identical to the launches it
+// replaces (tests/test_gpu_round6.py); the overflow watcher moves into the footprint launch (ss_render_footprints_watch).
+struct TvSplinesP {
+    const float *m12_1, *m12_2, *m23_1, *m23_2;       // smoothed pair meshes, LR scale; frame f at + f * mesh_fs floats
+    long long mesh_fs;
+    const float *first_box, *out_box, *nrigid;        // (wmin, wmax, hmin, hmax) x 2; normalised rigid mesh [63][2]
+    float *mesh1, *middle, *mesh3;                    // [frames][63][2], first-canvas pixels
+    float *src, *T;                                   // [frames][3][63][2] normalised on the output canvas; [frames][3][2][66]
+    float img_h, img_w;
+};
+__global__ __launch_bounds__(64 * TPS_NW) void three_view_splines_kernel(TvSplinesP p) {
+    __shared__ TpsShared sh;
+    __shared__ float al[5][SS_NV * 2];                // a1, a2, b1, b2, mid in HR pixels
+    __shared__ float tg[SS_NV * 2], Tl[2 * SS_NT], fin[SS_NV * 2];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const long long f = blockIdx.y;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (q == 0) {                                      // three_view_align_kernel, thread = vertex
+        const int v = lane;
+        const bool on = v < SS_NV;
+        const long long o = f * p.mesh_fs + (on ? v : 0) * 2;
+        auto sx = [&](float x) { return __fmul_rn(x, p.img_w) / 480.0f; };
+        auto sy = [&](float y) { return __fmul_rn(y, p.img_h) / 360.0f; };
+        const float a1x = sx(p.m12_1[o]), a1y = sy(p.m12_1[o + 1]), a2x = sx(p.m12_2[o]), a2y = sy(p.m12_2[o + 1]);
+        float b1x = sx(p.m23_1[o]), b1y = sy(p.m23_1[o + 1]), b2x = sx(p.m23_2[o]), b2y = sy(p.m23_2[o + 1]);
+        const float ox = ss_wave_sum(on ? __fsub_rn(a2x, b1x) : 0.f) / (float)SS_NV;
+        const float oy = ss_wave_sum(on ? __fsub_rn(a2y, b1y) : 0.f) / (float)SS_NV;
+        if (on) {
+            b1x = __fadd_rn(b1x, ox); b1y = __fadd_rn(b1y, oy);
+            b2x = __fadd_rn(b2x, ox); b2y = __fadd_rn(b2y, oy);
+            al[0][2 * v] = a1x; al[0][2 * v + 1] = a1y; al[1][2 * v] = a2x; al[1][2 * v + 1] = a2y;
+            al[2][2 * v] = b1x; al[2][2 * v + 1] = b1y; al[3][2 * v] = b2x; al[3][2 * v + 1] = b2y;
+            al[4][2 * v] = __fadd_rn(a2x, b1x) / 2.0f;
+            al[4][2 * v + 1] = __fadd_rn(a2y, b1y) / 2.0f;
+        }
+    }
+    __syncthreads();
+    const float fwmin = p.first_box[0], fhmin = p.first_box[2];
+    const float fow = __fsub_rn(p.first_box[1], fwmin), foh = __fsub_rn(p.first_box[3], fhmin);
+    const float owmin = p.out_box[0], ohmin = p.out_box[2];
+    const float oow = __fsub_rn(p.out_box[1], owmin), ooh = __fsub_rn(p.out_box[3], ohmin);
+    float* mesh_out = (k == 0 ? p.mesh1 : (k == 1 ? p.middle : p.mesh3)) + f * SS_NV * 2;
+    float px = 0.f, py = 0.f;                          // the point this thread re-projects (pass 0)
+    if (k == 1 && tid < SS_NV) {                       // the middle plane needs no spline: three_view_finish's translation
+        fin[2 * tid] = __fsub_rn(al[4][2 * tid], fwmin);
+        fin[2 * tid + 1] = __fsub_rn(al[4][2 * tid + 1], fhmin);
+        mesh_out[2 * tid] = fin[2 * tid];
+        mesh_out[2 * tid + 1] = fin[2 * tid + 1];
+    }
+#pragma unroll 1
+    for (int pass = (k == 1 ? 1 : 0); pass < 2; ++pass) {
+        if (tid < SS_NV) {
+            if (pass == 0) {                           // three_view_normalize_kernel: points a1 | b2, sources a2 | b1, targets mid
+                const float* P = k == 0 ? al[0] : al[3];
+                const float* S = k == 0 ? al[1] : al[2];
+                px = norm1(__fsub_rn(P[2 * tid], fwmin), fow); py = norm1(__fsub_rn(P[2 * tid + 1], fhmin), foh);
+                sh.sx[tid] = norm1(__fsub_rn(S[2 * tid], fwmin), fow); sh.sy[tid] = norm1(__fsub_rn(S[2 * tid + 1], fhmin), foh);
+                tg[2 * tid] = norm1(__fsub_rn(al[4][2 * tid], fwmin), fow); tg[2 * tid + 1] = norm1(__fsub_rn(al[4][2 * tid + 1], fhmin), foh);
+            } else {                                   // stream_normalize_watch_kernel (meshes are canvas pixels already)
+                const float nx = norm1(__fsub_rn(fin[2 * tid], owmin), oow), ny = norm1(__fsub_rn(fin[2 * tid + 1], ohmin), ooh);
+                sh.sx[tid] = nx; sh.sy[tid] = ny;
+                float* so = p.src + ((f * 3 + k) * SS_NV + tid) * 2;
+                so[0] = nx; so[1] = ny;
+                tg[2 * tid] = p.nrigid[2 * tid]; tg[2 * tid + 1] = p.nrigid[2 * tid + 1];
+            }
+        }
+        __syncthreads();
+        tps_eliminate(sh, tg, pass == 0 ? Tl : p.T + (f * 3 + k) * 2 * SS_NT, lane, q);
+        __syncthreads();
+        if (pass == 0 && tid < SS_NV) {                // tps_points_kernel + three_view_finish_kernel
+            float ox, oy;
+            tps_eval(sh.sx, sh.sy, Tl, Tl + SS_NT, px, py, ox, oy);
+            fin[2 * tid] = recover1(ox, fow); fin[2 * tid + 1] = recover1(oy, foh);
+            mesh_out[2 * tid] = fin[2 * tid];
+            mesh_out[2 * tid + 1] = fin[2 * tid + 1];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int ss_three_view_splines(const float* w12_m1, const float* w12_m2, const float* w23_m1, const float* w23_m2,
+                                     long long mesh_frame_stride, const float* first_box, const float* out_box, const float* nrigid,
+                                     float* mesh1, float* middle, float* mesh3, float* src, float* T, int frames, float img_h,
+                                     float img_w, void* stream) {
+    if (!w12_m1 || !w12_m2 || !w23_m1 || !w23_m2 || !first_box || !out_box || !nrigid || !mesh1 || !middle || !mesh3 || !src || !T ||
+        frames <= 0 || frames > 65535 || mesh_frame_stride < 0)
+        return SS_ERR_ARG;
+    TvSplinesP p;
+    p.m12_1 = w12_m1; p.m12_2 = w12_m2; p.m23_1 = w23_m1; p.m23_2 = w23_m2;
+    p.mesh_fs = mesh_frame_stride;
+    p.first_box = first_box; p.out_box = out_box; p.nrigid = nrigid;
+    p.mesh1 = mesh1; p.middle = middle; p.mesh3 = mesh3; p.src = src; p.T = T;
+    p.img_h = img_h; p.img_w = img_w;
+    hipLaunchKernelGGL(three_view_splines_kernel, dim3(3, frames), dim3(64 * TPS_NW), 0, (hipStream_t)stream, p);
     return ss_launch_status();
 }

@@ -224,7 +224,7 @@ __device__ __forceinline__ float avg_fuse(float a, float b) {
 // outside (validity mask of the full evaluation ~ 0) and that nothing else changes.
 __global__ void render_lattice_kernel(const float* __restrict__ source, const float* __restrict__ T,
                                       float* __restrict__ fp, long long frame_stride, int views, int hc, int wc,
-                                      int ny, int nx) {
+                                      int ny, int nx, float guard, int* __restrict__ watch_i, float* __restrict__ watch_f) {
     const int fv = blockIdx.y;                       // frame * views + view
     const int frame = fv / views, view = fv - frame * views;
     float* lattice = fp + frame * frame_stride + (long long)view * ny * nx * 2;
@@ -241,6 +241,20 @@ __global__ void render_lattice_kernel(const float* __restrict__ source, const fl
         }
         margin[2 * threadIdx.x] = lo;
         margin[2 * threadIdx.x + 1] = hi;
+    }
+    if (watch_i && blockIdx.x == 0 && view == 0 && threadIdx.x < 64) {
+        // the streaming canvas' overflow watcher over ALL views of this frame (canvas_watch_kernel's arithmetic; frame = stream):
+        // the control points are read here anyway, and a launch of its own is a node on the push's critical path
+        const float* s = source + (long long)frame * views * SS_NV * 2;
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        bool bad = false;
+        for (int k = threadIdx.x; k < views * SS_NV; k += 64) {
+            const float x = s[2 * k], y = s[2 * k + 1];
+            bad = bad || x != x || y != y;
+            xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+            ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+        }
+        canvas_watch_update(xmin, xmax, ymin, ymax, bad, guard, watch_i + frame * 4, watch_f + frame * 4);
     }
     if (idx >= ny * nx) return;
     const int i = idx / nx, j = idx - i * nx;
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(RO_THREADS) void render_order_kernel(float* __restr
     // one tile per iteration ran at one L2 round trip per iteration: 19 us per frame for 3100 tiles), and kept in registers
     // for both passes; one LDS atomic per wave and class (ballot + popcount; a lane's rank inside its wave's share is the
     // popcount of the lower lanes).  Canvases of more than RO_THREADS * TPT tiles evaluate the rest per pass.
-    constexpr int TPT = 4;
+    constexpr int TPT = 8;              // 8192 tiles in one pass (a 720p three-view canvas has ~4200: with 4 it ran a second, nearly empty pass: 17 us instead of 10)
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     unsigned char m0[TPT];
@@ -358,8 +372,8 @@ extern "C" long long ss_render_footprint_floats(int views, int hc, int wc) {
 }
 
 // footprints of `frames` x `views` splines in one launch: fp [frames][ lattice [views][ny][nx][2] | margin [views][2] ]
-extern "C" int ss_render_footprints(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
-                                    int hc, int wc, void* stream) {
+static int render_footprints_launch(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
+                                    int hc, int wc, float guard, int* watch_i, float* watch_f, void* stream) {
     if (!source || !T || !fp || frames <= 0 || views <= 0 || views > 3 || h <= 1 || w <= 1 || hc <= 1 || wc <= 1)
         return SS_ERR_ARG;
     const int ny = ss_cdiv(hc, 8) + 1, nx = 2 * ss_cdiv(wc, 64) + 1;
@@ -372,11 +386,25 @@ extern "C" int ss_render_footprints(const float* source, const float* T, float* 
         const int nf = frames - f0 < fmax ? frames - f0 : fmax;
         hipLaunchKernelGGL(render_lattice_kernel, dim3(ss_cdiv(ny * nx, 128), nf * views), dim3(128), 0, (hipStream_t)stream,
                            source + (long long)f0 * views * SS_NV * 2, T + (long long)f0 * views * 2 * SS_NT,
-                           fp + (long long)f0 * stride, stride, views, hc, wc, ny, nx);
+                           fp + (long long)f0 * stride, stride, views, hc, wc, ny, nx, guard, watch_i ? watch_i + 4 * f0 : nullptr,
+                           watch_f ? watch_f + 4 * f0 : nullptr);
     }
     hipLaunchKernelGGL(render_order_kernel, dim3(frames), dim3(RO_THREADS), 0, (hipStream_t)stream, fp, stride, views, h, w, hc, wc,
                        ny, nx);
     return ss_launch_status();
+}
+
+extern "C" int ss_render_footprints(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
+                                    int hc, int wc, void* stream) {
+    return render_footprints_launch(source, T, fp, frames, views, h, w, hc, wc, 0.f, nullptr, nullptr, stream);
+}
+
+// the same + the streaming canvas' overflow watcher (ss_canvas_watch's update of watch_i / watch_f [frames][4], frame = stream) inside
+// the lattice launch: `source` is what the watcher reads, and the push saves a graph node
+extern "C" int ss_render_footprints_watch(const float* source, const float* T, float* fp, int frames, int views, int h, int w,
+                                          int hc, int wc, float guard, int* watch_i, float* watch_f, void* stream) {
+    if (!watch_i || !watch_f || !(guard >= 0.f)) return SS_ERR_ARG;
+    return render_footprints_launch(source, T, fp, frames, views, h, w, hc, wc, guard, watch_i, watch_f, stream);
 }
 
 __device__ __forceinline__ void sample3(const float* __restrict__ in, float xn, float yn, int w, int h, long long hw, int mode,

@@ -20,6 +20,7 @@ captured ONCE into a HIP graph (state lives in static tensors: the rings are shi
 two input copies + one graph launch: the Python / ctypes launch overhead (~1 ms per pair, more than the kernels'
 own time at batch 1) disappears.  `use_graph=False` runs the same code eagerly.
 """
+import os
 import time
 
 import torch
@@ -434,6 +435,7 @@ class OnlineStitcher:
         return [self._render(hr1, hr2, m1[-1:], m2[-1:])]
 
 
+FUSED_SPLINES = os.environ.get('SS_FUSED_SPLINES', '1') != '0'   # ThreeViewOnlineStitcher: composition + splines in one launch
 PIPE_STREAM_CANDIDATES = 5        # streams tried pairwise by _TwoInFlight._pick_streams
 PIPE_PROBE_PUSHES = 8
 
@@ -1083,19 +1085,40 @@ class ThreeViewOnlineStitcher:
         return pipeline.three_view_compose(sh(m12[0]), sh(m12[1]), sh(m23[0]), sh(m23[1]), self.h, self.w,
                                            first_canvas=self.first_canvas)
 
+    def _compose_render(self, m1, m2, imgs, out):
+        """One steady-state triple from the chains' newest meshes m1, m2 [2,1,7,9,2] (stream 0 = pair (1,2), stream 1 = pair (2,3)):
+        composition + the render's splines as ONE launch (FUSED_SPLINES; else the seven launches it replaces), then the render."""
+        if FUSED_SPLINES:
+            meshes, src, T = ops.three_view_splines(m1[0], m2[0], m1[1], m2[1], self.first_canvas, self.bbox, self.nrigid, self.h, self.w)
+            self.last_composed = meshes
+            return self._render(imgs, meshes, out=out, splines=(src[0], T[0]))
+        meshes = self._compose((m1[0], m2[0]), (m1[1], m2[1]))
+        self.last_composed = meshes
+        return self._render(imgs, meshes, out=out)
+
     def _grown(self, bb):
         bb = bb.cpu()
         gw, gh = self.margin * (bb[1] - bb[0]), self.margin * (bb[3] - bb[2])
         return torch.stack((bb[0] - gw, bb[1] + gw, bb[2] - gh, bb[3] + gh)).to(self.dev)
 
-    def _render(self, imgs, meshes, out=None):
-        """imgs: three [1,3,H,W]; meshes: (mesh1, middle, mesh3) [1,1,7,9,2] in first-canvas pixels -> [3,Hc,Wc]."""
-        src4 = ops.stream_normalize_watch([m.contiguous() for m in meshes], 126, self.bbox, 0.0, 0.0, self._guard(), self.watch_i,
-                                          self.watch_f)                              # [1,3,63,2] on the output canvas
-        src = src4[0]
-        T = ops.tps_solve_shared(src, self.nrigid)
+    def _render(self, imgs, meshes, out=None, splines=None):
+        """imgs: three [1,3,H,W]; meshes: (mesh1, middle, mesh3) [1,1,7,9,2] in first-canvas pixels -> [3,Hc,Wc].
+        splines = (src [3,63,2], T [3,2,66]) from ops.three_view_splines: the steady-state push has them already, and the overflow
+        watcher runs inside the footprint launch (or as a launch of its own when there is none)."""
+        watch = None
+        if splines is None:
+            src4 = ops.stream_normalize_watch([m.contiguous() for m in meshes], 126, self.bbox, 0.0, 0.0, self._guard(), self.watch_i,
+                                              self.watch_f)                          # [1,3,63,2] on the output canvas
+            src = src4[0]
+            T = ops.tps_solve_shared(src, self.nrigid)
+        else:
+            src, T = splines
+            if self.fusion_mode == 'AVERAGE' and pipeline.SKIP_OUTSIDE:
+                watch = (self._guard(), self.watch_i, self.watch_f)
+            else:
+                ops.canvas_watch(src[None], self.watch_i, self.watch_f, self._guard())
         if self.fusion_mode == 'AVERAGE':
-            fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc)[0] if pipeline.SKIP_OUTSIDE else None
+            fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc, watch=watch)[0] if pipeline.SKIP_OUTSIDE else None
             return ops.render_average(imgs, src, T, self.hc, self.wc, self.warp_mode, out=out, footprint=fp)
         w = ops.tps_warp_views(imgs, src, T, self.hc, self.wc, self.warp_mode)        # [3,4,Hc,Wc]
         f = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
@@ -1110,9 +1133,8 @@ class ThreeViewOnlineStitcher:
         ch, st = self.chains, self.static
         ch._step_static()
         m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
-        meshes = self._compose((m1[0], m2[0]), (m1[1], m2[1]))
         hr = st['hr']
-        self._render([hr[0:1], hr[1:2], hr[2:3]], meshes, out=st['out'])
+        self._compose_render(m1, m2, [hr[0:1], hr[1:2], hr[2:3]], st['out'])
 
     def _state(self):
         return [self.chains.static[k] for k in MultiOnlineStitcher._STATE] + [self.watch_i, self.watch_f]
@@ -1237,9 +1259,8 @@ class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
         P, ch = self.pipe, self.chains
         ch._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], None, None, None, None)
         m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
-        meshes = self._compose((m1[0], m2[0]), (m1[1], m2[1]))
         hr = P['hr'][p]
-        self._render([hr[0:1], hr[1:2], hr[2:3]], meshes, out=P['out'][p])
+        self._compose_render(m1, m2, [hr[0:1], hr[1:2], hr[2:3]], P['out'][p])
 
     def _pipe_take(self, p):
         return [self.pipe['out'][p].clone()]

@@ -4,6 +4,8 @@ mesh-sized torch expressions of the path live in pipeline.py and are named there
 import os
 import threading
 
+import ctypes
+
 import torch
 
 from . import _hip as H
@@ -650,6 +652,16 @@ def homo_warp_pair(x1, x2, th1, th2, out_h, out_w):
         H.call('ss_homo_warp_nhwc', H.dptr(x1), H.dptr(th1), H.dptr(out), n1 + n2, x1.shape[1], x1.shape[2], x1.shape[3], out_h, out_w,
                H.stream())
         return out[:n1], out[n1:]
+    if (adjacent(th1, th2) and x1.shape == x2.shape and x1.is_contiguous() and x2.is_contiguous() and x1.device == x2.device):
+        # views of ONE tensor a whole number of images apart (a chain of pairs: views [0:n] and [1:n+1]): still one launch
+        img = x1[0].numel() * 4
+        d = x2.data_ptr() - x1.data_ptr()
+        if 0 <= d <= x1.numel() * 4 and d % img == 0 and x1.untyped_storage().data_ptr() == x2.untyped_storage().data_ptr():
+            n = x1.shape[0]
+            out = torch.empty((2 * n, out_h, out_w, x1.shape[3]), device=x1.device, dtype=torch.float32)
+            H.call('ss_homo_warp_pair_nhwc', H.dptr(x1), H.dptr(x2), H.dptr(th1), H.dptr(out), n, x1.shape[1], x1.shape[2], x1.shape[3],
+                   out_h, out_w, H.stream())
+            return out[:n], out[n:]
     return homo_warp_nhwc(x1, th1, out_h, out_w), homo_warp_nhwc(x2, th2, out_h, out_w)
 
 
@@ -767,13 +779,21 @@ def tps_warp(U, source, T, hc, wc, mode='NORMAL', with_mask=False):
     return out
 
 
-def render_footprints(source, T, h, w, hc, wc):
+def render_footprints(source, T, h, w, hc, wc, watch=None):
     """source [n,V,63,2], T [n,V,2,66], images h x w -> footprints [n, ss_render_footprint_floats] of every (frame, view) on
-    the hc x wc canvas (tile-corner sampling coordinates, mesh hulls, tile order), two small launches for the whole clip."""
+    the hc x wc canvas (tile-corner sampling coordinates, mesh hulls, tile order), two small launches for the whole clip.
+    watch = (guard, watch_i [n,4], watch_f [n,4]): the streaming overflow watcher (ops.canvas_watch on `source`, frame = stream) inside
+    the same launches."""
     n, v = source.shape[0], source.shape[1]
     per = int(H.lib().ss_render_footprint_floats(v, hc, wc))
     fp = torch.empty((n, per), device=source.device, dtype=torch.float32)
-    H.call('ss_render_footprints', H.dptr(_f(source)), H.dptr(_f(T)), H.dptr(fp), n, v, h, w, hc, wc, H.stream())
+    if watch is None:
+        H.call('ss_render_footprints', H.dptr(_f(source)), H.dptr(_f(T)), H.dptr(fp), n, v, h, w, hc, wc, H.stream())
+    else:
+        guard, wi, wf = watch
+        assert tuple(wi.shape) == (n, 4) and tuple(wf.shape) == (n, 4)
+        H.call('ss_render_footprints_watch', H.dptr(_f(source)), H.dptr(_f(T)), H.dptr(fp), n, v, h, w, hc, wc, float(guard),
+               H.dptr(wi, dtype=torch.int32), H.dptr(wf), H.stream())
     return fp
 
 
@@ -1054,6 +1074,25 @@ def three_view_finish(n1, n3, mid, bbox):
     H.call('ss_three_view_finish', H.dptr(_f(n1)), H.dptr(_f(n3)), H.dptr(_f(mid)), H.dptr(bbox), *[H.dptr(o) for o in outs],
            n * 63, H.stream())
     return outs
+
+
+def three_view_splines(m12_1, m12_2, m23_1, m23_2, first_box, out_box, nrigid, img_h, img_w):
+    """The streaming three-view push between the chains' smoothed meshes and the render in ONE launch (ss_three_view_splines =
+    three_view_align -> three_view_normalize -> tps_solve -> tps_points -> three_view_finish on the first canvas, then the final
+    meshes normalised on the output canvas and tps_solve_shared onto the rigid mesh; bit-identical to those launches).
+    m*: [k,7,9,2] contiguous, LR scale -> ((mesh1, middle, mesh3) [1,k,7,9,2] first-canvas pixels, src [k,3,63,2], T [k,3,2,66]).
+    The overflow watcher is not touched: render_footprints(..., watch=...) or canvas_watch(src, ...)."""
+    k = m12_1.numel() // 126
+    for m in (m12_1, m12_2, m23_1, m23_2):
+        assert m.is_contiguous() and m.dtype == torch.float32 and m.numel() == k * 126
+    assert nrigid.numel() == 126 and nrigid.is_contiguous()
+    d = m12_1.device
+    outs = [torch.empty((1, k, 7, 9, 2), device=d, dtype=torch.float32) for _ in range(3)]
+    src = torch.empty((k, 3, 63, 2), device=d, dtype=torch.float32)
+    T = torch.empty((k, 3, 2, 66), device=d, dtype=torch.float32)
+    H.call('ss_three_view_splines', H.dptr(m12_1), H.dptr(m12_2), H.dptr(m23_1), H.dptr(m23_2), 126, H.dptr(first_box), H.dptr(out_box),
+           H.dptr(nrigid), *[H.dptr(o) for o in outs], H.dptr(src), H.dptr(T), k, float(img_h), float(img_w), H.stream())
+    return tuple(outs), src, T
 
 
 def fill(t, value=0.0):

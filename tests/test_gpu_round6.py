@@ -397,6 +397,87 @@ def test_pipelined_stitcher_measures_its_stream_pair(dev, hip_nets):
     assert max(rates) < 1.25 * min(rates), rates
 
 
+def test_three_view_splines_equal_the_seven_launches(dev):
+    """ss_three_view_splines (align -> normalise -> solve -> points -> finish on the first canvas, then normalise on the output
+    canvas + solve onto the rigid mesh, 3 workgroups per frame) against the seven launches it replaces: meshes, control points
+    and coefficients bit for bit; the watcher inside ss_render_footprints_watch against stream_normalize_watch's."""
+    from stabstitch2_amd import ops, pipeline
+    from stabstitch2_amd.spatial_network import get_rigid_mesh, get_norm_mesh
+    h, w = 720, 1280
+    g = torch.Generator().manual_seed(5)
+    rigid_lr = get_rigid_mesh(1, 360, 480, device='cpu').reshape(1, 7, 9, 2)
+    nrigid = get_norm_mesh(get_rigid_mesh(1, h, w, device=dev), h, w).contiguous()
+    for k, amp in ((1, 6.0), (3, 25.0)):
+        ms = [(rigid_lr + amp * torch.randn((k, 7, 9, 2), generator=g) + off).to(dev).contiguous()
+              for off in (torch.tensor([0.0, 0.0]), torch.tensor([300.0, 4.0]), torch.tensor([-8.0, 3.0]), torch.tensor([290.0, -5.0]))]
+        first = torch.tensor([-40.0, 2900.0, -60.0, 800.0], device=dev)
+        outb = torch.tensor([-90.0, 3000.0, -100.0, 850.0], device=dev) if amp < 10 else torch.tensor([0.0, 2400.0, 0.0, 700.0], device=dev)
+        sh = lambda m: m.reshape(1, k, 7, 9, 2)
+        ref = pipeline.three_view_compose(sh(ms[0]), sh(ms[1]), sh(ms[2]), sh(ms[3]), h, w, first_canvas=first)
+        wi0, wf0 = ops.canvas_watch_state(k, dev)
+        src_ref = ops.stream_normalize_watch([m.contiguous() for m in ref], 126, outb.expand(k, 4).contiguous(), 0.0, 0.0, 0.01, wi0, wf0)
+        T_ref = ops.tps_solve_shared(src_ref.reshape(k * 3, 63, 2), nrigid).reshape(k, 3, 2, 66)
+        meshes, src, T = ops.three_view_splines(ms[0], ms[1], ms[2], ms[3], first, outb, nrigid, h, w)
+        torch.cuda.synchronize()
+        for a, b in zip(meshes, ref):
+            assert torch.equal(a, b)
+        assert torch.equal(src, src_ref) and torch.equal(T, T_ref)
+        wi1, wf1 = ops.canvas_watch_state(k, dev)
+        ops.render_footprints(src, T, h, w, 760, 2900, watch=(0.01, wi1, wf1))
+        torch.cuda.synchronize()
+        assert torch.equal(wi1, wi0) and torch.equal(wf1, wf0)
+        if amp > 10:
+            assert int(wi0[:, 1].sum()) > 0            # the second box is too small on purpose: the watcher has something to say
+
+
+def test_chain_pairs_share_their_launches(dev):
+    """A chain of pairs (view 1, view 2), (view 2, view 3) reads views [0:2] and [1:3] of one trunk output: the feature normalisation
+    of ss_ccl and the homography warp take them as ONE launch (overlapping inputs) -- results equal to separate tensors."""
+    from stabstitch2_amd import ops
+    g = torch.Generator().manual_seed(9)
+    f = torch.randn((3, 23, 30, 256), generator=g).to(dev)
+    a, b = f[0:2], f[1:3]
+    flow_o, _ = ops.ccl(a, b, 10.0, True, False)
+    flow_s, _ = ops.ccl(a.clone(), b.clone(), 10.0, True, False)
+    assert torch.equal(flow_o, flow_s)
+    x = torch.randn((3, 45, 60, 128), generator=g).to(dev)
+    th = (torch.eye(3).reshape(1, 9).repeat(4, 1) + 0.05 * torch.randn((4, 9), generator=g)).to(dev).contiguous()
+    w1, w2 = ops.homo_warp_pair(x[0:2], x[1:3], th[0:2], th[2:4], 45, 60)
+    r1, r2 = ops.homo_warp_nhwc(x[0:2].clone(), th[0:2].clone(), 45, 60), ops.homo_warp_nhwc(x[1:3].clone(), th[2:4].clone(), 45, 60)
+    torch.cuda.synchronize()
+    assert torch.equal(w1, r1) and torch.equal(w2, r2)
+    assert w2.data_ptr() == w1.data_ptr() + w1.numel() * 4          # one launch: one output tensor
+
+
+def test_three_view_stream_fused_splines_are_frame_neutral(dev, hip_nets, monkeypatch):
+    """ThreeViewOnlineStitcher with the fused composition launch (default) against the seven separate launches: frames, overflow
+    report and canvases identical, graph nodes fewer."""
+    from stabstitch2_amd import online
+    from stabstitch2_amd.online import ThreeViewOnlineStitcher
+    n, h, w = 16, 180, 320
+    hr, lr = synth.make_clip(n, h, w, seed=6, views=3)
+    hrd = [[f.to(dev) for f in v] for v in hr]
+    lrd = [[f.to(dev) for f in v] for v in lr]
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(online, 'FUSED_SPLINES', fused)
+        for fusion in ('AVERAGE', 'LINEAR'):
+            st = ThreeViewOnlineStitcher(hip_nets, h, w, fusion_mode=fusion, margin=0.0)      # margin 0: the watcher has work
+            frames = []
+            for t in range(22):
+                i = t % n
+                frames += st.push(hrd[0][i], hrd[1][i], hrd[2][i], lrd[0][i], lrd[1][i], lrd[2][i])
+            torch.cuda.synchronize()
+            res[(fused, fusion)] = (frames, st.overflow_report(), (st.hc, st.wc), st.graph_nodes)
+    for fusion in ('AVERAGE', 'LINEAR'):
+        a, b = res[(True, fusion)], res[(False, fusion)]
+        assert len(a[0]) == len(b[0]) and a[2] == b[2] and a[1] == b[1]
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        if a[3] is not None and b[3] is not None:
+            assert a[3] <= b[3] - 5
+
+
 def test_tps_solve_round6_kernel_against_round4(dev, request):
     """tps_solve_kernel of round 6 (four waves, lane = row, one barrier per column, pivot search under the previous update) against
     the round-4 kernel kept in the tuning build (`ss_tps_solve_r4`): same pivot rule and factors, the update an fma instead of
