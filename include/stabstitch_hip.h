@@ -297,7 +297,8 @@ SS_API int ss_render_average_clip_u8(const unsigned char* const* views_base, con
 /* footprints of frames x views splines (source [frames][views][63][2], T [frames][views][2][66]) on an hc x wc canvas, one
  * launch: per frame ss_render_footprint_floats(views, hc, wc) floats = exactly evaluated sampling coordinates on the
  * lattice of tile corners and long-edge midpoints, the bounding box of each view's control points (its mesh hull) and the
- * frame's tile order (tiles sorted by the number of views that reach them, most expensive first); a tile is skipped for a
+ * frame's tile order (four counters + four lists: the tiles by the number of views that reach them, most expensive class
+ * first; the order inside a class is not specified); a tile is skipped for a
  * view when it lies outside the hull AND its four corners and two long-edge midpoints all sample more than 8 pixels beyond
  * the same side of the (h x w) image (csrc/render.hip; a test, not a proof -- pass footprint = NULL for the reference's
  * arithmetic at every pixel). */

@@ -232,6 +232,8 @@ __global__ void render_lattice_kernel(const float* __restrict__ source, const fl
     const float* src = source + (long long)fv * SS_NV * 2;
     const float* Tx = T + (long long)fv * 2 * SS_NT;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && view == 0 && threadIdx.x >= 64 && threadIdx.x < 68)       // the frame's tile-class counters (render_order_kernel)
+        reinterpret_cast<unsigned*>(fp + frame * frame_stride + (long long)views * ny * nx * 2 + 4 * views)[threadIdx.x - 64] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < 2) {       // hull of the control points: thread 0 -> x range, thread 1 -> y range
         float lo = INFINITY, hi = -INFINITY;
         for (int k = 0; k < SS_NV; ++k) {
@@ -294,81 +296,55 @@ __device__ __forceinline__ unsigned tile_views(const float* __restrict__ fp, int
 }
 
 
-// Tile order of one frame: the fused render takes its tiles from this table, most expensive class first (tiles reached
-// by 3, 2, 1, 0 views cost ~2 : 1 : 0.5 : 0 spline evaluations per pixel).  With ~11 workgroups per CU and mixed costs a
-// row-major order left the CUs 25 % apart (measured: 55 us per frame against 45 for the cost-weighted sum of the tile
-// classes); longest-first hands the expensive tiles out evenly and fills in with the cheap ones.
+// Tile order of one frame: the fused render takes its tiles most expensive class first (tiles reached by 3, 2, 1, 0 views cost
+// ~2 : 1 : 0.5 : 0 spline evaluations per pixel).  With ~11 workgroups per CU and mixed costs a row-major order left the CUs 25 %
+// apart (measured: 55 us per frame against 45 for the cost-weighted sum of the tile classes); longest-first hands the expensive
+// tiles out evenly and fills in with the cheap ones.
 //   entry = bx | by << 12 | mask << 24
-#define RO_THREADS 1024
-__global__ __launch_bounds__(RO_THREADS) void render_order_kernel(float* __restrict__ fp, long long frame_stride, int views, int h,
+// Round 6: one LIST per class (4 x nt entries behind 4 counters that render_lattice_kernel zeroes) instead of one sorted table: a
+// tile's slot no longer depends on the totals of the classes in front of it, so the tiles are classified by nt / 256 workgroups,
+// one tile per thread, one global atomic per wave and class -- 3-4 us instead of the single workgroup's 9 (two views, 3100 tiles) /
+// 16 us (three views, 4158) on a streaming push's critical path.  The render finds its tile from the counters (render_tile_entry).
+// Which tile a workgroup of a class gets depends on the atomics' arrival order; every tile is still rendered exactly once.
+__global__ __launch_bounds__(256) void render_order_kernel(float* __restrict__ fp, long long frame_stride, int views, int h,
                                                            int w, int hc, int wc, int ny, int nx) {
-    __shared__ unsigned cnt[4], base[4];
-    float* f = fp + (long long)blockIdx.x * frame_stride;
-    unsigned* order = reinterpret_cast<unsigned*>(f + (long long)views * ny * nx * 2 + 4 * views);
+    float* f = fp + (long long)blockIdx.y * frame_stride;
+    unsigned* cnt = reinterpret_cast<unsigned*>(f + (long long)views * ny * nx * 2 + 4 * views);
+    unsigned* lists = cnt + 4;
     const int nbx = (nx - 1) / 2, nby = ny - 1, nt = nbx * nby;
-    if (threadIdx.x < 4) cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    // Counting sort by class.  The masks of a thread's tiles are evaluated FIRST, all loads independent (a loop that classified
-    // one tile per iteration ran at one L2 round trip per iteration: 19 us per frame for 3100 tiles), and kept in registers
-    // for both passes; one LDS atomic per wave and class (ballot + popcount; a lane's rank inside its wave's share is the
-    // popcount of the lower lanes).  Canvases of more than RO_THREADS * TPT tiles evaluate the rest per pass.
-    constexpr int TPT = 8;              // 8192 tiles in one pass (a 720p three-view canvas has ~4200: with 4 it ran a second, nearly empty pass: 17 us instead of 10)
+    const int t = blockIdx.x * 256 + (int)threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned char m0[TPT];
+    const int by = t / nbx, bx = t - by * nbx;
+    const unsigned mm = t < nt ? tile_views(f, views, by, bx, ny, nx, h, w, hc, wc) : 0xFFu;
+    const int c = mm == 0xFFu ? -1 : 3 - __popc(mm);
 #pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-        const int t = i * RO_THREADS + (int)threadIdx.x;
-        m0[i] = t < nt ? (unsigned char)tile_views(f, views, t / nbx, t % nbx, ny, nx, h, w, hc, wc) : (unsigned char)0xFF;
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long b = __ballot(c == k);
+        if (b == 0ull) continue;                    // (wave-uniform)
+        unsigned wb = 0u;
+        if (lane == 0) wb = atomicAdd(&cnt[k], (unsigned)__popcll(b));
+        wb = (unsigned)__shfl((int)wb, 0, 64);
+        if (c == k) lists[(long long)k * nt + wb + (unsigned)__popcll(b & below)] = (unsigned)bx | ((unsigned)by << 12) | (mm << 24);
     }
-    auto mask_of = [&](int r0, int i) -> unsigned {          // 0xFF: no such tile
-        if (r0 == 0) return m0[i];
-        const int t = r0 + i * RO_THREADS + (int)threadIdx.x;
-        return t < nt ? tile_views(f, views, t / nbx, t % nbx, ny, nx, h, w, hc, wc) : 0xFFu;
-    };
-    for (int r0 = 0; r0 < nt; r0 += RO_THREADS * TPT) {
-#pragma unroll
-        for (int i = 0; i < TPT; ++i) {
-            const unsigned mm = mask_of(r0, i);
-            const int c = mm == 0xFFu ? -1 : 3 - __popc(mm);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned long long b = __ballot(c == k);
-                if (lane == 0 && b) atomicAdd(&cnt[k], (unsigned)__popcll(b));
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned a = 0u;
-        for (int c = 0; c < 4; ++c) { base[c] = a; a += cnt[c]; cnt[c] = 0u; }
-    }
-    __syncthreads();
-    for (int r0 = 0; r0 < nt; r0 += RO_THREADS * TPT) {
-#pragma unroll
-        for (int i = 0; i < TPT; ++i) {
-            const int t = r0 + i * RO_THREADS + (int)threadIdx.x;
-            const int by = t / nbx, bx = t - by * nbx;
-            const unsigned mm = mask_of(r0, i);
-            const int c = mm == 0xFFu ? -1 : 3 - __popc(mm);
-            unsigned slot = 0u;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned long long b = __ballot(c == k);
-                unsigned wb = 0u;
-                if (lane == 0 && b) wb = atomicAdd(&cnt[k], (unsigned)__popcll(b));
-                wb = (unsigned)__shfl((int)wb, 0, 64);
-                if (c == k) slot = base[k] + wb + (unsigned)__popcll(b & below);
-            }
-            if (c >= 0) order[slot] = (unsigned)bx | ((unsigned)by << 12) | (mm << 24);
-        }
-    }
+}
+
+// the i-th tile of a frame in cost order: class lists back to back
+__device__ __forceinline__ unsigned render_tile_entry(const float* __restrict__ fp, int views, int ny, int nx, unsigned i) {
+    const unsigned* cnt = reinterpret_cast<const unsigned*>(fp + (long long)views * ny * nx * 2 + 4 * views);
+    const unsigned nt = (unsigned)((nx - 1) / 2 * (ny - 1));
+    const unsigned c0 = cnt[0], c1 = cnt[1], c2 = cnt[2];
+    unsigned k = 0u, off = i;
+    if (i >= c0) { k = 1u; off = i - c0; }
+    if (i >= c0 + c1) { k = 2u; off = i - c0 - c1; }
+    if (i >= c0 + c1 + c2) { k = 3u; off = i - c0 - c1 - c2; }
+    return cnt[4 + (unsigned long long)k * nt + off];
 }
 
 extern "C" long long ss_render_footprint_floats(int views, int hc, int wc) {
     if (views <= 0 || hc <= 1 || wc <= 1) return 0;
     return (long long)views * ((long long)(ss_cdiv(hc, 8) + 1) * (2 * ss_cdiv(wc, 64) + 1) * 2 + 4) +
-           (long long)ss_cdiv(hc, 8) * ss_cdiv(wc, 64);       // + the tile order table
+           4 + 4ll * ss_cdiv(hc, 8) * ss_cdiv(wc, 64);       // + 4 class counters + 4 class lists of tiles
 }
 
 // footprints of `frames` x `views` splines in one launch: fp [frames][ lattice [views][ny][nx][2] | margin [views][2] ]
@@ -389,8 +365,12 @@ static int render_footprints_launch(const float* source, const float* T, float* 
                            fp + (long long)f0 * stride, stride, views, hc, wc, ny, nx, guard, watch_i ? watch_i + 4 * f0 : nullptr,
                            watch_f ? watch_f + 4 * f0 : nullptr);
     }
-    hipLaunchKernelGGL(render_order_kernel, dim3(frames), dim3(RO_THREADS), 0, (hipStream_t)stream, fp, stride, views, h, w, hc, wc,
-                       ny, nx);
+    const int nt = (ny - 1) * ((nx - 1) / 2);
+    for (int f0 = 0; f0 < frames; f0 += 65535) {
+        const int nf = frames - f0 < 65535 ? frames - f0 : 65535;
+        hipLaunchKernelGGL(render_order_kernel, dim3(ss_cdiv(nt, 256), nf), dim3(256), 0, (hipStream_t)stream, fp + (long long)f0 * stride,
+                           stride, views, h, w, hc, wc, ny, nx);
+    }
     return ss_launch_status();
 }
 
@@ -494,8 +474,7 @@ __global__ __launch_bounds__(256) void render_average_kernel(RenderViews rv, con
     int tbx, tby;
     unsigned mask;
     if (fp) {                                       // tile and its view set from the frame's order table (longest first)
-        const unsigned* order = reinterpret_cast<const unsigned*>(fp + (long long)VIEWS * ny * nx * 2 + 4 * VIEWS);
-        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);
+        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)render_tile_entry(fp, VIEWS, ny, nx, blockIdx.x));
         tbx = (int)(e & 0xFFFu); tby = (int)((e >> 12) & 0xFFFu); mask = e >> 24;
     } else {
         tby = blockIdx.x / nbx; tbx = blockIdx.x - tby * nbx; mask = (1u << VIEWS) - 1u;

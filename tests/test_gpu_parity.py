@@ -1221,8 +1221,18 @@ def test_render_footprint_skipping(dev, hip_nets, views):
     # lattice: rows every 8 px, columns every 32 px (tile corners + long-edge midpoints); nbx tiles per row
     nbx = (wc + 63) // 64
     ny, nx = (hc + 7) // 8 + 1, 2 * nbx + 1
-    assert fp.shape == (n, views * ny * nx * 2 + views * 4 + (ny - 1) * nbx)
+    assert fp.shape == (n, views * ny * nx * 2 + views * 4 + 4 + 4 * (ny - 1) * nbx)         # lattice, hulls, 4 class counters + lists
     assert bool(torch.isfinite(fp[:, :views * ny * nx * 2 + views * 4]).all())
+    base = views * ny * nx * 2 + views * 4
+    nt = (ny - 1) * nbx
+    for i in range(n):                                     # the tile order: every tile in exactly one class list, classes by view count
+        words = fp[i, base:].view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        cnt, lists = words[:4], words[4:].reshape(4, nt)
+        assert int(cnt.sum()) == nt
+        seen = np.concatenate([lists[k, :cnt[k]] for k in range(4)])
+        assert len(np.unique((seen & 0xFFF) + ((seen >> 12) & 0xFFF) * nbx)) == nt
+        for k in range(4):
+            assert all(bin(int(e >> 24)).count('1') == 3 - k for e in lists[k, :cnt[k]][:50])
     skipped_frac = []
     for i in (0, n - 1):
         imgs = [hr[k][i] for k in range(views)]
