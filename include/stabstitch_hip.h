@@ -199,6 +199,11 @@ SS_API int ss_cost_volume(const float* x1, const float* x2, float* out, int n, i
  * cost_volume(x1, x2), cost_volume(x2, x1) */
 SS_API int ss_cost_volume_bidir(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r,
                          int out_cs, void* stream);
+/* n volumes over inputs that hold every image ONCE: volume b = ss_cost_volume of image b + (b >= split ? shift : 0) of x1 and x2.
+ * A chain of S pairs (view s, view s + 1) stores its S + 1 views' features once and gets the 2 S volumes [first views | second
+ * views] with split = S, shift = 1 - S (temporal_network.py:120-147 per view). */
+SS_API int ss_cost_volume_shifted(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r, int out_cs,
+                                  int split, int shift, void* stream);
 /* tile height of the cost-volume kernel (spatial_network.py:333-358; process-wide A/B knob): 0 = the library's choice, 4 or 8 output rows x 16 columns per
  * workgroup; identical results. */
 SS_API int ss_cost_volume_set_tile(int ty);

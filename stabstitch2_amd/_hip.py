@@ -52,6 +52,7 @@ SIGNATURES = {
     'ss_l2norm_nhwc': (c_i, [c_fp, c_fp, c_ll, c_i, c_st]),
     'ss_cost_volume': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     'ss_cost_volume_bidir': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    'ss_cost_volume_shifted': (c_i, [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_st]),
     'ss_cost_volume_set_tile': (c_i, [c_i]),
     'ss_wino43_set_persistent': (c_i, [c_i]),
     'ss_tensor_dlt': (c_i, [c_fp, c_fp, c_fp, c_i, c_st]),

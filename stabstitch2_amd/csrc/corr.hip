@@ -21,7 +21,7 @@ extern "C" int ss_conv_nhwc(const float*, const float*, const float*, const floa
 template <int R, int CV_TY>
 __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void cost_volume_kernel(
     const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ out, int h, int w, int c,
-    int out_cs, int n_fwd, int n_img, int tiles_x, int tiles_y) {
+    int out_cs, int n_fwd, int n_img, int tiles_x, int tiles_y, int split, int shift) {
     constexpr int KD = 2 * R + 1;
     constexpr int D = KD * KD;
     constexpr int PG = 4 * CV_TY;                      // threads per displacement row: CV_TY rows x 4 pixel quads
@@ -76,8 +76,10 @@ __global__ __launch_bounds__(64 * ((4 * CV_TY * (2 * R + 1) + 63) / 64)) void co
     const int py = pg >> 2, g4 = (pg & 3) * 4;
     // (Eight lanes of a 16-byte read = the four g4 of two ADJACENT window rows.  Round 3 tried a lane map that pairs rows half a
     // bank cycle apart -- 256 threads with 80 idle lanes at R = 5: slower.  Round 4 rotates the odd rows' chunks instead, above.)
-    const float* x1n = x1 + (long long)n * h * w * c;
-    const float* x2n = x2 + (long long)n * h * w * c;
+    // volume n reads image n + (n >= split ? shift : 0) of both inputs (a chain of pairs stores every view once: ss_cost_volume_shifted)
+    const int ni = n + (n >= split ? shift : 0);
+    const float* x1n = x1 + (long long)ni * h * w * c;
+    const float* x2n = x2 + (long long)ni * h * w * c;
 
     // accumulators as PAIRS for v_pk_fma_f32 (two fp32 FMAs per issue slot).  acc(p, i) += a[p] * v[p + i]: the window values
     // arrive as aligned register pairs (v[2t], v[2t+1]), so pixel p pairs its displacements (i, i + 1) with p + i EVEN -- even p:
@@ -254,7 +256,7 @@ extern "C" int ss_cost_volume_set_tile(int ty) {
 }
 
 static int cv_launch(const float* x1, const float* x2, float* out, int n_fwd, int n_img, int h, int w, int c, int r, int out_cs,
-                     hipStream_t st) {
+                     hipStream_t st, int split = 1 << 30, int shift = 0) {
     if (r != 5 && r != 3) return SS_ERR_UNSUPPORTED;
     // measured (tools/bench_cv.py, 32 / 62 pairs): R = 5: 93-106 us at TY 4, 119-128 at TY 8; R = 3: 91 at TY 4, 79 at TY 8
     const int TY = g_cv_ty ? g_cv_ty : (r == 3 ? 8 : CV_DEFAULT_TY);
@@ -262,11 +264,11 @@ static int cv_launch(const float* x1, const float* x2, float* out, int n_fwd, in
     if ((long long)tx * ty * n_img > (1ll << 30)) return SS_ERR_UNSUPPORTED;
     dim3 g(8 * ss_cdiv((long long)tx * ty * n_img, 8));
     if (TY == 8) {
-        if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5, 8>), g, dim3(384), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty);
-        else hipLaunchKernelGGL((cost_volume_kernel<3, 8>), g, dim3(256), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty);
+        if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5, 8>), g, dim3(384), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty, split, shift);
+        else hipLaunchKernelGGL((cost_volume_kernel<3, 8>), g, dim3(256), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty, split, shift);
     } else {
-        if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5, 4>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty);
-        else hipLaunchKernelGGL((cost_volume_kernel<3, 4>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty);
+        if (r == 5) hipLaunchKernelGGL((cost_volume_kernel<5, 4>), g, dim3(192), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty, split, shift);
+        else hipLaunchKernelGGL((cost_volume_kernel<3, 4>), g, dim3(128), 0, st, x1, x2, out, h, w, c, out_cs, n_fwd, n_img, tx, ty, split, shift);
     }
     return ss_launch_status();
 }
@@ -277,6 +279,17 @@ extern "C" int ss_cost_volume(const float* x1, const float* x2, float* out, int 
     int D = (2 * r + 1) * (2 * r + 1);
     if (out_cs < D) return SS_ERR_ARG;
     return cv_launch(x1, x2, out, n, n, h, w, c, r, out_cs, (hipStream_t)stream);
+}
+
+// n volumes over inputs that hold every image ONCE: volume b = cv(x1[i], x2[i]) with i = b + (b >= split ? shift : 0).  A chain of S
+// pairs (view s, view s + 1) keeps its S + 1 views' TemporalNet features once and asks for the 2 S volumes [first views | second
+// views] with split = S, shift = 1 - S (temporal_network.py:120-147 per view; no concatenated copy of the features).
+extern "C" int ss_cost_volume_shifted(const float* x1, const float* x2, float* out, int n, int h, int w, int c, int r, int out_cs,
+                                      int split, int shift, void* stream) {
+    if (!x1 || !x2 || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || split < 0 || split + shift < 0) return SS_ERR_ARG;
+    int D = (2 * r + 1) * (2 * r + 1);
+    if (out_cs < D) return SS_ERR_ARG;
+    return cv_launch(x1, x2, out, n, n, h, w, c, r, out_cs, (hipStream_t)stream, split, shift);
 }
 
 // both directions in ONE launch: out [2][n][h][w][out_cs] = cv(x1, x2), cv(x2, x1)

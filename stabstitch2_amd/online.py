@@ -96,7 +96,7 @@ def _heads_b(spatial, temporal, f64, off1, prev_feat, feat, b, tm_out, chain=Fal
     -> (offset_2_ref, offset_2_tgt); temporal motions into tm_out."""
     o2 = 1 if chain else b
     cv_s = spatial.cv_from_offset1(f64[:b], f64[o2:o2 + b], off1, pipeline.LR_H, pipeline.LR_W)
-    cv_t = ops.cost_volume(prev_feat, feat, 3)
+    cv_t = ops.cost_volume(prev_feat, feat, 3, chain=b if chain else 0)      # [2b] volumes, view-major (chain: from b + 1 views stored once)
     off_ref = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
     off_tgt = torch.empty((b, 126), device=f64.device, dtype=torch.float32)
     L.run_regressor_quad(cv_s, cv_t.view((2, b) + tuple(cv_t.shape[1:])), L.get_quad(spatial, temporal),
@@ -243,12 +243,19 @@ class OnlineStitcher:
         T = ops.tps_solve_shared(src, self.nrigid)
         return self._render_solved(hr1, hr2, src, T, out)
 
+    def _direct(self):
+        """Does the steady-state push launch its render itself (DIRECT_RENDER), outside the graph?"""
+        return bool(DIRECT_RENDER and self.use_graph and self.fusion_mode == 'AVERAGE' and not self.meshes_only)
+
     def _render_solved(self, hr1, hr2, src, T, out=None):
         """src [2,63,2] normalised control points on this stream's canvas, T [2,2,66] their splines -> stitched frame."""
         if self.fusion_mode == 'AVERAGE':
             fp = None
             if pipeline.SKIP_OUTSIDE:        # same footprint skipping as the offline render (pipeline.render_frames)
                 fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc)[0]
+            if out is _DEFER:
+                self._deferred = (src, T, fp)
+                return None
             return ops.render_average([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode, out=out, footprint=fp)
         w = ops.tps_warp_views([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode)
         res = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
@@ -282,7 +289,7 @@ class OnlineStitcher:
         lands in place -- no torch op in the step besides the copy of the cached features)."""
         st = self.static
         f2, off1 = self._stage_a(st['lr1'], st['lr2'])
-        self._stage_b(f2, off1, st['hr1'], st['hr2'], st['out'])
+        self._stage_b(f2, off1, st['hr1'], st['hr2'], _DEFER if self._direct() else st['out'])
 
     def _stage_a(self, lr1, lr2):
         """First half of a steady-state push -- it touches NO stream state: both nets' stage-1 trunks on the two LR frames (one
@@ -336,7 +343,8 @@ class OnlineStitcher:
             # weights (the graph by address); rebuild and recapture instead of silently stitching with stale filters
             self.trunk_pair = None
             self.graph = None
-        if not self.meshes_only:             # (meshes_only: the frames are not looked at, None will do)
+        direct = self._direct()
+        if not self.meshes_only and not direct:      # (meshes_only: the frames are not looked at, None will do; direct: rendered in place)
             st['hr1'].copy_(hr1.reshape(st['hr1'].shape)); st['hr2'].copy_(hr2.reshape(st['hr2'].shape))
         st['lr1'].copy_(lr1.reshape(st['lr1'].shape)); st['lr2'].copy_(lr2.reshape(st['lr2'].shape))
         if not self.use_graph:
@@ -370,6 +378,10 @@ class OnlineStitcher:
             return tuple(m.clone() for m in self.last_meshes)
         if self.grow == 'recapture':
             self._post_watch_copy()
+        if direct:                       # the graph left splines and footprints; the render reads the caller's frames, writes a new tensor
+            src, T, fp = self._deferred
+            return [ops.render_average([hr1.reshape(st['hr1'].shape), hr2.reshape(st['hr2'].shape)], src, T, self.hc, self.wc,
+                                       self.warp_mode, footprint=fp)]
         return [st['out'].clone()]
 
     @torch.no_grad()
@@ -435,6 +447,11 @@ class OnlineStitcher:
         return [self._render(hr1, hr2, m1[-1:], m2[-1:])]
 
 
+# Steady-state AVERAGE render OUTSIDE the captured graph, on the caller's own HR frames and into a fresh tensor: the graph ends with the
+# splines / footprints, the push saves the copies of the HR frames into static buffers and the clone of the static canvas (720p, three
+# views: 66 + 50 MB of HBM traffic, ~35 us of a 1.1 ms push).  Same kernel, same operands: frames bit-identical.
+DIRECT_RENDER = os.environ.get('SS_DIRECT_RENDER', '1') != '0'
+_DEFER = object()                      # `out=_DEFER`: compute splines and footprints, leave the render launch to the push
 FUSED_SPLINES = os.environ.get('SS_FUSED_SPLINES', '1') != '0'   # ThreeViewOnlineStitcher: composition + splines in one launch
 PIPE_STREAM_CANDIDATES = 5        # streams tried pairwise by _TwoInFlight._pick_streams
 PIPE_PROBE_PUSHES = 8
@@ -478,6 +495,8 @@ class _TwoInFlight:
                 with torch.cuda.graph(g):
                     fn(p)
                 self.pipe[key][p] = g
+                if key == 'gb':              # (direct render: the second half left this parity's splines and footprints)
+                    self.pipe.setdefault('deferred', [None, None])[p] = getattr(self, '_deferred', None)
                 if p == 0:
                     n = _graph_nodes(g)
                     nodes = None if nodes is None or n is None else nodes + n
@@ -566,7 +585,7 @@ class _TwoInFlight:
         sa, sb = P['sa'], P['sb']
         eb = self._enqueue(p, sa, sb, lambda: self._pipe_load(p, sa, sb, *inputs))
         with torch.cuda.stream(sb):
-            result = self._pipe_take(p)
+            result = self._pipe_take(p, *inputs)
             eb = torch.cuda.Event()
             eb.record(sb)
         P['eB'][p] = eb
@@ -636,9 +655,10 @@ class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
         with torch.cuda.stream(sa):
             P['lr'][p][0].copy_(lr1.reshape(P['lr'][p][0].shape))
             P['lr'][p][1].copy_(lr2.reshape(P['lr'][p][1].shape))
-        with torch.cuda.stream(sb):
-            P['hr1'][p].copy_(hr1.reshape(P['hr1'][p].shape))
-            P['hr2'][p].copy_(hr2.reshape(P['hr2'][p].shape))
+        if not self._direct():               # (direct render: the second stream's render reads the caller's frames)
+            with torch.cuda.stream(sb):
+                P['hr1'][p].copy_(hr1.reshape(P['hr1'][p].shape))
+                P['hr2'][p].copy_(hr2.reshape(P['hr2'][p].shape))
         for t in (hr1, hr2):
             t.record_stream(sb)
         for t in (lr1, lr2):
@@ -652,10 +672,15 @@ class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
 
     def _run_b(self, p):
         P = self.pipe
-        self._stage_b(P['f2'][p], P['off1'][p], P['hr1'][p], P['hr2'][p], P['out'][p])
+        self._stage_b(P['f2'][p], P['off1'][p], P['hr1'][p], P['hr2'][p], _DEFER if self._direct() else P['out'][p])
 
-    def _pipe_take(self, p):
-        return [self.pipe['out'][p].clone()]
+    def _pipe_take(self, p, hr1, hr2, lr1, lr2):
+        P = self.pipe
+        if self._direct():
+            src, T, fp = P['deferred'][p]
+            return [ops.render_average([hr1.reshape(P['hr1'][p].shape), hr2.reshape(P['hr2'][p].shape)], src, T, self.hc, self.wc,
+                                       self.warp_mode, footprint=fp)]
+        return [P['out'][p].clone()]
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         return self._push_pipelined(hr1, hr2, lr1, lr2)
@@ -730,7 +755,8 @@ class MultiOnlineStitcher:
 
     def _init_static(self):
         """Batched steady-state buffers from the S single-stream states (each has just completed its first window):
-          pair_s / pair_t [2 views][prev, new][S][126], ring [4 kinds][S][7][126], prev_feat [2 views * S,45,60,128] view-major."""
+          pair_s / pair_t [2 views][prev, new][S][126], ring [4 kinds][S][7][126], prev_feat [2 views * S,45,60,128] view-major
+          (chain: [S + 1,45,60,128])."""
         d, S, e = self.dev, self.S, 126
         one = [s.static for s in self.single]
         lr = torch.empty((2, S, 3, pipeline.LR_H, pipeline.LR_W), device=d)       # both views back to back: one layout launch per push
@@ -738,7 +764,9 @@ class MultiOnlineStitcher:
         st = {'hr1': None if hr is None else hr[0], 'hr2': None if hr is None else hr[1],
               'lr1': lr[0], 'lr2': lr[1],
               'lrc': torch.empty((S + 1, 3, pipeline.LR_H, pipeline.LR_W), device=d) if self.chain else None,
-              'prev_feat': torch.cat([torch.stack([o['prev_feat'][v] for o in one], 0) for v in range(2)], 0).contiguous(),
+              # (chain: the S + 1 views once -- pair s holds views s and s + 1; ops.cost_volume(chain=S) pairs them up)
+              'prev_feat': (torch.stack([o['prev_feat'][0] for o in one] + [one[-1]['prev_feat'][1]], 0).contiguous() if self.chain else
+                            torch.cat([torch.stack([o['prev_feat'][v] for o in one], 0) for v in range(2)], 0).contiguous()),
               'pair_s': torch.stack([o['pair_s'] for o in one], 2).contiguous(),           # [2,2,S,126]
               'pair_t': torch.zeros((2, 2, S, e), device=d),
               'ring': torch.stack([o['ring'] for o in one], 1).contiguous(),               # [4,S,7,126]
@@ -820,27 +848,32 @@ class MultiOnlineStitcher:
     def _step_static(self):
         st = self.static
         f64, feat, off1 = self._stage_a(st['lrc'] if self.chain else [st['lr1'], st['lr2']])
-        self._stage_b(f64, feat, off1, st['hr1'], st['hr2'], st['out_all'], st['out'])
+        self._stage_b(f64, feat, off1, st['hr1'], st['hr2'], st['out_all'], st['out'], defer=self._direct())
+
+    def _direct(self):
+        """DIRECT_RENDER: the captured step stops at splines + footprints, the push renders from the caller's frames."""
+        return bool(DIRECT_RENDER and self.use_graph and self.fusion_mode == 'AVERAGE' and not self.meshes_only)
 
     def _stage_a(self, lr):
         """First half of a steady-state push (no stream state): trunks, SpatialNet's stage-2 trunk, CCL, regressNet1.
         lr: [lr1, lr2] ([S,3,360,480] each) or, chain mode, the S + 1 views' frames [S+1,3,360,480] (each view once)
-        -> (f64 SpatialNet trunk features, feat TemporalNet features [2S, view-major], offset_1 [S,8] | None)."""
+        -> (f64 SpatialNet trunk features, feat TemporalNet features [2S, view-major] (chain: [S + 1], each view once), offset_1 [S,8] | None)."""
         S = self.S
         if self.trunk_pair is None:
             self.trunk_pair = L.pair_trunks(self.spatial._prepared()['s1'], self.temporal._prepared()['s1'])
             self.trunk_versions = self._versions()
         if self.chain:
             fc = L.run_stage1_pair([lr], self.trunk_pair)                          # [2(net), S + 1 views, 45,60,128]: each view once
-            feat = torch.cat((fc[1][:S], fc[1][1:]), 0)                            # TemporalNet's features, view-major per pair
+            feat = fc[1]                                                           # TemporalNet's features of the S + 1 views, each once
             f64 = fc[0]
         else:
             f2 = L.run_stage1_pair(list(lr), self.trunk_pair)                      # [2(net), 2S (view-major), 45,60,128]
             feat, f64 = f2[1], f2[0]
         return f64, feat, (_heads_a(self.spatial, f64, S, self.chain) if L.QUAD else None)
 
-    def _stage_b(self, f64, feat, off1, hr1, hr2, out_all, out):
-        """Second half: everything that reads or advances the streams' state, and the render into out_all / out."""
+    def _stage_b(self, f64, feat, off1, hr1, hr2, out_all, out, defer=False):
+        """Second half: everything that reads or advances the streams' state, and the render into out_all / out (defer: splines
+        and footprints only -- self._deferred / the single stitchers' _deferred -- the push launches the render itself)."""
         st, S, e = self.static, self.S, 126
         ps, pt = st['pair_s'], st['pair_t']
         tm_out = (pt[0, 1], pt[1, 1])
@@ -877,12 +910,15 @@ class MultiOnlineStitcher:
             hc, wc = self.single[0].hc, self.single[0].wc
             if self.fusion_mode == 'AVERAGE':
                 fp = ops.render_footprints(src, T, self.h, self.w, hc, wc) if pipeline.SKIP_OUTSIDE else None
+                if defer:
+                    self._deferred = (src, T, fp)
+                    return
                 ops.render_average_clip([hr1, hr2], src, T, hc, wc, self.warp_mode, out=out_all, footprint=fp)
             else:
                 ops.render_linear_clip([hr1, hr2], src, T, hc, wc, self.warp_mode, out=out_all)
             return
         for s, one in enumerate(self.single):
-            one._render_solved(hr1[s:s + 1], hr2[s:s + 1], src[s], T[s], out=out[s])
+            one._render_solved(hr1[s:s + 1], hr2[s:s + 1], src[s], T[s], out=_DEFER if defer else out[s])
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static
@@ -895,7 +931,8 @@ class MultiOnlineStitcher:
             st['lrc'][:self.S].copy_(lr1); st['lrc'][self.S:].copy_(lr2[self.S - 1:])
         else:
             st['lr1'].copy_(lr1); st['lr2'].copy_(lr2)
-        if not self.meshes_only:
+        direct = self._direct()
+        if not self.meshes_only and not direct:
             st['hr1'].copy_(hr1); st['hr2'].copy_(hr2)
         if not self.use_graph:
             self._step_static()
@@ -923,6 +960,18 @@ class MultiOnlineStitcher:
             return tuple(m.clone() for m in self.last_meshes)
         if self.grow == 'recapture':
             self._post_watch_copy()
+        if direct:                       # the graph left splines and footprints: render from the caller's frames into new tensors
+            hr1, hr2 = hr1.reshape(st['hr1'].shape), hr2.reshape(st['hr2'].shape)
+            if st['out_all'] is not None:
+                src, T, fp = self._deferred
+                one = self.single[0]
+                frames = ops.render_average_clip([hr1.contiguous(), hr2.contiguous()], src, T, one.hc, one.wc, self.warp_mode, footprint=fp)
+                return [[frames[s]] for s in range(self.S)]
+            res = []
+            for s, one in enumerate(self.single):
+                src, T, fp = one._deferred
+                res.append([ops.render_average([hr1[s:s + 1], hr2[s:s + 1]], src, T, one.hc, one.wc, self.warp_mode, footprint=fp)])
+            return res
         return [[o.clone()] for o in st['out']]
 
     @torch.no_grad()
@@ -1010,7 +1059,7 @@ class PipelinedMultiOnlineStitcher(_TwoInFlight, MultiOnlineStitcher):
         P = self.pipe
         self._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], P['hr'][p][0], P['hr'][p][1], P['out_all'][p], P['out'][p])
 
-    def _pipe_take(self, p):
+    def _pipe_take(self, p, *inputs):
         return [[o.clone()] for o in self.pipe['out'][p]]
 
     def _push_static(self, hr1, hr2, lr1, lr2):
@@ -1070,6 +1119,10 @@ class ThreeViewOnlineStitcher:
     # ------------------------------------------------------------------ overflow / growth of the output canvas: as OnlineStitcher
     _guard = OnlineStitcher._guard
     _set_canvas = OnlineStitcher._set_canvas
+
+    def _direct(self):
+        return bool(DIRECT_RENDER and self.use_graph and self.fusion_mode == 'AVERAGE')
+
     _needed_bbox = OnlineStitcher._needed_bbox
     _regrow = OnlineStitcher._regrow
     _poll_growth = OnlineStitcher._poll_growth
@@ -1119,6 +1172,9 @@ class ThreeViewOnlineStitcher:
                 ops.canvas_watch(src[None], self.watch_i, self.watch_f, self._guard())
         if self.fusion_mode == 'AVERAGE':
             fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc, watch=watch)[0] if pipeline.SKIP_OUTSIDE else None
+            if out is _DEFER:
+                self._deferred = (src, T, fp)
+                return None
             return ops.render_average(imgs, src, T, self.hc, self.wc, self.warp_mode, out=out, footprint=fp)
         w = ops.tps_warp_views(imgs, src, T, self.hc, self.wc, self.warp_mode)        # [3,4,Hc,Wc]
         f = ops.linear_blend(w[0, 0:3], w[1, 0:3], w[0, 3], w[1, 3])
@@ -1134,7 +1190,7 @@ class ThreeViewOnlineStitcher:
         ch._step_static()
         m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
         hr = st['hr']
-        self._compose_render(m1, m2, [hr[0:1], hr[1:2], hr[2:3]], st['out'])
+        self._compose_render(m1, m2, [hr[0:1], hr[1:2], hr[2:3]], _DEFER if self._direct() else st['out'])
 
     def _state(self):
         return [self.chains.static[k] for k in MultiOnlineStitcher._STATE] + [self.watch_i, self.watch_f]
@@ -1147,8 +1203,10 @@ class ThreeViewOnlineStitcher:
             self.chains.trunk_pair = None
             self.graph = None
             self.versions = self._versions()
+        direct = self._direct()
         for k, (h, l) in enumerate(((hr1, lr1), (hr2, lr2), (hr3, lr3))):      # each view once: three frames, three LR frames
-            st['hr'][k:k + 1].copy_(h.reshape(st['hr'][k:k + 1].shape))
+            if not direct:                                                     # (direct: the render reads the caller's frames)
+                st['hr'][k:k + 1].copy_(h.reshape(st['hr'][k:k + 1].shape))
             c['lrc'][k:k + 1].copy_(l.reshape(c['lrc'][k:k + 1].shape))
         if not self.use_graph:
             self._step_static()
@@ -1175,6 +1233,11 @@ class ThreeViewOnlineStitcher:
         self.frames_in += 1
         if self.grow == 'recapture':
             self._post_watch_copy()
+        if direct:                       # the graph left splines and footprints; the render reads the caller's frames, writes a new tensor
+            src, T, fp = self._deferred
+            shp = st['hr'][0:1].shape
+            return [ops.render_average([hr1.reshape(shp), hr2.reshape(shp), hr3.reshape(shp)], src, T, self.hc, self.wc, self.warp_mode,
+                                       footprint=fp)]
         return [st['out'].clone()]
 
     @torch.no_grad()
@@ -1230,7 +1293,7 @@ class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
         two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
         fh, fw = pipeline.LR_H // 8, pipeline.LR_W // 8
         return {'lrc': two(3, 3, pipeline.LR_H, pipeline.LR_W), 'hr': two(3, 3, self.h, self.w), 'f64': two(3, fh, fw, 128),
-                'feat': two(4, fh, fw, 128), 'off1': two(2, 8), 'out': two(3, self.hc, self.wc)}
+                'feat': two(3, fh, fw, 128), 'off1': two(2, 8), 'out': two(3, self.hc, self.wc)}
 
     def _pipe_state(self):
         return self._state()
@@ -1243,8 +1306,9 @@ class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
         for k, (h, l) in enumerate(((hr1, lr1), (hr2, lr2), (hr3, lr3))):
             with torch.cuda.stream(sa):
                 P['lrc'][p][k:k + 1].copy_(l.reshape(P['lrc'][p][k:k + 1].shape))
-            with torch.cuda.stream(sb):
-                P['hr'][p][k:k + 1].copy_(h.reshape(P['hr'][p][k:k + 1].shape))
+            if not self._direct():           # (direct render: the second stream's render reads the caller's frames)
+                with torch.cuda.stream(sb):
+                    P['hr'][p][k:k + 1].copy_(h.reshape(P['hr'][p][k:k + 1].shape))
             h.record_stream(sb)
             l.record_stream(sa)
 
@@ -1260,10 +1324,16 @@ class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
         ch._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], None, None, None, None)
         m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
         hr = P['hr'][p]
-        self._compose_render(m1, m2, [hr[0:1], hr[1:2], hr[2:3]], P['out'][p])
+        self._compose_render(m1, m2, [hr[0:1], hr[1:2], hr[2:3]], _DEFER if self._direct() else P['out'][p])
 
-    def _pipe_take(self, p):
-        return [self.pipe['out'][p].clone()]
+    def _pipe_take(self, p, hr1, hr2, hr3, lr1, lr2, lr3):
+        P = self.pipe
+        if self._direct():
+            src, T, fp = P['deferred'][p]
+            shp = P['hr'][p][0:1].shape
+            return [ops.render_average([hr1.reshape(shp), hr2.reshape(shp), hr3.reshape(shp)], src, T, self.hc, self.wc, self.warp_mode,
+                                       footprint=fp)]
+        return [P['out'][p].clone()]
 
     def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3):
         return self._push_pipelined(hr1, hr2, hr3, lr1, lr2, lr3)

@@ -584,15 +584,23 @@ def l2norm(x):
     return out
 
 
-def cost_volume(x1, x2, r, out=None):
-    """nhwc in -> nhwc [n,h,w,pad4((2r+1)^2)] (padding channels are zero)."""
+def cost_volume(x1, x2, r, out=None, chain=0):
+    """nhwc in -> nhwc [n,h,w,pad4((2r+1)^2)] (padding channels are zero).
+    chain = S > 0: x1 / x2 hold the S + 1 views of a chain of S pairs ONCE; -> the 2 S volumes [first views | second views] of the
+    pairs (ss_cost_volume_shifted), equal to the volumes of cat(x[:S], x[1:])."""
     n, h, w, c = x1.shape
     d = (2 * r + 1) ** 2
     cs = ((d + 3) // 4) * 4
+    if chain:
+        assert n == chain + 1 and tuple(x2.shape) == tuple(x1.shape)
+        n = 2 * chain
     if out is None:
         out = torch.empty((n, h, w, cs), device=x1.device, dtype=torch.float32)
     assert tuple(out.shape) == (n, h, w, cs)
-    H.call('ss_cost_volume', H.dptr(x1), H.dptr(x2), H.dptr(out), n, h, w, c, r, cs, H.stream())
+    if chain:
+        H.call('ss_cost_volume_shifted', H.dptr(x1), H.dptr(x2), H.dptr(out), n, h, w, c, r, cs, chain, 1 - chain, H.stream())
+    else:
+        H.call('ss_cost_volume', H.dptr(x1), H.dptr(x2), H.dptr(out), n, h, w, c, r, cs, H.stream())
     return out
 
 

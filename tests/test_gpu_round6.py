@@ -478,6 +478,61 @@ def test_three_view_stream_fused_splines_are_frame_neutral(dev, hip_nets, monkey
             assert a[3] <= b[3] - 5
 
 
+def test_direct_render_is_frame_neutral(dev, hip_nets, clip16, monkeypatch):
+    """DIRECT_RENDER (default): the steady-state graph ends with splines and footprints, the AVERAGE render is launched by the push on
+    the caller's own HR frames into a fresh tensor (no copies of the frames into static buffers, no clone of a static canvas).  Frames
+    equal those of the render-inside-the-graph form bit for bit -- plain and pipelined, two and three views; a returned frame is
+    not overwritten by later pushes."""
+    from stabstitch2_amd import online
+    from stabstitch2_amd.online import OnlineStitcher, PipelinedOnlineStitcher, ThreeViewOnlineStitcher, PipelinedThreeViewOnlineStitcher
+    hr, lr = clip16
+    hr = [[f.to(dev) for f in v] for v in hr]
+    lr = [[f.to(dev) for f in v] for v in lr]
+    n = len(hr[0])
+    out = {}
+    for direct in (True, False):
+        monkeypatch.setattr(online, 'DIRECT_RENDER', direct)
+        for cls in (OnlineStitcher, PipelinedOnlineStitcher):
+            st = cls(hip_nets, hr[0][0].shape[-2], hr[0][0].shape[-1])
+            frames = []
+            for t in range(20):
+                i = t % n
+                frames += st.push(hr[0][i], hr[1][i], lr[0][i], lr[1][i])
+            if hasattr(st, 'flush'):
+                frames += st.flush()
+            torch.cuda.synchronize()
+            out[(direct, cls.__name__)] = [f.clone() for f in frames]
+            if direct and cls is OnlineStitcher:
+                assert st._direct() and frames[-1].data_ptr() != frames[-2].data_ptr()
+    for name in ('OnlineStitcher', 'PipelinedOnlineStitcher'):
+        a, b = out[(True, name)], out[(False, name)]
+        assert len(a) == len(b) == 20
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    h, w = 180, 320
+    hr3, lr3 = synth.make_clip(12, h, w, seed=8, views=3)
+    hr3 = [[f.to(dev) for f in v] for v in hr3]
+    lr3 = [[f.to(dev) for f in v] for v in lr3]
+    out3 = {}
+    for direct in (True, False):
+        monkeypatch.setattr(online, 'DIRECT_RENDER', direct)
+        for cls in (ThreeViewOnlineStitcher, PipelinedThreeViewOnlineStitcher):
+            st = cls(hip_nets, h, w)
+            frames = []
+            for t in range(16):
+                i = t % 12
+                frames += st.push(hr3[0][i], hr3[1][i], hr3[2][i], lr3[0][i], lr3[1][i], lr3[2][i])
+            if hasattr(st, 'flush'):
+                frames += st.flush()
+            torch.cuda.synchronize()
+            out3[(direct, cls.__name__)] = frames
+    for name in ('ThreeViewOnlineStitcher', 'PipelinedThreeViewOnlineStitcher'):
+        a, b = out3[(True, name)], out3[(False, name)]
+        assert len(a) == len(b) == 16
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_tps_solve_round6_kernel_against_round4(dev, request):
     """tps_solve_kernel of round 6 (four waves, lane = row, one barrier per column, pivot search under the previous update) against
     the round-4 kernel kept in the tuning build (`ss_tps_solve_r4`): same pivot rule and factors, the update an fma instead of
