@@ -496,7 +496,7 @@ class _TwoInFlight:
                     fn(p)
                 self.pipe[key][p] = g
                 if key == 'gb':              # (direct render: the second half left this parity's splines and footprints)
-                    self.pipe.setdefault('deferred', [None, None])[p] = getattr(self, '_deferred', None)
+                    self.pipe.setdefault('deferred', [None, None])[p] = self._pipe_deferred()
                 if p == 0:
                     n = _graph_nodes(g)
                     nodes = None if nodes is None or n is None else nodes + n
@@ -593,6 +593,9 @@ class _TwoInFlight:
         self._t += 1
         self.frames_in += 1
         return self._hand_out(prev)
+
+    def _pipe_deferred(self):
+        return getattr(self, '_deferred', None)
 
     def _hand_out(self, item):
         if item is None:
@@ -1041,8 +1044,9 @@ class PipelinedMultiOnlineStitcher(_TwoInFlight, MultiOnlineStitcher):
         P = self.pipe
         with torch.cuda.stream(sa):
             P['lr'][p][0].copy_(lr1); P['lr'][p][1].copy_(lr2)
-        with torch.cuda.stream(sb):
-            P['hr'][p][0].copy_(hr1); P['hr'][p][1].copy_(hr2)
+        if not self._direct():               # (direct render: the second stream's render reads the caller's frames)
+            with torch.cuda.stream(sb):
+                P['hr'][p][0].copy_(hr1); P['hr'][p][1].copy_(hr2)
         for t in (hr1, hr2):
             t.record_stream(sb)
         for t in (lr1, lr2):
@@ -1057,10 +1061,29 @@ class PipelinedMultiOnlineStitcher(_TwoInFlight, MultiOnlineStitcher):
 
     def _run_b(self, p):
         P = self.pipe
-        self._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], P['hr'][p][0], P['hr'][p][1], P['out_all'][p], P['out'][p])
+        self._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], P['hr'][p][0], P['hr'][p][1], P['out_all'][p], P['out'][p],
+                      defer=self._direct())
 
-    def _pipe_take(self, p, *inputs):
-        return [[o.clone()] for o in self.pipe['out'][p]]
+    def _pipe_deferred(self):
+        if self.static['out_all'] is not None:
+            return getattr(self, '_deferred', None)
+        return [getattr(one, '_deferred', None) for one in self.single]
+
+    def _pipe_take(self, p, hr1, hr2, lr1, lr2):
+        P = self.pipe
+        if not self._direct():
+            return [[o.clone()] for o in P['out'][p]]
+        hr1, hr2 = hr1.reshape(P['hr'][p][0].shape), hr2.reshape(P['hr'][p][1].shape)
+        if self.static['out_all'] is not None:
+            src, T, fp = P['deferred'][p]
+            one = self.single[0]
+            frames = ops.render_average_clip([hr1.contiguous(), hr2.contiguous()], src, T, one.hc, one.wc, self.warp_mode, footprint=fp)
+            return [[frames[s]] for s in range(self.S)]
+        res = []
+        for s, one in enumerate(self.single):
+            src, T, fp = P['deferred'][p][s]
+            res.append([ops.render_average([hr1[s:s + 1], hr2[s:s + 1]], src, T, one.hc, one.wc, self.warp_mode, footprint=fp)])
+        return res
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         return self._push_pipelined(hr1, hr2, lr1, lr2)
