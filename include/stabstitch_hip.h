@@ -381,6 +381,13 @@ SS_API int ss_three_view_splines(const float* w12_m1, const float* w12_m2, const
                                  long long mesh_frame_stride, const float* first_box, const float* out_box, const float* nrigid,
                                  float* mesh1, float* middle, float* mesh3, float* src, float* T, int frames, float img_h,
                                  float img_w, void* stream);
+/* A streaming push's render splines as ONE launch (views x streams workgroups): ss_stream_normalize_watch's normalisation of
+ * every view's newest mesh on its stream's canvas (same arguments) + ss_tps_solve_shared_target onto `nrigid`; -> src
+ * [streams][views][63][2], T [streams][views][2][66].  Bit-identical to the two launches; the watcher is NOT updated here
+ * (ss_render_footprints_watch or ss_canvas_watch on `src`). */
+SS_API int ss_stream_splines(const float* const* meshes, int views, long long mesh_frame_stride, const float* bboxes,
+                             int bbox_frame_stride, const float* nrigid, float* src, float* T, int streams, float img_h,
+                             float img_w, void* stream);
 /* Streaming mode (stabstitch2_amd/online.py): the reference sizes the canvas from ALL frames of the clip (test_online_tra.py:
  * 106-120); a live stream fixes it after its first window, so a mesh that drifts past it later would be cropped silently.  This
  * launch (one wave per stream, capturable) looks at the push's control points src [streams][views][63][2], already normalised to

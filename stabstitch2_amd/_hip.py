@@ -99,6 +99,7 @@ SIGNATURES = {
     'ss_three_view_align': (c_i, [c_fp] * 9 + [c_i, c_f, c_f, c_st]),
     'ss_three_view_finish': (c_i, [c_fp] * 7 + [c_ll, c_st]),
     'ss_three_view_splines': (c_i, [c_fp] * 4 + [c_ll] + [c_fp] * 8 + [c_i, c_f, c_f, c_st]),
+    'ss_stream_splines': (c_i, [ctypes.c_void_p, c_i, c_ll, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_f, c_f, c_st]),
     'ss_three_view_normalize': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_st]),
     'ss_smooth_embed': (c_i, [c_fp] * 9 + [c_i] * 4 + [c_st]),
     'ss_smooth_finalize': (c_i, [c_fp] * 13 + [c_i] * 4 + [c_st]),

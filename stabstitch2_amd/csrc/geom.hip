@@ -1255,3 +1255,55 @@ extern "C" int ss_three_view_splines(const float* w12_m1, const float* w12_m2, c
     hipLaunchKernelGGL(three_view_splines_kernel, dim3(3, frames), dim3(64 * TPS_NW), 0, (hipStream_t)stream, p);
     return ss_launch_status();
 }
+
+// A streaming push's render splines as ONE launch: workgroup (view v, stream f) normalises its mesh on the stream's canvas
+// (stream_normalize_watch_kernel's arithmetic) and solves the spline onto the rigid mesh (tps_solve_shared_target) -- it was a
+// normalisation launch and a solve launch; the watcher moves into the footprint launch (ss_render_footprints_watch).
+struct StreamSplinesP {
+    const float* m[3];
+    long long mesh_fs;
+    const float *bbox, *nrigid;
+    int bbox_fs;
+    float *src, *T;
+    int views;
+    float img_h, img_w;
+};
+__global__ __launch_bounds__(64 * TPS_NW) void stream_splines_kernel(StreamSplinesP p) {
+    __shared__ TpsShared sh;
+    __shared__ float tg[SS_NV * 2];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const long long f = blockIdx.y;
+    if (tid < SS_NV) {
+        const float* bb = p.bbox + f * p.bbox_fs;
+        const float wmin = bb[0], hmin = bb[2];
+        const float ow = __fsub_rn(bb[1], wmin), oh = __fsub_rn(bb[3], hmin);
+        const float* mesh = v == 0 ? p.m[0] : (v == 1 ? p.m[1] : p.m[2]);
+        const float* m = mesh + f * p.mesh_fs + tid * 2;
+        const float x = p.img_w > 0.f ? __fmul_rn(m[0], p.img_w) / 480.0f : m[0];
+        const float y = p.img_h > 0.f ? __fmul_rn(m[1], p.img_h) / 360.0f : m[1];
+        const float nx = norm1(__fsub_rn(x, wmin), ow), ny = norm1(__fsub_rn(y, hmin), oh);
+        sh.sx[tid] = nx; sh.sy[tid] = ny;
+        float* so = p.src + ((f * p.views + v) * SS_NV + tid) * 2;
+        so[0] = nx; so[1] = ny;
+        tg[2 * tid] = p.nrigid[2 * tid]; tg[2 * tid + 1] = p.nrigid[2 * tid + 1];
+    }
+    __syncthreads();
+    tps_eliminate(sh, tg, p.T + (f * p.views + v) * 2 * SS_NT, tid & 63, __builtin_amdgcn_readfirstlane(tid >> 6));
+}
+
+extern "C" int ss_stream_splines(const float* const* meshes, int views, long long mesh_frame_stride, const float* bboxes,
+                                 int bbox_frame_stride, const float* nrigid, float* src, float* T, int streams, float img_h,
+                                 float img_w, void* stream) {
+    if (!meshes || !bboxes || !nrigid || !src || !T || streams <= 0 || streams > 65535 || views <= 0 || views > 3 || mesh_frame_stride < 0 ||
+        (bbox_frame_stride != 0 && bbox_frame_stride != 4))
+        return SS_ERR_ARG;
+    StreamSplinesP p;
+    for (int v = 0; v < 3; ++v) {
+        p.m[v] = v < views ? meshes[v] : nullptr;
+        if (v < views && !p.m[v]) return SS_ERR_ARG;
+    }
+    p.mesh_fs = mesh_frame_stride; p.bbox = bboxes; p.bbox_fs = bbox_frame_stride; p.nrigid = nrigid; p.src = src; p.T = T;
+    p.views = views; p.img_h = img_h; p.img_w = img_w;
+    hipLaunchKernelGGL(stream_splines_kernel, dim3(views, streams), dim3(64 * TPS_NW), 0, (hipStream_t)stream, p);
+    return ss_launch_status();
+}

@@ -237,6 +237,9 @@ class OnlineStitcher:
     @torch.no_grad()
     def _render(self, hr1, hr2, mesh1, mesh2, out=None):
         """mesh* [1,7,9,2] LR-scale smoothed meshes of ONE frame -> stitched frame [3,Hc,Wc] (written to `out` if given)."""
+        if FUSED_SPLINES:                    # control points + splines in one launch, the watcher inside the footprint launch
+            src4, T4 = ops.stream_splines([mesh1, mesh2], 126, self.bbox, self.nrigid, self.h, self.w)
+            return self._render_solved(hr1, hr2, src4[0], T4[0], out, watch=(self._guard(), self.watch_i, self.watch_f))
         src4 = ops.stream_normalize_watch([mesh1, mesh2], 126, self.bbox, self.h, self.w, self._guard(), self.watch_i,
                                           self.watch_f)                                      # [1,2,63,2], watcher updated
         src = src4[0]
@@ -247,12 +250,16 @@ class OnlineStitcher:
         """Does the steady-state push launch its render itself (DIRECT_RENDER), outside the graph?"""
         return bool(DIRECT_RENDER and self.use_graph and self.fusion_mode == 'AVERAGE' and not self.meshes_only)
 
-    def _render_solved(self, hr1, hr2, src, T, out=None):
-        """src [2,63,2] normalised control points on this stream's canvas, T [2,2,66] their splines -> stitched frame."""
+    def _render_solved(self, hr1, hr2, src, T, out=None, watch=None):
+        """src [2,63,2] normalised control points on this stream's canvas, T [2,2,66] their splines -> stitched frame.
+        watch = (guard, watch_i [1,4], watch_f [1,4]): the overflow watcher has not seen `src` yet."""
+        if watch is not None and not (self.fusion_mode == 'AVERAGE' and pipeline.SKIP_OUTSIDE):
+            ops.canvas_watch(src[None], watch[1], watch[2], watch[0])            # no footprint launch to carry it
+            watch = None
         if self.fusion_mode == 'AVERAGE':
             fp = None
             if pipeline.SKIP_OUTSIDE:        # same footprint skipping as the offline render (pipeline.render_frames)
-                fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc)[0]
+                fp = ops.render_footprints(src[None], T[None], self.h, self.w, self.hc, self.wc, watch=watch)[0]
             if out is _DEFER:
                 self._deferred = (src, T, fp)
                 return None
@@ -905,14 +912,23 @@ class MultiOnlineStitcher:
             return
         # every stream's newest smoothed mesh on its own canvas: one normalisation launch per view and ONE batched TPS solve for
         # the 2 S splines (a solve is latency-bound, ~48 us whether it holds 2 systems or 16), then the render stream by stream
-        src = ops.stream_normalize_watch([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w, self.single[0]._guard(),
-                                         st['watch_i'], st['watch_f'])                                             # [S,2,63,2]
-        T = ops.tps_solve_shared(src.view(2 * S, 63, 2), self.single[0].nrigid).view(S, 2, 2, 66)
+        guard = self.single[0]._guard()
+        watch = None
+        if FUSED_SPLINES:                    # control points + splines in one launch; the watcher rides on the footprint launch(es)
+            src, T = ops.stream_splines([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.single[0].nrigid, self.h, self.w)
+            if self.fusion_mode == 'AVERAGE' and pipeline.SKIP_OUTSIDE:
+                watch = (guard, st['watch_i'], st['watch_f'])
+            else:
+                ops.canvas_watch(src, st['watch_i'], st['watch_f'], guard)
+        else:
+            src = ops.stream_normalize_watch([m1[0, -1], m2[0, -1]], WINDOW * e, st['bboxes'], self.h, self.w, guard,
+                                             st['watch_i'], st['watch_f'])                                         # [S,2,63,2]
+            T = ops.tps_solve_shared(src.view(2 * S, 63, 2), self.single[0].nrigid).view(S, 2, 2, 66)
         if out_all is not None:
             # all streams render onto canvases of ONE size (e.g. the caller fixed them): the S current frames are a clip
             hc, wc = self.single[0].hc, self.single[0].wc
             if self.fusion_mode == 'AVERAGE':
-                fp = ops.render_footprints(src, T, self.h, self.w, hc, wc) if pipeline.SKIP_OUTSIDE else None
+                fp = ops.render_footprints(src, T, self.h, self.w, hc, wc, watch=watch) if pipeline.SKIP_OUTSIDE else None
                 if defer:
                     self._deferred = (src, T, fp)
                     return
@@ -921,7 +937,8 @@ class MultiOnlineStitcher:
                 ops.render_linear_clip([hr1, hr2], src, T, hc, wc, self.warp_mode, out=out_all)
             return
         for s, one in enumerate(self.single):
-            one._render_solved(hr1[s:s + 1], hr2[s:s + 1], src[s], T[s], out=_DEFER if defer else out[s])
+            one._render_solved(hr1[s:s + 1], hr2[s:s + 1], src[s], T[s], out=_DEFER if defer else out[s],
+                               watch=None if watch is None else (guard, st['watch_i'][s:s + 1], st['watch_f'][s:s + 1]))
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         st = self.static

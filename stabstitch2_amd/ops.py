@@ -1033,6 +1033,23 @@ def stream_normalize_watch(meshes, frame_stride, bboxes, img_h, img_w, guard=0.0
     return out
 
 
+def stream_splines(meshes, frame_stride, bboxes, nrigid, img_h, img_w):
+    """One push's render control points AND their splines in ONE launch (ss_stream_splines): arguments as stream_normalize_watch
+    -> (src [S,V,63,2], T [S,V,2,66]), equal bit for bit to stream_normalize_watch + tps_solve_shared.  The overflow watcher is not
+    touched: render_footprints(..., watch=...) or canvas_watch(src, ...)."""
+    v = len(meshes)
+    s = 1 if bboxes.dim() == 1 else bboxes.shape[0]
+    for m in meshes:
+        assert m.is_contiguous() and m.dtype == torch.float32
+    assert nrigid.numel() == 126 and nrigid.is_contiguous()
+    src = torch.empty((s, v, 63, 2), device=bboxes.device, dtype=torch.float32)
+    T = torch.empty((s, v, 2, 66), device=bboxes.device, dtype=torch.float32)
+    arr = H.ptr_array(list(meshes))
+    H.call('ss_stream_splines', arr, v, int(frame_stride), H.dptr(bboxes), 0 if bboxes.dim() == 1 else 4, H.dptr(nrigid), H.dptr(src),
+           H.dptr(T), s, float(img_h), float(img_w), H.stream())
+    return src, T
+
+
 def mesh_normalize_views_boxes(meshes, frame_stride, bboxes, img_h, img_w):
     """Per-frame canvases: meshes = list of V tensors whose frame f starts `frame_stride` floats after frame f - 1 (the tensor
     handed in starts at frame 0's mesh); bboxes [n,4] -> [n,V,63,2]."""

@@ -244,15 +244,15 @@ def test_streaming_canvas_overflow_is_detected_and_grown(dev, hip_nets, clip16, 
     n = 44
     # --- never: count + first frame, against the meshes themselves
     seen = []
-    real = ops.stream_normalize_watch          # (round 6: normalisation of both views + the watcher are one launch)
+    real = ops.stream_splines                  # (round 6: normalisation of both views + their splines are one launch)
 
     def spy(meshes, *a, **k):
         seen.append(torch.stack([m.reshape(-1, 2).clone() for m in meshes], 0))       # [2,63,2] LR px
         return real(meshes, *a, **k)
     st = OnlineStitcher(hip_nets, 360, 480, use_graph=False)
-    monkeypatch.setattr(ops, 'stream_normalize_watch', spy)
+    monkeypatch.setattr(ops, 'stream_splines', spy)
     _push_drifting(st, hip_nets, hrd, lrd, n)
-    monkeypatch.setattr(ops, 'stream_normalize_watch', real)
+    monkeypatch.setattr(ops, 'stream_splines', real)
     assert len(seen) == n
     bb = st.bbox.cpu()
     first = -1

@@ -430,6 +430,40 @@ def test_three_view_splines_equal_the_seven_launches(dev):
             assert int(wi0[:, 1].sum()) > 0            # the second box is too small on purpose: the watcher has something to say
 
 
+def test_stream_splines_equal_normalise_plus_solve(dev):
+    """ss_stream_splines (control points + splines of every view and stream in one launch) == stream_normalize_watch +
+    tps_solve_shared bit for bit, one canvas for all streams and a canvas per stream, LR-scale and canvas-pixel meshes; the watcher
+    through render_footprints(watch=...) per stream slice equals stream_normalize_watch's."""
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.spatial_network import get_rigid_mesh, get_norm_mesh
+    h, w = 720, 1280
+    g = torch.Generator().manual_seed(12)
+    nrigid = get_norm_mesh(get_rigid_mesh(1, h, w, device=dev), h, w).contiguous()
+    rigid_lr = get_rigid_mesh(1, 360, 480, device='cpu').reshape(1, 7, 9, 2)
+    S = 3
+    for views in (2, 3):
+        meshes = [(rigid_lr + 8.0 * torch.randn((S, 7, 9, 2), generator=g) + torch.tensor([150.0 * v, 2.0 * v])).to(dev).contiguous()
+                  for v in range(views)]
+        for boxes in (torch.tensor([-30.0, 2700.0, -40.0, 780.0], device=dev),
+                      torch.tensor([[-30.0, 2700.0, -40.0, 780.0], [0.0, 2000.0, 0.0, 700.0], [-100.0, 3000.0, -90.0, 900.0]], device=dev)):
+            wi0, wf0 = ops.canvas_watch_state(S if boxes.dim() == 2 else 1, dev)
+            if boxes.dim() == 1:
+                continue_streams = 1
+                ms = [m[:1].contiguous() for m in meshes]
+            else:
+                ms = meshes
+            ref = ops.stream_normalize_watch(ms, 126, boxes, h, w, 0.02, wi0, wf0)
+            T_ref = ops.tps_solve_shared(ref.reshape(-1, 63, 2), nrigid).reshape(ref.shape[0], views, 2, 66)
+            src, T = ops.stream_splines(ms, 126, boxes, nrigid, h, w)
+            torch.cuda.synchronize()
+            assert torch.equal(src, ref) and torch.equal(T, T_ref)
+            wi1, wf1 = ops.canvas_watch_state(src.shape[0], dev)
+            for s_ in range(src.shape[0]):
+                ops.render_footprints(src[s_:s_ + 1], T[s_:s_ + 1], h, w, 800, 2800, watch=(0.02, wi1[s_:s_ + 1], wf1[s_:s_ + 1]))
+            torch.cuda.synchronize()
+            assert torch.equal(wi1, wi0) and torch.equal(wf1, wf0)
+
+
 def test_chain_pairs_share_their_launches(dev):
     """A chain of pairs (view 1, view 2), (view 2, view 3) reads views [0:2] and [1:3] of one trunk output: the feature normalisation
     of ss_ccl and the homography warp take them as ONE launch (overlapping inputs) -- results equal to separate tensors."""
