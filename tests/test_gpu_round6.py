@@ -481,6 +481,14 @@ def test_chain_pairs_share_their_launches(dev):
     torch.cuda.synchronize()
     assert torch.equal(w1, r1) and torch.equal(w2, r2)
     assert w2.data_ptr() == w1.data_ptr() + w1.numel() * 4          # one launch: one output tensor
+    # temporal cost volumes of a chain of S pairs from the S + 1 views stored once == the volumes of the concatenated layout
+    for S in (1, 2, 4):
+        prev = torch.randn((S + 1, 45, 60, 128), generator=g).to(dev)
+        cur = torch.randn((S + 1, 45, 60, 128), generator=g).to(dev)
+        got = ops.cost_volume(prev, cur, 3, chain=S)
+        ref = ops.cost_volume(torch.cat((prev[:S], prev[1:]), 0), torch.cat((cur[:S], cur[1:]), 0), 3)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape and torch.equal(got, ref)
 
 
 def test_three_view_stream_fused_splines_are_frame_neutral(dev, hip_nets, monkeypatch):
