@@ -1068,7 +1068,7 @@ extern "C" int ss_nhwc_to_nchw(const float* in, float* out, int n, int c, int h,
     return ss_launch_status();
 }
 
-extern "C" int ss_version(void) { return 500; }
+extern "C" int ss_version(void) { return 600; }
 
 extern "C" const char* ss_error_string(int code) {
     switch (code) {
