@@ -651,8 +651,10 @@ class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
     def _pipe_alloc(self):
         d = self.dev
         two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
-        return {'lr': two(2, 1, 3, pipeline.LR_H, pipeline.LR_W), 'hr1': two(1, 3, self.h, self.w), 'hr2': two(1, 3, self.h, self.w),
-                'f2': two(2, 2, pipeline.LR_H // 8, pipeline.LR_W // 8, 128), 'off1': two(1, 8), 'out': two(3, self.hc, self.wc)}
+        hr = (lambda: [None, None]) if self._direct() else (lambda: two(1, 3, self.h, self.w))     # direct render: no copies of the frames
+        return {'lr': two(2, 1, 3, pipeline.LR_H, pipeline.LR_W), 'hr1': hr(), 'hr2': hr(),
+                'f2': two(2, 2, pipeline.LR_H // 8, pipeline.LR_W // 8, 128), 'off1': two(1, 8),
+                'out': [None, None] if self._direct() else two(3, self.hc, self.wc)}
 
     def _pipe_state(self):
         return [self.static[k] for k in self._STATE] + [self.watch_i, self.watch_f]
@@ -688,7 +690,8 @@ class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
         P = self.pipe
         if self._direct():
             src, T, fp = P['deferred'][p]
-            return [ops.render_average([hr1.reshape(P['hr1'][p].shape), hr2.reshape(P['hr2'][p].shape)], src, T, self.hc, self.wc,
+            shp = (1, 3, self.h, self.w)
+            return [ops.render_average([hr1.reshape(shp), hr2.reshape(shp)], src, T, self.hc, self.wc,
                                        self.warp_mode, footprint=fp)]
         return [P['out'][p].clone()]
 
@@ -937,7 +940,7 @@ class MultiOnlineStitcher:
                 ops.render_linear_clip([hr1, hr2], src, T, hc, wc, self.warp_mode, out=out_all)
             return
         for s, one in enumerate(self.single):
-            one._render_solved(hr1[s:s + 1], hr2[s:s + 1], src[s], T[s], out=_DEFER if defer else out[s],
+            one._render_solved(None if defer else hr1[s:s + 1], None if defer else hr2[s:s + 1], src[s], T[s], out=_DEFER if defer else out[s],
                                watch=None if watch is None else (guard, st['watch_i'][s:s + 1], st['watch_f'][s:s + 1]))
 
     def _push_static(self, hr1, hr2, lr1, lr2):
@@ -1041,7 +1044,8 @@ class PipelinedMultiOnlineStitcher(_TwoInFlight, MultiOnlineStitcher):
         d, S = self.dev, self.S
         two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
         fh, fw = pipeline.LR_H // 8, pipeline.LR_W // 8
-        P = {'lr': two(2, S, 3, pipeline.LR_H, pipeline.LR_W), 'hr': two(2, S, 3, self.h, self.w),
+        P = {'lr': two(2, S, 3, pipeline.LR_H, pipeline.LR_W),
+             'hr': [[None, None], [None, None]] if self._direct() else two(2, S, 3, self.h, self.w),     # (direct render: no copies)
              'f64': two(2 * S, fh, fw, 128), 'feat': two(2 * S, fh, fw, 128), 'off1': two(S, 8)}
         if self.static['out_all'] is not None:
             P['out_all'] = two(*self.static['out_all'].shape)
@@ -1090,7 +1094,7 @@ class PipelinedMultiOnlineStitcher(_TwoInFlight, MultiOnlineStitcher):
         P = self.pipe
         if not self._direct():
             return [[o.clone()] for o in P['out'][p]]
-        hr1, hr2 = hr1.reshape(P['hr'][p][0].shape), hr2.reshape(P['hr'][p][1].shape)
+        hr1, hr2 = hr1.reshape(self.S, 3, self.h, self.w), hr2.reshape(self.S, 3, self.h, self.w)
         if self.static['out_all'] is not None:
             src, T, fp = P['deferred'][p]
             one = self.single[0]
@@ -1332,8 +1336,9 @@ class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
         d = self.dev
         two = lambda *shape: [torch.empty(shape, device=d) for _ in range(2)]
         fh, fw = pipeline.LR_H // 8, pipeline.LR_W // 8
-        return {'lrc': two(3, 3, pipeline.LR_H, pipeline.LR_W), 'hr': two(3, 3, self.h, self.w), 'f64': two(3, fh, fw, 128),
-                'feat': two(3, fh, fw, 128), 'off1': two(2, 8), 'out': two(3, self.hc, self.wc)}
+        return {'lrc': two(3, 3, pipeline.LR_H, pipeline.LR_W), 'hr': [None, None] if self._direct() else two(3, 3, self.h, self.w),
+                'f64': two(3, fh, fw, 128),
+                'feat': two(3, fh, fw, 128), 'off1': two(2, 8), 'out': [None, None] if self._direct() else two(3, self.hc, self.wc)}
 
     def _pipe_state(self):
         return self._state()
@@ -1364,13 +1369,14 @@ class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
         ch._stage_b(P['f64'][p], P['feat'][p], P['off1'][p], None, None, None, None)
         m1, m2 = ch.last_meshes                                  # [2,1,7,9,2]: stream 0 = pair (1,2), stream 1 = pair (2,3)
         hr = P['hr'][p]
-        self._compose_render(m1, m2, [hr[0:1], hr[1:2], hr[2:3]], _DEFER if self._direct() else P['out'][p])
+        imgs = None if hr is None else [hr[0:1], hr[1:2], hr[2:3]]
+        self._compose_render(m1, m2, imgs, _DEFER if self._direct() else P['out'][p])
 
     def _pipe_take(self, p, hr1, hr2, hr3, lr1, lr2, lr3):
         P = self.pipe
         if self._direct():
             src, T, fp = P['deferred'][p]
-            shp = P['hr'][p][0:1].shape
+            shp = (1, 3, self.h, self.w)
             return [ops.render_average([hr1.reshape(shp), hr2.reshape(shp), hr3.reshape(shp)], src, T, self.hc, self.wc, self.warp_mode,
                                        footprint=fp)]
         return [P['out'][p].clone()]
