@@ -333,8 +333,8 @@ def path_traffic(pmc, algorithmic_bytes_per_step):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--frames', type=int, default=32)
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
