@@ -613,6 +613,21 @@ def other_configs(nets, dev, args):
                'frames bit-identical to OnlineStitcher, handed out one push late (flush() for the last)')
     res['720p 2-view streaming, two pushes in flight (opt-in PipelinedOnlineStitcher)']['graph_nodes'] = stp.graph_nodes
     del stp
+    # the reference's own frame loop shape: decoded uint8 frames in (cv2.imread's layout), uint8 video frames out (push_u8)
+    st8 = OnlineStitcher(nets, 720, 1280)
+    u8 = [[hr[v][i].clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous() for i in range(n)] for v in range(2)]
+    for t in range(12):
+        st8.push_u8(u8[0][t], u8[1][t])
+    sync()
+    t0 = time.perf_counter()
+    for t in range(200):
+        i = t % n
+        st8.push_u8(u8[0][i], u8[1][i])
+    sync()
+    entry('720p 2-view streaming from decoded uint8 frames to uint8 video frames (push_u8)', 200, time.perf_counter() - t0, 1, st8.hc, st8.wc,
+          note='device-resident uint8 [H,W,3] frames in, uint8 [Hc,Wc,3] out; the cv2-exact resize feeds the graph, the render samples '
+               'the uint8 frames and writes the uint8 frame: byte for byte ingest_u8 -> push -> canvas_to_u8')
+    del st8, u8
     std = OnlineStitcher(nets, 720, 1280, deterministic=True)
     for t in range(12):
         std.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
@@ -1046,7 +1061,7 @@ def main():
                 'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
                 'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push'),
                 'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
-                'streaming_pipelined_fps': pick('streaming, two pushes in flight'),
+                'streaming_pipelined_fps': pick('streaming, two pushes in flight'), 'streaming_u8_fps': pick('streaming from decoded uint8'),
                 'streaming_8_streams_pipelined_fps': pick('streams per push, two pushes in flight'),
                 'three_view_streaming_pipelined_fps': pick('3-view streaming, two pushes in flight'),
                 'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),

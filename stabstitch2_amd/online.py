@@ -341,7 +341,7 @@ class OnlineStitcher:
     def _versions(self):
         return (self.spatial.weights_version, self.temporal.weights_version, self.smooth.weights_version)
 
-    def _push_static(self, hr1, hr2, lr1, lr2):
+    def _push_static(self, hr1, hr2, lr1, lr2, u8=None):
         st = self.static
         if self.grow == 'recapture' and not self.meshes_only:
             self._poll_growth()
@@ -351,9 +351,13 @@ class OnlineStitcher:
             self.trunk_pair = None
             self.graph = None
         direct = self._direct()
-        if not self.meshes_only and not direct:      # (meshes_only: the frames are not looked at, None will do; direct: rendered in place)
-            st['hr1'].copy_(hr1.reshape(st['hr1'].shape)); st['hr2'].copy_(hr2.reshape(st['hr2'].shape))
-        st['lr1'].copy_(lr1.reshape(st['lr1'].shape)); st['lr2'].copy_(lr2.reshape(st['lr2'].shape))
+        if u8 is not None:                   # decoded uint8 frames (push_u8): the cv2-exact resize writes the graph's LR buffers itself
+            ops.ingest_u8(u8[0][None], pipeline.LR_H, pipeline.LR_W, want_hr=False, lr_out=st['lr1'])
+            ops.ingest_u8(u8[1][None], pipeline.LR_H, pipeline.LR_W, want_hr=False, lr_out=st['lr2'])
+        else:
+            if not self.meshes_only and not direct:  # (meshes_only: the frames are not looked at, None will do; direct: rendered in place)
+                st['hr1'].copy_(hr1.reshape(st['hr1'].shape)); st['hr2'].copy_(hr2.reshape(st['hr2'].shape))
+            st['lr1'].copy_(lr1.reshape(st['lr1'].shape)); st['lr2'].copy_(lr2.reshape(st['lr2'].shape))
         if not self.use_graph:
             self._step_static()
         elif self.graph is None:
@@ -387,6 +391,8 @@ class OnlineStitcher:
             self._post_watch_copy()
         if direct:                       # the graph left splines and footprints; the render reads the caller's frames, writes a new tensor
             src, T, fp = self._deferred
+            if u8 is not None:               # uint8 frames in, the uint8 video frame out: no fp32 frame planes, no fp32 canvas
+                return [ops.render_average_u8([u8[0], u8[1]], src, T, self.hc, self.wc, self.warp_mode, footprint=fp)]
             return [ops.render_average([hr1.reshape(st['hr1'].shape), hr2.reshape(st['hr2'].shape)], src, T, self.hc, self.wc,
                                        self.warp_mode, footprint=fp)]
         return [st['out'].clone()]
@@ -398,6 +404,24 @@ class OnlineStitcher:
         meshes_only: -> None for the first 6 pushes, then (m1, m2) [k,7,9,2] (k = 7 on the 7th push, then 1)."""
         with ops.deterministic(self.deterministic):
             return self._push(hr1, hr2, lr1, lr2)
+
+    @torch.no_grad()
+    def push_u8(self, img1, img2):
+        """One DECODED frame pair: img* uint8 [H,W,3] device tensors in cv2.imread's layout and channel order (the reference's frame
+        loop, test_online_tra.py:252-278) -> list of stitched VIDEO frames uint8 [Hc,Wc,3] (`.astype(np.uint8)` of the fused values,
+        :413), empty for the first 6 pushes, 7 frames on the 7th, then one per push.  Byte for byte ops.ingest_u8 -> push ->
+        ops.canvas_to_u8; in the steady state (DIRECT_RENDER, fusion AVERAGE) the cv2-exact resize writes the graph's LR inputs and
+        the render samples the uint8 frames and writes the uint8 frame itself: no fp32 frame planes, no fp32 canvas."""
+        if self.meshes_only:
+            raise ValueError('push_u8 renders frames: not for meshes_only stitchers')
+        if img1.dtype != torch.uint8 or img1.dim() != 3 or img1.shape[-1] != 3 or tuple(img1.shape) != tuple(img2.shape):
+            raise ValueError('push_u8 takes two uint8 [H,W,3] frames')
+        with ops.deterministic(self.deterministic):
+            if self.static is not None and self._direct() and type(self)._push_static is OnlineStitcher._push_static:
+                return self._push_static(None, None, None, None, u8=(img1.contiguous(), img2.contiguous()))
+            hr, lr = ops.ingest_u8(torch.stack((img1, img2), 0), pipeline.LR_H, pipeline.LR_W)
+            frames = self._push(hr[0:1], hr[1:2], lr[0:1], lr[1:2])
+            return [ops.canvas_to_u8(f.reshape((1,) + tuple(f.shape[-3:])))[0] for f in frames]
 
     def _push(self, hr1, hr2, lr1, lr2):
         if self.static is not None:
@@ -617,6 +641,12 @@ class _TwoInFlight:
         """-> the result of the newest push (what `push` would have returned one push later), valid on the caller's stream."""
         item, self._pending = self._pending, None
         return self._hand_out(item)
+
+    def flush_u8(self):
+        """`flush()` for streams fed through push_u8: the last result as uint8 video frames."""
+        def conv(x):
+            return ops.canvas_to_u8(x.reshape((1,) + tuple(x.shape[-3:])))[0] if torch.is_tensor(x) else [conv(y) for y in x]
+        return conv(self.flush())
 
     def overflow_report(self):
         if getattr(self, 'pipe', None) is not None:
@@ -1239,7 +1269,7 @@ class ThreeViewOnlineStitcher:
     def _state(self):
         return [self.chains.static[k] for k in MultiOnlineStitcher._STATE] + [self.watch_i, self.watch_f]
 
-    def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3):
+    def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3, u8=None):
         c, st = self.chains.static, self.static
         if self.grow == 'recapture':
             self._poll_growth()
@@ -1249,6 +1279,9 @@ class ThreeViewOnlineStitcher:
             self.versions = self._versions()
         direct = self._direct()
         for k, (h, l) in enumerate(((hr1, lr1), (hr2, lr2), (hr3, lr3))):      # each view once: three frames, three LR frames
+            if u8 is not None:                                                 # decoded uint8 frames: resized into the graph's LR inputs
+                ops.ingest_u8(u8[k][None], pipeline.LR_H, pipeline.LR_W, want_hr=False, lr_out=c['lrc'][k:k + 1])
+                continue
             if not direct:                                                     # (direct: the render reads the caller's frames)
                 st['hr'][k:k + 1].copy_(h.reshape(st['hr'][k:k + 1].shape))
             c['lrc'][k:k + 1].copy_(l.reshape(c['lrc'][k:k + 1].shape))
@@ -1279,10 +1312,25 @@ class ThreeViewOnlineStitcher:
             self._post_watch_copy()
         if direct:                       # the graph left splines and footprints; the render reads the caller's frames, writes a new tensor
             src, T, fp = self._deferred
+            if u8 is not None:
+                return [ops.render_average_u8(list(u8), src, T, self.hc, self.wc, self.warp_mode, footprint=fp)]
             shp = st['hr'][0:1].shape
             return [ops.render_average([hr1.reshape(shp), hr2.reshape(shp), hr3.reshape(shp)], src, T, self.hc, self.wc, self.warp_mode,
                                        footprint=fp)]
         return [st['out'].clone()]
+
+    @torch.no_grad()
+    def push_u8(self, img1, img2, img3):
+        """One DECODED frame triple: uint8 [H,W,3] device tensors (cv2 layout) -> list of stitched video frames uint8 [Hc,Wc,3]; byte for
+        byte ops.ingest_u8 -> push -> ops.canvas_to_u8 (see OnlineStitcher.push_u8)."""
+        imgs = (img1, img2, img3)
+        if any(i.dtype != torch.uint8 or i.dim() != 3 or i.shape[-1] != 3 or tuple(i.shape) != tuple(img1.shape) for i in imgs):
+            raise ValueError('push_u8 takes three uint8 [H,W,3] frames')
+        if self.static is not None and self._direct() and type(self)._push_static is ThreeViewOnlineStitcher._push_static:
+            return self._push_static(None, None, None, None, None, None, u8=tuple(i.contiguous() for i in imgs))
+        hr, lr = ops.ingest_u8(torch.stack(imgs, 0), pipeline.LR_H, pipeline.LR_W)
+        frames = self.push(hr[0:1], hr[1:2], hr[2:3], lr[0:1], lr[1:2], lr[2:3])
+        return [ops.canvas_to_u8(f.reshape((1,) + tuple(f.shape[-3:])))[0] for f in frames]
 
     @torch.no_grad()
     def push(self, hr1, hr2, hr3, lr1, lr2, lr3):

@@ -575,6 +575,41 @@ def test_direct_render_is_frame_neutral(dev, hip_nets, clip16, monkeypatch):
             assert torch.equal(x, y)
 
 
+def test_push_u8_streams_decoded_frames_byte_for_byte(dev, hip_nets):
+    """push_u8: decoded uint8 frames in, uint8 video frames out.  Steady state: the cv2-exact resize writes the graph's LR inputs, the
+    render samples the uint8 frames and writes the uint8 frame (no fp32 planes, no fp32 canvas).  Equal, byte for byte, to
+    ingest_u8 -> push -> canvas_to_u8 on a second stitcher -- two views, three views, and a pipelined stitcher (fallback route)."""
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher, PipelinedOnlineStitcher
+    n, h, w = 12, 360, 640
+    hr, _ = synth.make_clip(n, h, w, seed=13, views=3)
+    u8 = [[f.reshape(3, h, w).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().to(dev) for f in v] for v in hr]     # [H,W,3]
+    def reference(cls, views):
+        st = cls(hip_nets, h, w)
+        out = []
+        for t in range(18):
+            i = t % n
+            hrf, lrf = ops.ingest_u8(torch.stack([u8[v][i] for v in range(views)], 0), 360, 480)
+            args = [hrf[v:v + 1] for v in range(views)] + [lrf[v:v + 1] for v in range(views)]
+            out += [ops.canvas_to_u8(f.reshape((1,) + tuple(f.shape[-3:])))[0] for f in st.push(*args)]
+        if hasattr(st, 'flush'):
+            out += [ops.canvas_to_u8(f.reshape((1,) + tuple(f.shape[-3:])))[0] for f in st.flush()]
+        return out
+    for cls, views in ((OnlineStitcher, 2), (ThreeViewOnlineStitcher, 3), (PipelinedOnlineStitcher, 2)):
+        st = cls(hip_nets, h, w)
+        got = []
+        for t in range(18):
+            i = t % n
+            got += st.push_u8(*[u8[v][i] for v in range(views)])
+        if hasattr(st, 'flush_u8'):
+            got += st.flush_u8()
+        ref = reference(cls, views)
+        torch.cuda.synchronize()
+        assert len(got) == len(ref) == 18
+        for a, b in zip(got, ref):
+            assert a.dtype == torch.uint8 and tuple(a.shape) == (st.hc, st.wc, 3) and torch.equal(a, b)
+
+
 def test_tps_solve_round6_kernel_against_round4(dev, request):
     """tps_solve_kernel of round 6 (four waves, lane = row, one barrier per column, pivot search under the previous update) against
     the round-4 kernel kept in the tuning build (`ss_tps_solve_r4`): same pivot rule and factors, the update an fma instead of
