@@ -627,7 +627,24 @@ def other_configs(nets, dev, args):
     entry('720p 2-view streaming from decoded uint8 frames to uint8 video frames (push_u8)', 200, time.perf_counter() - t0, 1, st8.hc, st8.wc,
           note='device-resident uint8 [H,W,3] frames in, uint8 [Hc,Wc,3] out; the cv2-exact resize feeds the graph, the render samples '
                'the uint8 frames and writes the uint8 frame: byte for byte ingest_u8 -> push -> canvas_to_u8')
-    del st8, u8
+    # ... and the whole loop of the reference: uint8 frames in pinned HOST memory in, uint8 frames in pinned host memory out, one pair
+    # per iteration, PCIe both ways beside the pushes (HostFrameStream: upload / compute / download streams)
+    from stabstitch2_amd.online import HostFrameStream
+    hp = [[f.cpu().pin_memory() for f in v] for v in u8]
+    runner = HostFrameStream(OnlineStitcher(nets, 720, 1280))
+    for _ in runner.run(tuple(hp[v][t % n] for v in range(2)) for t in range(40)):      # window fill, capture, first replays
+        pass
+    sync()
+    t0 = time.perf_counter()
+    nout = sum(1 for _ in runner.run(tuple(hp[v][t % n] for v in range(2)) for t in range(300)))
+    sync()
+    dth = time.perf_counter() - t0
+    assert nout == 300
+    entry('720p 2-view streaming from host memory to host memory: pinned uint8 frames in, one pair per push, pinned uint8 frames out', 300,
+          dth, 1, runner.st.hc, runner.st.wc,
+          note='the reference`s loop shape end to end (test_online_tra.py:250-417) at batch 1: 5.5 MB up + ~4.7 MB down per push over PCIe '
+               'on their own HIP streams beside the push (push_u8 on the uploaded frames); frames byte-identical to push_u8')
+    del st8, u8, hp, runner
     std = OnlineStitcher(nets, 720, 1280, deterministic=True)
     for t in range(12):
         std.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
@@ -1061,7 +1078,7 @@ def main():
                 'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
                 'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push'),
                 'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
-                'streaming_pipelined_fps': pick('streaming, two pushes in flight'), 'streaming_u8_fps': pick('streaming from decoded uint8'),
+                'streaming_pipelined_fps': pick('streaming, two pushes in flight'), 'streaming_u8_fps': pick('streaming from decoded uint8'), 'streaming_host_u8_fps': pick('streaming from host memory'),
                 'streaming_8_streams_pipelined_fps': pick('streams per push, two pushes in flight'),
                 'three_view_streaming_pipelined_fps': pick('3-view streaming, two pushes in flight'),
                 'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),

@@ -1431,3 +1431,106 @@ class PipelinedThreeViewOnlineStitcher(_TwoInFlight, ThreeViewOnlineStitcher):
 
     def _push_static(self, hr1, hr2, hr3, lr1, lr2, lr3):
         return self._push_pipelined(hr1, hr2, hr3, lr1, lr2, lr3)
+
+
+class HostFrameStream:
+    """The reference's frame loop end to end, one pair (or triple) at a time: decoded uint8 frames in HOST memory in, stitched uint8
+    video frames in pinned host memory out (test_online_tra.py:250-278 reads and resizes a frame pair per iteration, :409-417 writes
+    the fused frame) -- the PCIe copies of neighbouring pushes hidden behind the current push on three HIP streams:
+
+        st = OnlineStitcher(nets, H, W)                            # or ThreeViewOnlineStitcher
+        for frame in HostFrameStream(st).run(source):              # source yields (img1, img2[, img3]) uint8 [H,W,3] host frames
+            writer.write(frame.numpy())                            # uint8 [Hc,Wc,3], pinned host memory
+
+    The upload of pair t + prefetch is enqueued before pair t's launches (`stitcher.push_u8` on the compute stream: the resize feeds the
+    graph, the render samples the uploaded uint8 frames and writes the uint8 frame); the download of push t - 1's frame is enqueued
+    behind push t's launches and runs beside them.  Which copy may start is decided on the HOST, not by GPU-side waits of a copy stream
+    on a compute event: with pushes of 0.8 ms those waits cost 0.13 - 0.17 ms each and serialised copies and compute (1.08 ms per push;
+    `tools/diag_host_stream2.py`) -- the host waits for push t - 1's end event while push t is already queued, and a staging slot is reused
+    only when its last reader is known to have ended.  Frames come out in order, `depth` frames late at most; a yielded tensor stays
+    valid until `depth` more frames have been yielded.  Pinned (page-locked) input frames upload asynchronously; pageable ones (numpy
+    arrays) work and stall the loop for their copy."""
+
+    def __init__(self, stitcher, depth=4, prefetch=2, streams=None):
+        self.st, self.dev = stitcher, stitcher.dev
+        self.depth, self.prefetch = int(depth), max(1, int(prefetch))
+        self.up, self.comp, self.down = streams if streams is not None else pipeline.io_streams(self.dev)
+        self._in, self._free, self._k = None, None, 0          # ring of prefetch + 3 uploaded pairs and the end events of their readers
+        self._host, self._hk = None, 0                          # ring of 2 depth + 9 pinned result frames (7 arrive at once)
+
+    def _stage(self, frames):
+        src = [torch.from_numpy(f) if not torch.is_tensor(f) else f for f in frames]
+        n = self.prefetch + 3
+        if self._in is None or tuple(self._in[0][0].shape) != tuple(src[0].shape) or len(self._in[0]) != len(src):
+            torch.cuda.synchronize(self.dev)
+            self._in = [[torch.empty(tuple(t.shape), dtype=torch.uint8, device=self.dev) for t in src] for _ in range(n)]
+            self._free = [None] * n
+        j = self._k % n
+        self._k += 1
+        if self._free[j] is not None:
+            self._free[j].synchronize()          # host-side: the push that read this slot ended long ago (returns at once)
+        with torch.cuda.stream(self.up):
+            for dst, t in zip(self._in[j], src):
+                dst.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.up)
+        return j, ev
+
+    def _host_slot(self, shape):
+        n = 2 * self.depth + 9
+        if self._host is None or tuple(self._host[0].shape) != tuple(shape):
+            torch.cuda.synchronize(self.dev)
+            self._host = [torch.empty(tuple(shape), dtype=torch.uint8).pin_memory() for _ in range(n)]
+        h = self._host[self._hk % n]
+        self._hk += 1
+        return h
+
+    def _download(self, item, results):
+        """item = (end event of a push, its frames): wait for the push on the HOST, then copy its frames down on the download stream."""
+        done, outs = item
+        if not outs:
+            return
+        done.synchronize()
+        with torch.cuda.stream(self.down):
+            for o in outs:
+                h = self._host_slot(o.shape)
+                h.copy_(o, non_blocking=True)
+                o.record_stream(self.down)
+                e = torch.cuda.Event()
+                e.record(self.down)
+                results.append((e, h))
+
+    @torch.no_grad()
+    def run(self, source):
+        from collections import deque
+        it = iter(source)
+        staged, results = deque(), deque()
+        prev = None                                          # the previous push: (end event, frames still on the device)
+        for _ in range(self.prefetch):
+            nxt = next(it, None)
+            if nxt is not None:
+                staged.append(self._stage(nxt))
+        while staged:
+            j, ev = staged.popleft()
+            nxt = next(it, None)
+            if nxt is not None:
+                staged.append(self._stage(nxt))              # a later pair's upload is enqueued before this pair's launches
+            with torch.cuda.stream(self.comp):
+                self.comp.wait_event(ev)
+                outs = self.st.push_u8(*self._in[j])
+                done = torch.cuda.Event()
+                done.record(self.comp)
+            self._free[j] = done
+            if prev is not None:
+                self._download(prev, results)                # push t - 1's frames go down while push t (queued above) computes
+            prev = (done, outs)
+            while len(results) > self.depth:
+                e, h = results.popleft()
+                e.synchronize()
+                yield h
+        if prev is not None:
+            self._download(prev, results)
+        while results:
+            e, h = results.popleft()
+            e.synchronize()
+            yield h

@@ -825,9 +825,11 @@ class HostClipRunner:
         slot is reused once `consumed` has been told which event ends its last reader."""
         src = [(torch.from_numpy(f) if not torch.is_tensor(f) else f) for f in clip]
         j = self._in_slot([tuple(t.shape) for t in src])
+        if self._in_free[j] is not None:
+            # the slot's last reader ended `prefetch + 1` clips ago: settled on the HOST (returns at once) -- a GPU-side wait of the copy
+            # stream on a compute event costs 0.13-0.17 ms of serialisation per edge (online.HostFrameStream, tools/diag_host_stream2.py)
+            self._in_free[j].synchronize()
         with torch.cuda.stream(self.up):
-            if self._in_free[j] is not None:
-                self.up.wait_event(self._in_free[j])
             d = self._Staged(buf[:t.shape[0]] for buf, t in zip(self._in[j], src))
             d.slot = j
             d.gen = self._in_gen

@@ -610,6 +610,33 @@ def test_push_u8_streams_decoded_frames_byte_for_byte(dev, hip_nets):
             assert a.dtype == torch.uint8 and tuple(a.shape) == (st.hc, st.wc, 3) and torch.equal(a, b)
 
 
+def test_host_frame_stream_equals_push_u8(dev, hip_nets):
+    """HostFrameStream: uint8 frames in host memory (pinned tensors and plain numpy arrays) -> uint8 frames in pinned host memory,
+    uploads / downloads of neighbouring pushes on their own streams: every frame, in order, byte for byte what push_u8 returns on the
+    device; yielded tensors stay valid for `depth` further frames."""
+    from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher, HostFrameStream
+    n, h, w = 10, 360, 640
+    hr, _ = synth.make_clip(n, h, w, seed=14, views=3)
+    host = [[f.reshape(3, h, w).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous() for f in v] for v in hr]
+    for cls, views, pinned in ((OnlineStitcher, 2, True), (ThreeViewOnlineStitcher, 3, False)):
+        seq = [tuple((host[v][t % n].pin_memory() if pinned else host[v][t % n].numpy()) for v in range(views)) for t in range(25)]
+        ref_st = cls(hip_nets, h, w)
+        ref = []
+        for fr in seq:
+            ref += [f.cpu() for f in ref_st.push_u8(*[(x if torch.is_tensor(x) else torch.from_numpy(x)).to(dev) for x in fr])]
+        runner = HostFrameStream(cls(hip_nets, h, w), depth=3)
+        got, held = [], []
+        for f in runner.run(iter(seq)):
+            assert f.is_pinned() and f.dtype == torch.uint8
+            held.append(f)
+            got.append(f.clone())
+            if len(held) > 3:                      # a frame yielded `depth` frames ago is still intact
+                assert torch.equal(held[-4], got[-4])
+        assert len(got) == len(ref) == 25
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+
+
 def test_tps_solve_round6_kernel_against_round4(dev, request):
     """tps_solve_kernel of round 6 (four waves, lane = row, one barrier per column, pivot search under the previous update) against
     the round-4 kernel kept in the tuning build (`ss_tps_solve_r4`): same pivot rule and factors, the update an fma instead of
