@@ -644,7 +644,18 @@ def other_configs(nets, dev, args):
           dth, 1, runner.st.hc, runner.st.wc,
           note='the reference`s loop shape end to end (test_online_tra.py:250-417) at batch 1: 5.5 MB up + ~4.7 MB down per push over PCIe '
                'on their own HIP streams beside the push (push_u8 on the uploaded frames); frames byte-identical to push_u8')
-    del st8, u8, hp, runner
+    runner2 = HostFrameStream(PipelinedOnlineStitcher(nets, 720, 1280))
+    for _ in runner2.run(tuple(hp[v][t % n] for v in range(2)) for t in range(40)):
+        pass
+    sync()
+    t0 = time.perf_counter()
+    nout = sum(1 for _ in runner2.run(tuple(hp[v][t % n] for v in range(2)) for t in range(300)))
+    sync()
+    dth = time.perf_counter() - t0
+    assert nout == 300
+    entry('720p 2-view streaming from host memory to host memory, two pushes in flight (HostFrameStream over PipelinedOnlineStitcher)', 300,
+          dth, 1, runner2.st.hc, runner2.st.wc, note='the same loop with push t + 1`s first half beside push t`s second half; frames byte-identical')
+    del st8, u8, hp, runner, runner2
     std = OnlineStitcher(nets, 720, 1280, deterministic=True)
     for t in range(12):
         std.push(hr[0][t:t + 1], hr[1][t:t + 1], lr[0][t:t + 1], lr[1][t:t + 1])
@@ -1078,7 +1089,7 @@ def main():
                 'streaming_fps_incl_fill': pick('streaming (batch 1'), 'streaming_steady_fps': pick('streaming (batch 1', 'fps_steady'),
                 'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push'),
                 'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
-                'streaming_pipelined_fps': pick('streaming, two pushes in flight'), 'streaming_u8_fps': pick('streaming from decoded uint8'), 'streaming_host_u8_fps': pick('streaming from host memory'),
+                'streaming_pipelined_fps': pick('streaming, two pushes in flight'), 'streaming_u8_fps': pick('streaming from decoded uint8'), 'streaming_host_u8_fps': pick('streaming from host memory to host memory: pinned'), 'streaming_host_u8_pipelined_fps': pick('streaming from host memory to host memory, two pushes'),
                 'streaming_8_streams_pipelined_fps': pick('streams per push, two pushes in flight'),
                 'three_view_streaming_pipelined_fps': pick('3-view streaming, two pushes in flight'),
                 'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),

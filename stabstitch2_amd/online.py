@@ -645,7 +645,9 @@ class _TwoInFlight:
     def flush_u8(self):
         """`flush()` for streams fed through push_u8: the last result as uint8 video frames."""
         def conv(x):
-            return ops.canvas_to_u8(x.reshape((1,) + tuple(x.shape[-3:])))[0] if torch.is_tensor(x) else [conv(y) for y in x]
+            if torch.is_tensor(x):
+                return x if x.dtype == torch.uint8 else ops.canvas_to_u8(x.reshape((1,) + tuple(x.shape[-3:])))[0]
+            return [conv(y) for y in x]
         return conv(self.flush())
 
     def overflow_report(self):
@@ -694,6 +696,14 @@ class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
 
     def _pipe_load(self, p, sa, sb, hr1, hr2, lr1, lr2):
         P = self.pipe
+        if hr1.dtype == torch.uint8:         # push_u8: decoded [H,W,3] frames -- the cv2-exact resize writes this parity's LR inputs
+            with torch.cuda.stream(sa):
+                ops.ingest_u8(hr1[None], pipeline.LR_H, pipeline.LR_W, want_hr=False, lr_out=P['lr'][p][0])
+                ops.ingest_u8(hr2[None], pipeline.LR_H, pipeline.LR_W, want_hr=False, lr_out=P['lr'][p][1])
+            for t in (hr1, hr2):
+                t.record_stream(sa)
+                t.record_stream(sb)
+            return
         with torch.cuda.stream(sa):
             P['lr'][p][0].copy_(lr1.reshape(P['lr'][p][0].shape))
             P['lr'][p][1].copy_(lr2.reshape(P['lr'][p][1].shape))
@@ -720,6 +730,8 @@ class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
         P = self.pipe
         if self._direct():
             src, T, fp = P['deferred'][p]
+            if hr1.dtype == torch.uint8:     # push_u8: the uint8 video frame straight from the uint8 frames
+                return [ops.render_average_u8([hr1, hr2], src, T, self.hc, self.wc, self.warp_mode, footprint=fp)]
             shp = (1, 3, self.h, self.w)
             return [ops.render_average([hr1.reshape(shp), hr2.reshape(shp)], src, T, self.hc, self.wc,
                                        self.warp_mode, footprint=fp)]
@@ -727,6 +739,17 @@ class PipelinedOnlineStitcher(_TwoInFlight, OnlineStitcher):
 
     def _push_static(self, hr1, hr2, lr1, lr2):
         return self._push_pipelined(hr1, hr2, lr1, lr2)
+
+    @torch.no_grad()
+    def push_u8(self, img1, img2):
+        """OnlineStitcher.push_u8 with two pushes in flight: the frames of the PREVIOUS push come back (uint8 [Hc,Wc,3]); `flush_u8()`
+        for the last.  A stream is fed through push_u8 or through push, not both."""
+        if self.static is not None and self._direct():
+            if img1.dtype != torch.uint8 or img1.dim() != 3 or img1.shape[-1] != 3 or tuple(img1.shape) != tuple(img2.shape):
+                raise ValueError('push_u8 takes two uint8 [H,W,3] frames')
+            with ops.deterministic(self.deterministic):
+                return self._push_pipelined(img1.contiguous(), img2.contiguous(), None, None)
+        return OnlineStitcher.push_u8(self, img1, img2)
 
 
 class MultiOnlineStitcher:
@@ -1530,6 +1553,12 @@ class HostFrameStream:
                 yield h
         if prev is not None:
             self._download(prev, results)
+        if hasattr(self.st, 'flush_u8'):                     # a pipelined stitcher still holds its last push's frame
+            with torch.cuda.stream(self.comp):
+                outs = self.st.flush_u8()
+                done = torch.cuda.Event()
+                done.record(self.comp)
+            self._download((done, outs), results)
         while results:
             e, h = results.popleft()
             e.synchronize()

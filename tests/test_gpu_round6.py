@@ -618,9 +618,10 @@ def test_host_frame_stream_equals_push_u8(dev, hip_nets):
     n, h, w = 10, 360, 640
     hr, _ = synth.make_clip(n, h, w, seed=14, views=3)
     host = [[f.reshape(3, h, w).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous() for f in v] for v in hr]
-    for cls, views, pinned in ((OnlineStitcher, 2, True), (ThreeViewOnlineStitcher, 3, False)):
+    from stabstitch2_amd.online import PipelinedOnlineStitcher
+    for cls, views, pinned in ((OnlineStitcher, 2, True), (ThreeViewOnlineStitcher, 3, False), (PipelinedOnlineStitcher, 2, True)):
         seq = [tuple((host[v][t % n].pin_memory() if pinned else host[v][t % n].numpy()) for v in range(views)) for t in range(25)]
-        ref_st = cls(hip_nets, h, w)
+        ref_st = (OnlineStitcher if views == 2 else ThreeViewOnlineStitcher)(hip_nets, h, w)       # (the plain stitcher is the reference)
         ref = []
         for fr in seq:
             ref += [f.cpu() for f in ref_st.push_u8(*[(x if torch.is_tensor(x) else torch.from_numpy(x)).to(dev) for x in fr])]

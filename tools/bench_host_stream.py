@@ -6,13 +6,14 @@ import stabstitch2_amd  # noqa
 import torch
 import bench
 from stabstitch2_amd import synth
-from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher, HostFrameStream
+from stabstitch2_amd.online import OnlineStitcher, ThreeViewOnlineStitcher, HostFrameStream, PipelinedOnlineStitcher
 ap = argparse.ArgumentParser()
 ap.add_argument('--pushes', type=int, default=300)
 ap.add_argument('--views', type=int, default=2)
 ap.add_argument('--dummies', type=int, default=0)
 ap.add_argument('--depth', type=int, default=4)
 ap.add_argument('--prefetch', type=int, default=2)
+ap.add_argument('--pipelined', action='store_true')
 ap.add_argument('--no-up', action='store_true')
 ap.add_argument('--no-down', action='store_true')
 ap.add_argument('--cpu-only', action='store_true')
@@ -28,7 +29,7 @@ for _ in range(args.dummies):
     with torch.cuda.stream(s):
         torch.zeros(1, device=dev)
     dummies.append(s)
-st = (ThreeViewOnlineStitcher if args.views == 3 else OnlineStitcher)(nets, 720, 1280)
+st = (ThreeViewOnlineStitcher if args.views == 3 else (PipelinedOnlineStitcher if args.pipelined else OnlineStitcher))(nets, 720, 1280)
 runner = HostFrameStream(st, depth=args.depth, prefetch=args.prefetch)
 if args.no_up:          # experiment: the frames are uploaded once, later stages reuse the slots
     real_stage = runner._stage
