@@ -684,6 +684,19 @@ def other_configs(nets, dev, args):
           note='ThreeViewOnlineStitcher, steady state (graph replays), 100 pushes; the middle view passes the trunks once')
     res['720p 3-view streaming (batch 1, one triple per push)']['graph_nodes'] = st3.graph_nodes
     del st3
+    # the three-view loop host to host: pinned uint8 triples in, pinned uint8 frames out
+    from stabstitch2_amd.online import HostFrameStream
+    hp3 = [[hr[v][i].clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().pin_memory() for i in range(n)] for v in range(3)]
+    r3 = HostFrameStream(ThreeViewOnlineStitcher(nets, 720, 1280))
+    for _ in r3.run(tuple(hp3[v][t % n] for v in range(3)) for t in range(30)):
+        pass
+    sync()
+    t0 = time.perf_counter()
+    nout = sum(1 for _ in r3.run(tuple(hp3[v][t % n] for v in range(3)) for t in range(150)))
+    sync()
+    entry('720p 3-view streaming from host memory to host memory: pinned uint8 triples in, pinned uint8 frames out', nout, time.perf_counter() - t0,
+          1, r3.st.hc, r3.st.wc, note='HostFrameStream over ThreeViewOnlineStitcher (push_u8), PCIe both ways beside the pushes')
+    del hp3, r3
     from stabstitch2_amd.online import PipelinedThreeViewOnlineStitcher
     st3 = PipelinedThreeViewOnlineStitcher(nets, 720, 1280)
     for t in range(12):
@@ -1090,6 +1103,7 @@ def main():
                 'three_view_streaming_steady_fps': pick('3-view streaming'), 'streaming_8_streams_fps': pick('8 streams per push'), 'streaming_16_streams_fps': pick('16 streams per push'),
                 'streaming_graph_nodes': pick('streaming (batch 1', 'graph_nodes'), 'three_view_streaming_graph_nodes': pick('3-view streaming', 'graph_nodes'),
                 'streaming_pipelined_fps': pick('streaming, two pushes in flight'), 'streaming_u8_fps': pick('streaming from decoded uint8'), 'streaming_host_u8_fps': pick('streaming from host memory to host memory: pinned'), 'streaming_host_u8_pipelined_fps': pick('streaming from host memory to host memory, two pushes'),
+                'three_view_streaming_host_u8_fps': pick('3-view streaming from host memory'),
                 'streaming_8_streams_pipelined_fps': pick('streams per push, two pushes in flight'),
                 'three_view_streaming_pipelined_fps': pick('3-view streaming, two pushes in flight'),
                 'deterministic_clip_fps': pick('2-view, deterministic kernel policy'), 'deterministic_streaming_fps': pick('streaming, deterministic'),
