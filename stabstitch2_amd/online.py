@@ -996,20 +996,24 @@ class MultiOnlineStitcher:
             one._render_solved(None if defer else hr1[s:s + 1], None if defer else hr2[s:s + 1], src[s], T[s], out=_DEFER if defer else out[s],
                                watch=None if watch is None else (guard, st['watch_i'][s:s + 1], st['watch_f'][s:s + 1]))
 
-    def _push_static(self, hr1, hr2, lr1, lr2):
+    def _push_static(self, hr1, hr2, lr1, lr2, u8=None):
         st = self.static
         if self.grow == 'recapture' and not self.meshes_only:
             self._poll_growth()
         if self.trunk_pair is not None and self.trunk_versions != self._versions():
             self.trunk_pair = None           # a net was reloaded / moved: restack the twin trunk and recapture
             self.graph = None
-        if self.chain:                   # (pair s = views s, s + 1: lr1 holds views 0 .. S-1, lr2's last row is view S)
-            st['lrc'][:self.S].copy_(lr1); st['lrc'][self.S:].copy_(lr2[self.S - 1:])
-        else:
-            st['lr1'].copy_(lr1); st['lr2'].copy_(lr2)
         direct = self._direct()
-        if not self.meshes_only and not direct:
-            st['hr1'].copy_(hr1); st['hr2'].copy_(hr2)
+        if u8 is not None:               # push_u8: decoded [S,H,W,3] frames of both views -- the cv2-exact resize writes the LR inputs
+            ops.ingest_u8(u8[0], pipeline.LR_H, pipeline.LR_W, want_hr=False, lr_out=st['lr1'])
+            ops.ingest_u8(u8[1], pipeline.LR_H, pipeline.LR_W, want_hr=False, lr_out=st['lr2'])
+        else:
+            if self.chain:               # (pair s = views s, s + 1: lr1 holds views 0 .. S-1, lr2's last row is view S)
+                st['lrc'][:self.S].copy_(lr1); st['lrc'][self.S:].copy_(lr2[self.S - 1:])
+            else:
+                st['lr1'].copy_(lr1); st['lr2'].copy_(lr2)
+            if not self.meshes_only and not direct:
+                st['hr1'].copy_(hr1); st['hr2'].copy_(hr2)
         if not self.use_graph:
             self._step_static()
         elif self.graph is None:
@@ -1036,6 +1040,17 @@ class MultiOnlineStitcher:
             return tuple(m.clone() for m in self.last_meshes)
         if self.grow == 'recapture':
             self._post_watch_copy()
+        if direct and u8 is not None:    # uint8 frames in, uint8 video frames out: one clip-style launch, or one launch per canvas size
+            if st['out_all'] is not None:
+                src, T, fp = self._deferred
+                one = self.single[0]
+                frames = ops.render_average_clip_u8([u8[0], u8[1]], src, T, one.hc, one.wc, self.warp_mode, footprint=fp)
+                return [[frames[s]] for s in range(self.S)]
+            res = []
+            for s, one in enumerate(self.single):
+                src, T, fp = one._deferred
+                res.append([ops.render_average_u8([u8[0][s], u8[1][s]], src, T, one.hc, one.wc, self.warp_mode, footprint=fp)])
+            return res
         if direct:                       # the graph left splines and footprints: render from the caller's frames into new tensors
             hr1, hr2 = hr1.reshape(st['hr1'].shape), hr2.reshape(st['hr2'].shape)
             if st['out_all'] is not None:
@@ -1049,6 +1064,24 @@ class MultiOnlineStitcher:
                 res.append([ops.render_average([hr1[s:s + 1], hr2[s:s + 1]], src, T, one.hc, one.wc, self.warp_mode, footprint=fp)])
             return res
         return [[o.clone()] for o in st['out']]
+
+    @torch.no_grad()
+    def push_u8(self, frames1, frames2):
+        """One DECODED frame pair of every stream: uint8 [S,H,W,3] device tensors (cv2 layout) -> S lists of stitched video frames
+        uint8 [Hc,Wc,3]; byte for byte ops.ingest_u8 -> push -> ops.canvas_to_u8 (see OnlineStitcher.push_u8)."""
+        S = self.S
+        if self.meshes_only or self.chain:
+            raise ValueError('push_u8 renders frames of independent streams: not for meshes_only / chain stitchers')
+        for f in (frames1, frames2):
+            if f.dtype != torch.uint8 or f.dim() != 4 or f.shape[0] != S or f.shape[-1] != 3 or tuple(f.shape) != tuple(frames1.shape):
+                raise ValueError('push_u8 takes two uint8 [%d,H,W,3] tensors' % S)
+        with ops.deterministic(self.deterministic):
+            if self.static is not None and self._direct() and type(self)._push_static is MultiOnlineStitcher._push_static:
+                return self._push_static(None, None, None, None, u8=(frames1.contiguous(), frames2.contiguous()))
+            hr1, lr1 = ops.ingest_u8(frames1, pipeline.LR_H, pipeline.LR_W)
+            hr2, lr2 = ops.ingest_u8(frames2, pipeline.LR_H, pipeline.LR_W)
+            outs = self._push(hr1, hr2, lr1, lr2)
+            return [[ops.canvas_to_u8(f.reshape((1,) + tuple(f.shape[-3:])))[0] for f in per] for per in outs]
 
     @torch.no_grad()
     def push(self, hr1, hr2, lr1, lr2):

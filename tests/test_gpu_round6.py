@@ -610,6 +610,32 @@ def test_push_u8_streams_decoded_frames_byte_for_byte(dev, hip_nets):
             assert a.dtype == torch.uint8 and tuple(a.shape) == (st.hc, st.wc, 3) and torch.equal(a, b)
 
 
+def test_multi_stream_push_u8(dev, hip_nets):
+    """MultiOnlineStitcher.push_u8 (S streams of decoded uint8 frames per push): byte for byte ingest_u8 -> push -> canvas_to_u8 of a
+    second MultiOnlineStitcher, window fill and steady state; canvases per stream (one uint8 render per stream) and canvases of one size
+    (one clip-style uint8 render launch)."""
+    from stabstitch2_amd import ops
+    from stabstitch2_amd.online import MultiOnlineStitcher
+    n, h, w, S = 10, 360, 640, 3
+    hr, _ = synth.make_clip(n + S, h, w, seed=15, views=2)
+    u8 = [torch.stack([f.reshape(3, h, w).clamp(0, 255).to(torch.uint8).permute(1, 2, 0) for f in v], 0).contiguous().to(dev) for v in hr]   # [n+S,H,W,3]
+    for canvases in (None, [(-30.0, 1000.0, -20.0, 400.0)] * S):
+        a = MultiOnlineStitcher(hip_nets, h, w, streams=S, canvases=canvases)
+        b = MultiOnlineStitcher(hip_nets, h, w, streams=S, canvases=canvases)
+        for t in range(16):
+            i = t % n
+            f1, f2 = u8[0][i:i + S].contiguous(), u8[1][i:i + S].contiguous()          # stream s sees frame i + s
+            got = a.push_u8(f1, f2)
+            hr1, lr1 = ops.ingest_u8(f1, 360, 480)
+            hr2, lr2 = ops.ingest_u8(f2, 360, 480)
+            ref = [[ops.canvas_to_u8(x.reshape((1,) + tuple(x.shape[-3:])))[0] for x in per] for per in b.push(hr1, hr2, lr1, lr2)]
+            torch.cuda.synchronize()
+            assert [len(p_) for p_ in got] == [len(p_) for p_ in ref]
+            for ga, rb in zip(got, ref):
+                for x, y in zip(ga, rb):
+                    assert x.dtype == torch.uint8 and torch.equal(x, y)
+
+
 def test_host_frame_stream_equals_push_u8(dev, hip_nets):
     """HostFrameStream: uint8 frames in host memory (pinned tensors and plain numpy arrays) -> uint8 frames in pinned host memory,
     uploads / downloads of neighbouring pushes on their own streams: every frame, in order, byte for byte what push_u8 returns on the
